@@ -1,0 +1,145 @@
+/* include/sigax.h -- C-ABI of the MI355X-native `siga overlap` hot path.
+ *
+ * The reference (chungongyu/siga) has no FFI layer: the seam this library replaces is the C++ class
+ * OverlapBuilder (src/overlap_builder.h:19-45) as used by Overlapping::run (src/overlap.cpp:41-47) and the
+ * per-read call OverlapBuilder::overlap() that parallel::foreach drives (src/overlap_builder.cpp:269-280,
+ * 453-457; src/parallel_framework.h:16-59).  The batch entry points below are "overlap() for a batch of
+ * reads"; index lifetime replaces FMIndex::load (src/fmindex.cpp:353-366) + SuffixArray::load
+ * (src/suffix_array.cpp:104-118).  Plain pointers and sizes only; nothing throws across this boundary;
+ * every function returns SIGAX_OK (0) or a negative error code and sigax_last_error() gives the text.
+ *
+ * All compute runs in hand-written HIP kernels for gfx950.  There is no CPU fallback: if no GPU is
+ * visible the calls fail with SIGAX_E_DEVICE.
+ */
+#ifndef SIGAX_H_
+#define SIGAX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIGAX_OK           0
+#define SIGAX_E_ARG       -1  /* bad argument */
+#define SIGAX_E_IO        -2  /* file missing / malformed (.bwt magic, .sai header) */
+#define SIGAX_E_DEVICE    -3  /* HIP error (no device, out of memory, launch failure) */
+#define SIGAX_E_CAPACITY  -4  /* a device arena overflowed and could not be grown */
+#define SIGAX_E_SUBSTRING -5  /* reserved */
+#define SIGAX_E_STATE     -6  /* call order (e.g. edges requested before read metadata was set) */
+
+/* flags of the overlap calls: OverlapBuilder ctor arguments (src/overlap_builder.h:21-24) */
+#define SIGAX_IRREDUCIBLE  1u  /* irreducible=true  (CLI: absence of -x/--exhaustive, src/overlap.cpp:43) */
+#define SIGAX_RC           2u  /* rc=true           (CLI: absence of --no-opposite-strand) */
+#define SIGAX_EDGES        4u  /* also materialise edge records (Hit2OverlapConverter, src/overlap_builder.cpp:345-375) */
+
+typedef struct sigax_index sigax_index; /* both FM-indexes + both .sai tables, resident on one GPU */
+typedef struct sigax_batch sigax_batch; /* device workspace for batches of reads */
+
+/* One OverlapBlock in the order it is serialised to the hits text (src/overlap_builder.cpp:138-141,198-201):
+ * capped pair, raw pair, length, AlignFlags (bit0 QUERYREV, bit1 TARGETREV, bit2 QUERYCOMP; :42-44). */
+typedef struct sigax_block {
+  uint64_t capped0_lo, capped0_hi, capped1_lo, capped1_hi;
+  uint64_t raw0_lo, raw0_hi, raw1_lo, raw1_hi;
+  uint32_t length;
+  uint32_t af;
+  uint64_t reserved;  /* pads the record to 80 bytes = 5 x 16 so device vector accesses stay aligned */
+} sigax_block;
+
+/* One kept overlap of Hit2OverlapConverter::convert (src/overlap_builder.cpp:345-375): read indices are
+ * positions in the indexed read set; coordinates follow from (length, af, read lengths) exactly as
+ * OverlapBlock::overlap computes them (src/overlap_builder.cpp:158-175). */
+typedef struct sigax_edge {
+  uint32_t query, target;
+  uint32_t length;
+  uint32_t af;
+} sigax_edge;
+
+typedef struct sigax_stats {
+  uint64_t n_reads;
+  uint64_t n_candidate_blocks; /* blocks pushed by OverlapBlockFinder::find, containments included */
+  uint64_t n_blocks;           /* blocks returned */
+  uint64_t n_edges;
+  uint64_t n_occ_find;         /* Occ(i) evaluations made by the block finder (N_occ_min share) */
+  uint64_t n_occ_extract;      /* ... by sub-maximal filter + irreducible extraction */
+  uint64_t n_substring;        /* reads flagged substring (SS:i:1) */
+  uint64_t n_slow_reads;       /* reads that needed the general (serial) filter/extract kernel */
+  uint64_t n_extract_errors;   /* reads where extract() hit "substring read found" (src/overlap_builder.cpp:754-757) */
+} sigax_stats;
+
+typedef struct sigax_result {
+  uint32_t     n_reads;
+  uint64_t*    block_offs;  /* n_reads+1; blocks of read r are blocks[block_offs[r] .. block_offs[r+1]) in the
+                               reference's list order */
+  sigax_block* blocks;
+  uint8_t*     substring;   /* n_reads; OverlapResult::substring (src/overlap_builder.cpp:211-216) */
+  uint64_t     n_edges;
+  sigax_edge*  edges;       /* only with SIGAX_EDGES; in hits order = the ED order of the reference at -t 1 */
+  sigax_stats  stats;
+} sigax_result;
+
+typedef struct sigax_index_info {
+  uint64_t n_symbols;   /* BWT length (= sum(len+1)) per strand */
+  uint64_t n_strings;   /* reads */
+  uint64_t device_bytes;
+  uint64_t pred[5];     /* C[] of the forward index: FMIndex::getPC (src/fmindex.h:129-131) */
+  int      device;
+  int      wide;        /* 1 if positions need 64 bits */
+} sigax_index_info;
+
+const char* sigax_last_error(void);           /* thread-local text of the last failure */
+int  sigax_device_count(int* n);
+
+/* FMIndex::load x2 + SuffixArray::load x2 (src/overlap.cpp:41-42, src/overlap_builder.cpp:466).  The .sai
+ * paths may be NULL when SIGAX_EDGES is never requested. */
+int  sigax_index_open(const char* bwt_path, const char* rbwt_path, const char* sai_path, const char* rsai_path,
+                      int device, sigax_index** out);
+/* Same from memory: RL units exactly as in the .bwt payload (src/rlstring.h:10-63), read ids of the .sai lines. */
+int  sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const uint8_t* rruns, uint64_t n_rruns,
+                          uint64_t n_symbols, uint64_t n_strings, const uint32_t* sai, const uint32_t* rsai,
+                          int device, sigax_index** out);
+void sigax_index_close(sigax_index*);
+int  sigax_index_info_get(const sigax_index*, sigax_index_info* out);
+/* Per-read metadata Hit2OverlapConverter keeps (ReadInfo{name,length}, src/overlap_builder.cpp:333-343).
+ * name_rank[i] = rank of read i's name among all names under std::string operator< (equal names, equal rank):
+ * the dedup rule of src/overlap_builder.cpp:358,365 needs only equality and order of names. */
+int  sigax_index_set_reads(sigax_index*, const uint32_t* lengths, const uint32_t* name_rank, uint64_t n);
+
+/* FMIndex::getOcc(i) for many positions (src/fmindex.cpp:320-323): which = 0 forward, 1 reverse index;
+ * counts5[5*k..] = Occ($,A,C,G,T) inclusive of positions[k]; position 2^64-1 gives zeros. Host buffers. */
+int  sigax_occ_batch(sigax_index*, int which, const uint64_t* positions, uint64_t n, uint64_t* counts5);
+/* FMIndex::Interval::occurrences (src/fmindex.h:80-86) for n k-mers of length k on the forward index. */
+int  sigax_kmer_count_batch(sigax_index*, const char* kmers, uint32_t k, uint64_t n, uint64_t* counts);
+
+/* OverlapBuilder::overlap for a batch (host buffers in, host buffers out).  seqs = concatenated read bytes,
+ * offs[n_reads+1]; read r of the batch is read `read_base + r` of the indexed set (only used for edges).
+ * The result is filled with malloc'd arrays; release with sigax_result_free. */
+int  sigax_overlap_batch(sigax_index*, const char* seqs, const uint64_t* offs, uint32_t n_reads, uint32_t read_base,
+                         uint32_t min_overlap, uint32_t flags, sigax_result* out);
+void sigax_result_free(sigax_result*);
+
+/* Device-resident pipeline (what a batching runtime and bench.py use). */
+int  sigax_batch_create(sigax_index*, uint32_t max_reads, uint64_t max_bases, uint32_t max_read_len, sigax_batch** out);
+void sigax_batch_destroy(sigax_batch*);
+/* Copy reads to the device (async on `stream`, a hipStream_t or NULL). */
+int  sigax_batch_upload(sigax_batch*, const char* seqs, const uint64_t* offs, uint32_t n_reads, void* stream);
+/* Use reads that already sit in device memory (d_seqs bytes, d_offs u64[n_reads+1]); max_len = longest read. */
+int  sigax_batch_set_device_reads(sigax_batch*, const void* d_seqs, const void* d_offs, uint32_t n_reads,
+                                  uint64_t n_bases, uint32_t max_len);
+/* Enqueue the whole path on `stream`: find -> filter/extract -> order -> edges.  Asynchronous. */
+int  sigax_batch_run(sigax_batch*, uint32_t read_base, uint32_t min_overlap, uint32_t flags, void* stream);
+/* Wait for the stream, check arena overflow flags (growing arenas and re-running if needed), fill stats. */
+int  sigax_batch_finish(sigax_batch*, void* stream, sigax_stats* stats);
+/* Device pointers of the finished batch's outputs (valid until the next run on this batch). */
+int  sigax_batch_device_outputs(sigax_batch*, const sigax_block** d_blocks, const uint64_t** d_block_offs,
+                                const uint8_t** d_substring, const sigax_edge** d_edges);
+int  sigax_batch_download(sigax_batch*, sigax_result* out);
+/* Device time of each kernel of the last finished run, measured with HIP events on the run's stream:
+ * ms[0] find, ms[1] filter/extract (fast), ms[2] filter/extract (general), ms[3] order, ms[4] edges. */
+int  sigax_batch_kernel_ms(sigax_batch*, float ms[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGAX_H_ */

@@ -454,7 +454,8 @@ struct OverlapBlockFinder {
       IntervalPair probe = ranges;
       probe.updateL('$', fmi);
       if (probe.valid()) {
-        if (stats) stats->nmin += 1;  // updateR('$') needs one new upper position (ob.cpp:899)
+        // no new position: with no DNA extension every one of the range's extensions is '$', so updateL('$')
+        // keeps the whole range and updateR('$') (ob.cpp:899) queries the two positions rext just used
         probe.updateR('$', rfmi);
         assert(probe.valid());
         if (contains != NULL) contains->push_back(OverlapBlock(probe, ranges, l, af));

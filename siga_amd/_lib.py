@@ -1,0 +1,93 @@
+"""ctypes bindings of include/sigax.h.  Fails loudly when the native library is missing."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsigax.so")
+
+SIGAX_IRREDUCIBLE = 1
+SIGAX_RC = 2
+SIGAX_EDGES = 4
+
+BLOCK_DTYPE = np.dtype([
+    ("capped0_lo", "<u8"), ("capped0_hi", "<u8"), ("capped1_lo", "<u8"), ("capped1_hi", "<u8"),
+    ("raw0_lo", "<u8"), ("raw0_hi", "<u8"), ("raw1_lo", "<u8"), ("raw1_hi", "<u8"),
+    ("length", "<u4"), ("af", "<u4"), ("reserved", "<u8")])
+EDGE_DTYPE = np.dtype([("query", "<u4"), ("target", "<u4"), ("length", "<u4"), ("af", "<u4")])
+assert BLOCK_DTYPE.itemsize == 80 and EDGE_DTYPE.itemsize == 16
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "n_reads", "n_candidate_blocks", "n_blocks", "n_edges", "n_occ_find", "n_occ_extract", "n_substring",
+        "n_slow_reads", "n_extract_errors")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class Result(C.Structure):
+    _fields_ = [("n_reads", C.c_uint32), ("block_offs", C.POINTER(C.c_uint64)), ("blocks", C.c_void_p),
+                ("substring", C.POINTER(C.c_uint8)), ("n_edges", C.c_uint64), ("edges", C.c_void_p), ("stats", Stats)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("n_symbols", C.c_uint64), ("n_strings", C.c_uint64), ("device_bytes", C.c_uint64),
+                ("pred", C.c_uint64 * 5), ("device", C.c_int), ("wide", C.c_int)]
+
+
+# every symbol include/sigax.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "sigax_last_error", "sigax_device_count", "sigax_index_open", "sigax_index_open_mem", "sigax_index_close",
+    "sigax_index_info_get", "sigax_index_set_reads", "sigax_occ_batch", "sigax_kmer_count_batch",
+    "sigax_overlap_batch", "sigax_result_free", "sigax_batch_create", "sigax_batch_destroy", "sigax_batch_upload",
+    "sigax_batch_set_device_reads", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
+    "sigax_batch_download", "sigax_batch_kernel_ms",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libsigax.so.  No fallback: a missing library is an error, not a slow path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "siga_amd native library missing: %s (build it with `python -m siga_amd.build` or "
+            "__graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, cp, ci = C.c_void_p, C.c_uint32, C.c_uint64, C.c_char_p, C.c_int
+    pvp = C.POINTER(C.c_void_p)
+    L.sigax_last_error.restype = cp
+    L.sigax_device_count.argtypes = [C.POINTER(ci)]
+    L.sigax_index_open.argtypes = [cp, cp, cp, cp, ci, pvp]
+    L.sigax_index_open_mem.argtypes = [vp, u64, vp, u64, u64, u64, vp, vp, ci, pvp]
+    L.sigax_index_close.argtypes = [vp]
+    L.sigax_index_close.restype = None
+    L.sigax_index_info_get.argtypes = [vp, C.POINTER(IndexInfo)]
+    L.sigax_index_set_reads.argtypes = [vp, vp, vp, u64]
+    L.sigax_occ_batch.argtypes = [vp, ci, vp, u64, vp]
+    L.sigax_kmer_count_batch.argtypes = [vp, cp, u32, u64, vp]
+    L.sigax_overlap_batch.argtypes = [vp, cp, vp, u32, u32, u32, u32, C.POINTER(Result)]
+    L.sigax_result_free.argtypes = [C.POINTER(Result)]
+    L.sigax_result_free.restype = None
+    L.sigax_batch_create.argtypes = [vp, u32, u64, u32, pvp]
+    L.sigax_batch_destroy.argtypes = [vp]
+    L.sigax_batch_destroy.restype = None
+    L.sigax_batch_upload.argtypes = [vp, cp, vp, u32, vp]
+    L.sigax_batch_set_device_reads.argtypes = [vp, vp, vp, u32, u64, u32]
+    L.sigax_batch_run.argtypes = [vp, u32, u32, u32, vp]
+    L.sigax_batch_finish.argtypes = [vp, vp, C.POINTER(Stats)]
+    L.sigax_batch_device_outputs.argtypes = [vp, pvp, pvp, pvp, pvp]
+    L.sigax_batch_download.argtypes = [vp, C.POINTER(Result)]
+    L.sigax_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 5)]
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().sigax_last_error().decode(errors="replace")

@@ -1,0 +1,37 @@
+"""Build the in-tree native library: siga_amd/lib/libsigax.so (HIP kernels + C-ABI, gfx950)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib", "libsigax.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SOURCES = ["sigax_kernels.hip", "sigax_api.cpp"]
+HEADERS = ["sigax_kernels.h", "fm_layout.h", os.path.join(ROOT, "include", "sigax.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_libsigax(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "-Wno-unused-value",
+           "-I" + os.path.join(ROOT, "include"), "-o", LIB] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_libsigax(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,49 @@
+// siga_amd/csrc/fm_layout.h -- HBM layout of one FM-index strand and of the per-batch arenas.
+//
+// On disk the index stays the reference's 1-byte run-length units (src/rlstring.h:10-63, src/bwt.cpp:34-190).
+// In HBM it is decoded once into a fixed-rate, bit-sliced rank structure so that FMIndex::getOcc(i)
+// (src/fmindex.cpp:188-231: 48 B large marker + 12 B small marker + a serial walk over <=64 symbols of
+// runs) becomes ONE aligned 64-byte granule and a handful of v_bcnt instructions:
+//
+//   granule g (64 B) covers BWT symbols [128 g, 128 g + 128) as 4 chunks of 16 B;
+//   chunk j = { u32 cnt_j, u32 p0, u32 p1, u32 p2 }
+//     cnt_0..3 = number of A, C, G, T in BWT[0, 128 g)   (relative to the superblock in wide mode)
+//     p0,p1,p2 = bit planes of the 3-bit symbol codes of symbols [128 g + 32 j, +32); bit k = symbol k
+//     codes: $=0 A=1 C=2 G=3 T=4 (src/alphabet.h:14) so  A = p0&~p1, C = p1&~p0, G = p0&p1, T = p2.
+//   Occ('$') follows from the position: Occ($, p) = p - (A + C + G + T).
+//
+// Each chunk is self-contained (its own 32 symbols + one of the four counters), so a granule can be
+// consumed by one lane (4 x global_load_dwordx4) or by a quad of lanes (one dwordx4 each + DPP reduce).
+// Two adjacent granules form one 128-byte line with counters at symbol 0 and symbol 128.
+// 4 bits per symbol: C2 (1.51e8 symbols) = 75.5 MB per strand, C5 (1.255e10) = 6.3 GB per strand.
+#ifndef SIGA_AMD_FM_LAYOUT_H_
+#define SIGA_AMD_FM_LAYOUT_H_
+
+#include <stdint.h>
+
+#define SIGAX_GRANULE_SYMS 128
+#define SIGAX_GRANULE_BYTES 64
+#define SIGAX_SUPER_SHIFT 32  /* wide mode: u64 counters every 2^32 symbols */
+
+/* AlignFlags of the four finds of OverlapBuilder::overlap (src/overlap_builder.cpp:52-55,1124-1132), by chain:
+ * 0 seq on fmi (SuffixPrefix 000), 1 revcomp(seq) on fmi (PrefixPrefix qr,qc = 101b),
+ * 2 reverse(seq) on rfmi (PrefixSuffix qr,tr = 011b), 3 complement(seq) on rfmi (SuffixSuffix tr,qc = 110b). */
+#define SIGAX_AF_CHAIN0 0u
+#define SIGAX_AF_CHAIN1 5u
+#define SIGAX_AF_CHAIN2 3u
+#define SIGAX_AF_CHAIN3 6u
+
+struct FmStrand {
+  const uint32_t* granules;  /* n_granules x 16 u32 */
+  const unsigned long long* super;    /* [n_super][4] absolute A,C,G,T counts at each superblock start (wide mode) */
+  unsigned long long n;             /* symbols */
+  unsigned long long C[5];           /* FMIndex::_pred (src/fmindex.cpp:156-160) */
+  unsigned long long total[5];         /* symbol totals = Occ(c, n-1) */
+};
+
+/* chain_cnt word written by the block finder for every (read, chain) */
+#define SIGAX_CC_COUNT_MASK 0x0FFFFFFFu
+#define SIGAX_CC_CONTAIN    0x40000000u  /* a containment block sits in the chain's last slot */
+#define SIGAX_CC_SUBSTRING  0x80000000u  /* this find set OverlapResult::substring */
+
+#endif

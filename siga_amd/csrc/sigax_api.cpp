@@ -1,0 +1,719 @@
+// siga_amd/csrc/sigax_api.cpp -- implementation of include/sigax.h: index lifetime, device workspaces and the
+// launch sequence of the overlap path.  Compiled with hipcc together with sigax_kernels.hip into libsigax.so.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sigax_kernels.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ------------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return fail(SIGAX_E_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" const char* sigax_last_error(void) { return g_err; }
+
+extern "C" int sigax_device_count(int* n) {
+  if (!n) return fail(SIGAX_E_ARG, "n is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *n = 0;
+    return fail(SIGAX_E_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *n = c;
+  return SIGAX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// index
+// ------------------------------------------------------------------------------------------------------
+struct sigax_index {
+  int device;
+  bool wide;
+  FmStrand st[2];  // 0 forward (.bwt), 1 reverse (.rbwt); pointers are device pointers
+  void* d_gran[2];
+  void* d_super[2];
+  uint32_t* d_sai[2];
+  u64 n_sai;
+  uint32_t* d_read_len;
+  uint32_t* d_name_rank;
+  u64 n_meta;
+  u64 n_symbols, n_strings, device_bytes;
+};
+
+// RL units (src/rlstring.h:10-63) -> 64-byte rank granules (fm_layout.h)
+static int encode_strand(const uint8_t* runs, u64 nruns, u64 nsym, bool wide, std::vector<uint32_t>* gran,
+                         std::vector<u64>* super, u64 C[5], u64 total[5]) {
+  u64 ngran = nsym / SIGAX_GRANULE_SYMS + 1;
+  gran->assign(ngran * 16, 0u);
+  super->clear();
+  u64 cnt[5] = {0, 0, 0, 0, 0};
+  u64 sbase[4] = {0, 0, 0, 0};
+  uint32_t* g = gran->data();
+  auto header = [&](u64 gi) {
+    if ((gi * SIGAX_GRANULE_SYMS) % (1ull << SIGAX_SUPER_SHIFT) == 0) {
+      for (int j = 0; j < 4; ++j) {
+        sbase[j] = wide ? cnt[1 + j] : 0;
+        super->push_back(sbase[j]);
+      }
+    }
+    for (int j = 0; j < 4; ++j) g[gi * 16 + j * 4] = (uint32_t)(cnt[1 + j] - sbase[j]);
+  };
+  header(0);
+  u64 pos = 0;
+  for (u64 i = 0; i < nruns; ++i) {
+    uint32_t sym = runs[i] >> 5, c = runs[i] & 31u;
+    if (sym > 4) return fail(SIGAX_E_IO, "invalid RL unit 0x%02x at run %llu", runs[i], i);
+    if (pos + c > nsym) return fail(SIGAX_E_IO, "run lengths exceed the symbol count in the header");
+    for (uint32_t k = 0; k < c; ++k) {
+      u64 gi = pos >> 7;
+      uint32_t r = (uint32_t)pos & 127u, j = r >> 5, b = r & 31u;
+      uint32_t* ch = g + gi * 16 + j * 4;
+      ch[1] |= (sym & 1u) << b;
+      ch[2] |= ((sym >> 1) & 1u) << b;
+      ch[3] |= ((sym >> 2) & 1u) << b;
+      ++cnt[sym];
+      ++pos;
+      if ((pos & 127u) == 0) header(pos >> 7);
+    }
+  }
+  if (pos != nsym) return fail(SIGAX_E_IO, "run lengths (%llu) do not add up to the symbol count (%llu)", pos, nsym);
+  for (int k = 0; k < 5; ++k) total[k] = cnt[k];
+  C[0] = 0;
+  for (int k = 1; k < 5; ++k) C[k] = C[k - 1] + cnt[k - 1];  // src/fmindex.cpp:156-160
+  return SIGAX_OK;
+}
+
+static int read_file(const char* path, std::vector<uint8_t>* out) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(SIGAX_E_IO, "cannot open %s", path);
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out->resize(n > 0 ? (size_t)n : 0);
+  if (n > 0 && fread(out->data(), 1, (size_t)n, f) != (size_t)n) {
+    fclose(f);
+    return fail(SIGAX_E_IO, "short read on %s", path);
+  }
+  fclose(f);
+  return SIGAX_OK;
+}
+
+// src/bwt.cpp:59-98: u16 magic 0xCACA, u64 nStrings, u64 nSymbols, u64 nRuns, i32 flag, then the RL units
+static int parse_bwt(const std::vector<uint8_t>& buf, const char* path, u64* nstrings, u64* nsym, const uint8_t** runs,
+                     u64* nruns) {
+  if (buf.size() < 30) return fail(SIGAX_E_IO, "%s: truncated .bwt header", path);
+  uint16_t magic;
+  memcpy(&magic, buf.data(), 2);
+  if (magic != 0xCACA) return fail(SIGAX_E_IO, "%s: bad .bwt magic", path);
+  memcpy(nstrings, buf.data() + 2, 8);
+  memcpy(nsym, buf.data() + 10, 8);
+  memcpy(nruns, buf.data() + 18, 8);
+  if (buf.size() < 30 + *nruns) return fail(SIGAX_E_IO, "%s: truncated .bwt payload", path);
+  *runs = buf.data() + 30;
+  return SIGAX_OK;
+}
+
+// src/suffix_array.cpp:57-95: "51914\n<strings>\n<elems>\n" then elems lines "<readIdx> <j>"
+static int parse_sai(const std::vector<uint8_t>& buf, const char* path, std::vector<uint32_t>* out) {
+  const char* p = (const char*)buf.data();
+  const char* e = p + buf.size();
+  auto next = [&](u64* v) -> bool {
+    while (p < e && (*p < '0' || *p > '9')) ++p;
+    if (p >= e) return false;
+    u64 x = 0;
+    while (p < e && *p >= '0' && *p <= '9') x = x * 10 + (u64)(*p++ - '0');
+    *v = x;
+    return true;
+  };
+  u64 magic = 0, strings = 0, elems = 0;
+  if (!next(&magic) || magic != 0xCACA) return fail(SIGAX_E_IO, "%s: bad .sai magic", path);
+  if (!next(&strings) || !next(&elems)) return fail(SIGAX_E_IO, "%s: truncated .sai header", path);
+  out->resize(elems);
+  for (u64 i = 0; i < elems; ++i) {
+    u64 a, b;
+    if (!next(&a) || !next(&b)) return fail(SIGAX_E_IO, "%s: truncated .sai body", path);
+    (*out)[i] = (uint32_t)a;
+  }
+  return SIGAX_OK;
+}
+
+static int upload(const void* src, size_t bytes, void** dst, u64* acct) {
+  *dst = nullptr;
+  size_t alloc = bytes ? bytes : 16;
+  HIP_TRY(hipMalloc(dst, alloc));
+  if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  if (acct) *acct += alloc;
+  return SIGAX_OK;
+}
+
+extern "C" void sigax_index_close(sigax_index* ix) {
+  if (!ix) return;
+  hipSetDevice(ix->device);
+  for (int s = 0; s < 2; ++s) {
+    if (ix->d_gran[s]) hipFree(ix->d_gran[s]);
+    if (ix->d_super[s]) hipFree(ix->d_super[s]);
+    if (ix->d_sai[s]) hipFree(ix->d_sai[s]);
+  }
+  if (ix->d_read_len) hipFree(ix->d_read_len);
+  if (ix->d_name_rank) hipFree(ix->d_name_rank);
+  delete ix;
+}
+
+extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const uint8_t* rruns, uint64_t n_rruns,
+                                    uint64_t n_symbols, uint64_t n_strings, const uint32_t* sai, const uint32_t* rsai,
+                                    int device, sigax_index** out) {
+  if (!out || (!runs && n_runs) || (!rruns && n_rruns)) return fail(SIGAX_E_ARG, "NULL argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(SIGAX_E_DEVICE, "no HIP device visible: the overlap path has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(SIGAX_E_ARG, "device %d out of range (%d visible)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  sigax_index* ix = new sigax_index();
+  memset(ix, 0, sizeof(*ix));
+  ix->device = device;
+  ix->n_symbols = n_symbols;
+  ix->n_strings = n_strings;
+  ix->wide = n_symbols >= 0xFFFFFFF0ull;
+  const uint8_t* rr[2] = {runs, rruns};
+  u64 nr[2] = {n_runs, n_rruns};
+  for (int s = 0; s < 2; ++s) {
+    std::vector<uint32_t> gran;
+    std::vector<u64> super;
+    u64 C[5], total[5];
+    int rc = encode_strand(rr[s], nr[s], n_symbols, ix->wide, &gran, &super, C, total);
+    if (rc == SIGAX_OK) rc = upload(gran.data(), gran.size() * 4, &ix->d_gran[s], &ix->device_bytes);
+    if (rc == SIGAX_OK) rc = upload(super.data(), super.size() * 8, &ix->d_super[s], &ix->device_bytes);
+    if (rc != SIGAX_OK) {
+      sigax_index_close(ix);
+      return rc;
+    }
+    ix->st[s].granules = (const uint32_t*)ix->d_gran[s];
+    ix->st[s].super = (const u64*)ix->d_super[s];
+    ix->st[s].n = n_symbols;
+    for (int k = 0; k < 5; ++k) {
+      ix->st[s].C[k] = C[k];
+      ix->st[s].total[k] = total[k];
+    }
+  }
+  for (int k = 0; k < 5; ++k) {
+    if (ix->st[0].total[k] != ix->st[1].total[k]) {
+      sigax_index_close(ix);
+      return fail(SIGAX_E_IO, "forward and reverse BWT hold different symbol counts: not a .bwt/.rbwt pair");
+    }
+  }
+  if (sai && rsai) {
+    const uint32_t* ss[2] = {sai, rsai};
+    for (int s = 0; s < 2; ++s) {
+      int rc = upload(ss[s], n_strings * 4, (void**)&ix->d_sai[s], &ix->device_bytes);
+      if (rc != SIGAX_OK) {
+        sigax_index_close(ix);
+        return rc;
+      }
+    }
+    ix->n_sai = n_strings;
+  }
+  *out = ix;
+  return SIGAX_OK;
+}
+
+extern "C" int sigax_index_open(const char* bwt_path, const char* rbwt_path, const char* sai_path, const char* rsai_path,
+                                int device, sigax_index** out) {
+  if (!bwt_path || !rbwt_path || !out) return fail(SIGAX_E_ARG, "NULL argument");
+  std::vector<uint8_t> fb, rb, sb, rsb;
+  int rc;
+  if ((rc = read_file(bwt_path, &fb)) != SIGAX_OK) return rc;
+  if ((rc = read_file(rbwt_path, &rb)) != SIGAX_OK) return rc;
+  u64 ns[2], nsym[2], nruns[2];
+  const uint8_t* runs[2];
+  if ((rc = parse_bwt(fb, bwt_path, &ns[0], &nsym[0], &runs[0], &nruns[0])) != SIGAX_OK) return rc;
+  if ((rc = parse_bwt(rb, rbwt_path, &ns[1], &nsym[1], &runs[1], &nruns[1])) != SIGAX_OK) return rc;
+  if (ns[0] != ns[1] || nsym[0] != nsym[1]) return fail(SIGAX_E_IO, "%s and %s describe different read sets", bwt_path, rbwt_path);
+  std::vector<uint32_t> sai, rsai;
+  bool have_sai = sai_path && rsai_path && sai_path[0] && rsai_path[0];
+  if (have_sai) {
+    if ((rc = read_file(sai_path, &sb)) != SIGAX_OK) return rc;
+    if ((rc = read_file(rsai_path, &rsb)) != SIGAX_OK) return rc;
+    if ((rc = parse_sai(sb, sai_path, &sai)) != SIGAX_OK) return rc;
+    if ((rc = parse_sai(rsb, rsai_path, &rsai)) != SIGAX_OK) return rc;
+    if (sai.size() != ns[0] || rsai.size() != ns[0])
+      return fail(SIGAX_E_IO, ".sai tables (%zu, %zu entries) do not match the %llu strings of the .bwt", sai.size(), rsai.size(), ns[0]);
+  }
+  return sigax_index_open_mem(runs[0], nruns[0], runs[1], nruns[1], nsym[0], ns[0], have_sai ? sai.data() : nullptr,
+                              have_sai ? rsai.data() : nullptr, device, out);
+}
+
+extern "C" int sigax_index_info_get(const sigax_index* ix, sigax_index_info* out) {
+  if (!ix || !out) return fail(SIGAX_E_ARG, "NULL argument");
+  out->n_symbols = ix->n_symbols;
+  out->n_strings = ix->n_strings;
+  out->device_bytes = ix->device_bytes;
+  for (int k = 0; k < 5; ++k) out->pred[k] = ix->st[0].C[k];
+  out->device = ix->device;
+  out->wide = ix->wide ? 1 : 0;
+  return SIGAX_OK;
+}
+
+extern "C" int sigax_index_set_reads(sigax_index* ix, const uint32_t* lengths, const uint32_t* name_rank, uint64_t n) {
+  if (!ix || !lengths || !name_rank) return fail(SIGAX_E_ARG, "NULL argument");
+  if (n != ix->n_strings) return fail(SIGAX_E_ARG, "%llu reads given, index holds %llu", (u64)n, ix->n_strings);
+  HIP_TRY(hipSetDevice(ix->device));
+  if (ix->d_read_len) hipFree(ix->d_read_len);
+  if (ix->d_name_rank) hipFree(ix->d_name_rank);
+  ix->d_read_len = ix->d_name_rank = nullptr;
+  int rc = upload(lengths, n * 4, (void**)&ix->d_read_len, &ix->device_bytes);
+  if (rc == SIGAX_OK) rc = upload(name_rank, n * 4, (void**)&ix->d_name_rank, &ix->device_bytes);
+  if (rc == SIGAX_OK) ix->n_meta = n;
+  return rc;
+}
+
+extern "C" int sigax_occ_batch(sigax_index* ix, int which, const uint64_t* positions, uint64_t n, uint64_t* counts5) {
+  if (!ix || (n && (!positions || !counts5)) || which < 0 || which > 1) return fail(SIGAX_E_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(ix->device));
+  if (n == 0) return SIGAX_OK;
+  u64 *d_pos = nullptr, *d_out = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_pos, n * 8));
+  HIP_TRY(hipMalloc((void**)&d_out, n * 40));
+  HIP_TRY(hipMemcpy(d_pos, positions, n * 8, hipMemcpyHostToDevice));
+  launch_occ_batch(ix->st[which], ix->wide, d_pos, n, d_out, 0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(counts5, d_out, n * 40, hipMemcpyDeviceToHost));
+  hipFree(d_pos);
+  hipFree(d_out);
+  return SIGAX_OK;
+}
+
+extern "C" int sigax_kmer_count_batch(sigax_index* ix, const char* kmers, uint32_t k, uint64_t n, uint64_t* counts) {
+  if (!ix || k == 0 || (n && (!kmers || !counts))) return fail(SIGAX_E_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(ix->device));
+  if (n == 0) return SIGAX_OK;
+  unsigned char* d_k = nullptr;
+  u64* d_out = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_k, n * k));
+  HIP_TRY(hipMalloc((void**)&d_out, n * 8));
+  HIP_TRY(hipMemcpy(d_k, kmers, n * k, hipMemcpyHostToDevice));
+  launch_kmer_count(ix->st[0], ix->wide, d_k, k, n, d_out, 0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(counts, d_out, n * 8, hipMemcpyDeviceToHost));
+  hipFree(d_k);
+  hipFree(d_out);
+  return SIGAX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// batch workspace
+// ------------------------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p;
+  size_t bytes;
+  DevBuf() : p(nullptr), bytes(0) {}
+};
+
+static int ensure(DevBuf* b, size_t bytes) {
+  if (bytes <= b->bytes && b->p) return SIGAX_OK;
+  if (b->p) hipFree(b->p);
+  b->p = nullptr;
+  b->bytes = 0;
+  size_t want = bytes ? bytes : 16;
+  hipError_t e = hipMalloc(&b->p, want);
+  if (e != hipSuccess) return fail(SIGAX_E_DEVICE, "hipMalloc(%zu bytes): %s", want, hipGetErrorString(e));
+  b->bytes = want;
+  return SIGAX_OK;
+}
+
+enum { EV_START = 0, EV_FIND, EV_FX_FAST, EV_FX_GEN, EV_ORDER, EV_EDGES, EV_COUNT };
+
+struct sigax_batch {
+  sigax_index* ix;
+  uint32_t max_reads;
+  u64 max_bases;
+  uint32_t max_len;
+  DevBuf seqs_own, offs_own;
+  const unsigned char* d_seqs;
+  const u64* d_offs;
+  uint32_t n_reads;
+  u64 n_bases;
+  uint32_t cur_max_len;
+  // parameters of the last run (for the regrow-and-rerun loop)
+  uint32_t read_base, minov, flags;
+  bool ran;
+  // arenas
+  DevBuf arena, chain_cnt, pool, fin, fin_read, fin_seq, fin_cnt, substring, block_offs, outb, edge_cnt, edge_offs, edges,
+      partial, dstat;
+  uint32_t cap;
+  uint32_t pool_cap;
+  unsigned fx_grid;
+  u64 fin_cap, edge_cap;
+  hipEvent_t ev[EV_COUNT];
+  sigax_stats last;
+  u64 last_total_blocks, last_total_edges;
+  bool finished;
+};
+
+extern "C" void sigax_batch_destroy(sigax_batch* b) {
+  if (!b) return;
+  hipSetDevice(b->ix->device);
+  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->fin, &b->fin_read, &b->fin_seq,
+                   &b->fin_cnt, &b->substring, &b->block_offs, &b->outb, &b->edge_cnt, &b->edge_offs, &b->edges,
+                   &b->partial, &b->dstat};
+  for (DevBuf* d : all)
+    if (d->p) hipFree(d->p);
+  for (int i = 0; i < EV_COUNT; ++i)
+    if (b->ev[i]) hipEventDestroy(b->ev[i]);
+  delete b;
+}
+
+extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t max_bases, uint32_t max_read_len,
+                                  sigax_batch** out) {
+  if (!ix || !out) return fail(SIGAX_E_ARG, "NULL argument");
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(ix->device));
+  sigax_batch* b = new sigax_batch();
+  b->ix = ix;
+  b->max_reads = max_reads;
+  b->max_bases = max_bases;
+  b->max_len = max_read_len;
+  b->d_seqs = nullptr;
+  b->d_offs = nullptr;
+  b->n_reads = 0;
+  b->n_bases = 0;
+  b->cur_max_len = 0;
+  b->read_base = b->minov = b->flags = 0;
+  b->ran = b->finished = false;
+  b->cap = 0;
+  b->pool_cap = 0;
+  b->fx_grid = 0;
+  b->fin_cap = b->edge_cap = 0;
+  memset(&b->last, 0, sizeof(b->last));
+  b->last_total_blocks = b->last_total_edges = 0;
+  for (int i = 0; i < EV_COUNT; ++i) b->ev[i] = nullptr;
+  for (int i = 0; i < EV_COUNT; ++i) {
+    hipError_t e = hipEventCreate(&b->ev[i]);
+    if (e != hipSuccess) {
+      sigax_batch_destroy(b);
+      return fail(SIGAX_E_DEVICE, "hipEventCreate: %s", hipGetErrorString(e));
+    }
+  }
+  int rc = ensure(&b->dstat, DS_COUNT * 8);
+  if (rc != SIGAX_OK) {
+    sigax_batch_destroy(b);
+    return rc;
+  }
+  *out = b;
+  return SIGAX_OK;
+}
+
+extern "C" int sigax_batch_upload(sigax_batch* b, const char* seqs, const uint64_t* offs, uint32_t n_reads, void* stream) {
+  if (!b || (n_reads && (!seqs || !offs))) return fail(SIGAX_E_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(b->ix->device));
+  hipStream_t st = (hipStream_t)stream;
+  u64 nb = n_reads ? offs[n_reads] - offs[0] : 0;
+  if (n_reads && offs[0] != 0) return fail(SIGAX_E_ARG, "offs[0] must be 0");
+  uint32_t mx = 0;
+  for (uint32_t i = 0; i < n_reads; ++i) {
+    u64 l = offs[i + 1] - offs[i];
+    if (offs[i + 1] < offs[i] || l > 0x0FFFFFFFull) return fail(SIGAX_E_ARG, "bad offsets at read %u", i);
+    mx = std::max<uint32_t>(mx, (uint32_t)l);
+  }
+  int rc = ensure(&b->seqs_own, nb + 16);
+  if (rc == SIGAX_OK) rc = ensure(&b->offs_own, ((size_t)n_reads + 1) * 8);
+  if (rc != SIGAX_OK) return rc;
+  if (nb) HIP_TRY(hipMemcpyAsync(b->seqs_own.p, seqs, nb, hipMemcpyHostToDevice, st));
+  static const u64 zero = 0;
+  HIP_TRY(hipMemcpyAsync(b->offs_own.p, n_reads ? (const void*)offs : (const void*)&zero, ((size_t)n_reads + 1) * 8,
+                         hipMemcpyHostToDevice, st));
+  b->d_seqs = (const unsigned char*)b->seqs_own.p;
+  b->d_offs = (const u64*)b->offs_own.p;
+  b->n_reads = n_reads;
+  b->n_bases = nb;
+  b->cur_max_len = mx;
+  b->ran = b->finished = false;
+  return SIGAX_OK;
+}
+
+extern "C" int sigax_batch_set_device_reads(sigax_batch* b, const void* d_seqs, const void* d_offs, uint32_t n_reads,
+                                            uint64_t n_bases, uint32_t max_len) {
+  if (!b || (n_reads && (!d_seqs || !d_offs))) return fail(SIGAX_E_ARG, "NULL argument");
+  b->d_seqs = (const unsigned char*)d_seqs;
+  b->d_offs = (const u64*)d_offs;
+  b->n_reads = n_reads;
+  b->n_bases = n_bases;
+  b->cur_max_len = max_len;
+  b->ran = b->finished = false;
+  return SIGAX_OK;
+}
+
+static int enqueue(sigax_batch* b, hipStream_t st) {
+  sigax_index* ix = b->ix;
+  const uint32_t n = b->n_reads;
+  const bool edges = (b->flags & SIGAX_EDGES) != 0;
+  if (edges && (!ix->d_sai[0] || !ix->d_read_len))
+    return fail(SIGAX_E_STATE, "SIGAX_EDGES needs the .sai tables and sigax_index_set_reads()");
+  if (edges && (u64)b->read_base + n > ix->n_strings)
+    return fail(SIGAX_E_ARG, "read_base + n_reads exceeds the indexed read set");
+  // slots per chain: overlaps of length max(m,1)..L-1, plus one for the containment block
+  uint32_t mm = std::max<uint32_t>(b->minov, 1u);
+  b->cap = (b->cur_max_len > mm ? b->cur_max_len - mm : 0u) + 1u;
+  int rc;
+  if ((rc = ensure(&b->arena, (size_t)n * 4 * b->cap * sizeof(sigax_block))) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->chain_cnt, (size_t)n * 4 * 4)) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->fin_cnt, ((size_t)n + 1) * 4)) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->substring, (size_t)n + 16)) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->block_offs, ((size_t)n + 2) * 8)) != SIGAX_OK) return rc;
+  // general filter/extract kernel: persistent lanes with a private pool each
+  unsigned want_grid = (unsigned)std::min<u64>(512, ((u64)n + 255) / 256);
+  if (want_grid == 0) want_grid = 1;
+  uint32_t want_pool = std::max<uint32_t>(b->pool_cap, 4u * (b->cap + 2u) + 128u);
+  b->fx_grid = want_grid;
+  b->pool_cap = want_pool;
+  if ((rc = ensure(&b->pool, (size_t)want_grid * 256 * want_pool * SIGAX_ENT_BYTES)) != SIGAX_OK) return rc;
+  if (b->fin_cap == 0) b->fin_cap = (b->flags & SIGAX_IRREDUCIBLE) ? (u64)n * 8 + 1024 : (u64)n * 64 + 1024;
+  if ((rc = ensure(&b->fin, b->fin_cap * sizeof(sigax_block))) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->outb, b->fin_cap * sizeof(sigax_block))) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->fin_read, b->fin_cap * 4)) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->fin_seq, b->fin_cap * 4)) != SIGAX_OK) return rc;
+  u64 scan_n = std::max<u64>(n, b->fin_cap);
+  if ((rc = ensure(&b->partial, scan_partials_needed(scan_n) * 8)) != SIGAX_OK) return rc;
+  if (edges) {
+    if (b->edge_cap == 0) b->edge_cap = b->fin_cap * 2 + 1024;
+    if ((rc = ensure(&b->edge_cnt, (b->fin_cap + 1) * 4)) != SIGAX_OK) return rc;
+    if ((rc = ensure(&b->edge_offs, (b->fin_cap + 2) * 8)) != SIGAX_OK) return rc;
+    if ((rc = ensure(&b->edges, b->edge_cap * sizeof(sigax_edge))) != SIGAX_OK) return rc;
+  }
+  u64* dstat = (u64*)b->dstat.p;
+  HIP_TRY(hipMemsetAsync(dstat, 0, DS_COUNT * 8, st));
+  HIP_TRY(hipEventRecord(b->ev[EV_START], st));
+
+  FindArgs fa;
+  fa.fwd = ix->st[0];
+  fa.rev = ix->st[1];
+  fa.seqs = b->d_seqs;
+  fa.offs = b->d_offs;
+  fa.n_reads = n;
+  fa.minov = b->minov;
+  fa.rc = (b->flags & SIGAX_RC) ? 1u : 0u;
+  fa.cap = b->cap;
+  fa.arena = (sigax_block*)b->arena.p;
+  fa.chain_cnt = (uint32_t*)b->chain_cnt.p;
+  fa.dstat = dstat;
+  launch_find(fa, ix->wide, st);
+  HIP_TRY(hipEventRecord(b->ev[EV_FIND], st));
+  HIP_TRY(hipEventRecord(b->ev[EV_FX_FAST], st));  // the fast filter/extract kernel slots in here
+
+  FxArgs xa;
+  xa.fwd = ix->st[0];
+  xa.rev = ix->st[1];
+  xa.offs = b->d_offs;
+  xa.n_reads = n;
+  xa.cap = b->cap;
+  xa.irreducible = (b->flags & SIGAX_IRREDUCIBLE) ? 1u : 0u;
+  xa.arena = (const sigax_block*)b->arena.p;
+  xa.chain_cnt = (const uint32_t*)b->chain_cnt.p;
+  xa.pool = (Ent*)b->pool.p;
+  xa.pool_cap = b->pool_cap;
+  xa.work = nullptr;
+  xa.n_work = n;
+  xa.fin = (sigax_block*)b->fin.p;
+  xa.fin_read = (uint32_t*)b->fin_read.p;
+  xa.fin_seq = (uint32_t*)b->fin_seq.p;
+  xa.fin_cap = b->fin_cap;
+  xa.fin_cnt = (uint32_t*)b->fin_cnt.p;
+  xa.substring = (uint8_t*)b->substring.p;
+  xa.dstat = dstat;
+  launch_filter_extract(xa, ix->wide, b->fx_grid, st);
+  HIP_TRY(hipEventRecord(b->ev[EV_FX_GEN], st));
+
+  launch_scan((const uint32_t*)b->fin_cnt.p, n, (u64*)b->partial.p, (u64*)b->block_offs.p, dstat + DS_TOTAL_BLOCKS, st);
+  OrderArgs oa;
+  oa.fin = (const sigax_block*)b->fin.p;
+  oa.fin_read = (const uint32_t*)b->fin_read.p;
+  oa.fin_seq = (const uint32_t*)b->fin_seq.p;
+  oa.fin_cap = b->fin_cap;
+  oa.block_offs = (const u64*)b->block_offs.p;
+  oa.out = (sigax_block*)b->outb.p;
+  oa.out_cap = b->fin_cap;
+  oa.dstat = dstat;
+  launch_order_scatter(oa, b->fin_cap, st);
+  HIP_TRY(hipEventRecord(b->ev[EV_ORDER], st));
+
+  if (edges) {
+    EdgeArgs ea;
+    ea.blocks = (const sigax_block*)b->outb.p;
+    ea.block_offs = (const u64*)b->block_offs.p;
+    ea.n_reads = n;
+    ea.read_base = b->read_base;
+    ea.sai = ix->d_sai[0];
+    ea.rsai = ix->d_sai[1];
+    ea.n_sai = ix->n_sai;
+    ea.read_len = ix->d_read_len;
+    ea.name_rank = ix->d_name_rank;
+    ea.edge_cnt = (uint32_t*)b->edge_cnt.p;
+    ea.cnt_cap = b->fin_cap;
+    ea.edge_offs = (const u64*)b->edge_offs.p;
+    ea.edges = (sigax_edge*)b->edges.p;
+    ea.edge_cap = b->edge_cap;
+    launch_edges(ea, false, b->fin_cap, st);
+    launch_scan((const uint32_t*)b->edge_cnt.p, b->fin_cap, (u64*)b->partial.p, (u64*)b->edge_offs.p,
+                dstat + DS_TOTAL_EDGES, st);
+    launch_edges(ea, true, b->fin_cap, st);
+  }
+  HIP_TRY(hipEventRecord(b->ev[EV_EDGES], st));
+  HIP_TRY(hipGetLastError());
+  return SIGAX_OK;
+}
+
+extern "C" int sigax_batch_run(sigax_batch* b, uint32_t read_base, uint32_t min_overlap, uint32_t flags, void* stream) {
+  if (!b) return fail(SIGAX_E_ARG, "NULL batch");
+  if (b->n_reads && !b->d_seqs) return fail(SIGAX_E_STATE, "no reads set on this batch");
+  HIP_TRY(hipSetDevice(b->ix->device));
+  b->read_base = read_base;
+  b->minov = min_overlap;
+  b->flags = flags;
+  b->finished = false;
+  int rc = enqueue(b, (hipStream_t)stream);
+  b->ran = rc == SIGAX_OK;
+  return rc;
+}
+
+extern "C" int sigax_batch_finish(sigax_batch* b, void* stream, sigax_stats* stats) {
+  if (!b) return fail(SIGAX_E_ARG, "NULL batch");
+  if (!b->ran) return fail(SIGAX_E_STATE, "sigax_batch_run was not called");
+  HIP_TRY(hipSetDevice(b->ix->device));
+  hipStream_t st = (hipStream_t)stream;
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    HIP_TRY(hipStreamSynchronize(st));
+    u64 ds[DS_COUNT];
+    HIP_TRY(hipMemcpy(ds, b->dstat.p, sizeof(ds), hipMemcpyDeviceToHost));
+    if (ds[DS_FIND_OVERFLOW]) return fail(SIGAX_E_CAPACITY, "candidate arena overflow (max read length given too small?)");
+    bool again = false;
+    if (ds[DS_POOL_OVERFLOW]) {
+      if (b->pool_cap > (1u << 22)) return fail(SIGAX_E_CAPACITY, "%llu reads overflow the filter/extract pool", ds[DS_POOL_OVERFLOW]);
+      b->pool_cap *= 4;
+      again = true;
+    }
+    if (ds[DS_FIN_TOP] > b->fin_cap) {
+      b->fin_cap = ds[DS_FIN_TOP] + ds[DS_FIN_TOP] / 4 + 1024;
+      if (b->edge_cap) b->edge_cap = std::max<u64>(b->edge_cap, b->fin_cap * 2);
+      again = true;
+    }
+    if (!again && (b->flags & SIGAX_EDGES) && ds[DS_TOTAL_EDGES] > b->edge_cap) {
+      b->edge_cap = ds[DS_TOTAL_EDGES] + ds[DS_TOTAL_EDGES] / 4 + 1024;
+      again = true;
+    }
+    if (again) {
+      int rc = enqueue(b, st);
+      if (rc != SIGAX_OK) return rc;
+      continue;
+    }
+    memset(&b->last, 0, sizeof(b->last));
+    b->last.n_reads = b->n_reads;
+    b->last.n_candidate_blocks = ds[DS_CAND_BLOCKS];
+    b->last.n_blocks = ds[DS_TOTAL_BLOCKS];
+    b->last.n_edges = (b->flags & SIGAX_EDGES) ? ds[DS_TOTAL_EDGES] : 0;
+    b->last.n_occ_find = ds[DS_OCC_FIND];
+    b->last.n_occ_extract = ds[DS_OCC_EXTRACT];
+    b->last.n_substring = ds[DS_SUBSTRING];
+    b->last.n_slow_reads = ds[DS_SLOW_READS];
+    b->last.n_extract_errors = ds[DS_EXTRACT_ERRORS];
+    b->last_total_blocks = ds[DS_TOTAL_BLOCKS];
+    b->last_total_edges = b->last.n_edges;
+    b->finished = true;
+    if (stats) *stats = b->last;
+    return SIGAX_OK;
+  }
+  return fail(SIGAX_E_CAPACITY, "arenas still overflowing after 8 attempts");
+}
+
+extern "C" int sigax_batch_device_outputs(sigax_batch* b, const sigax_block** d_blocks, const uint64_t** d_block_offs,
+                                          const uint8_t** d_substring, const sigax_edge** d_edges) {
+  if (!b || !b->finished) return fail(SIGAX_E_STATE, "batch not finished");
+  if (d_blocks) *d_blocks = (const sigax_block*)b->outb.p;
+  if (d_block_offs) *d_block_offs = (const uint64_t*)b->block_offs.p;
+  if (d_substring) *d_substring = (const uint8_t*)b->substring.p;
+  if (d_edges) *d_edges = (const sigax_edge*)b->edges.p;
+  return SIGAX_OK;
+}
+
+extern "C" void sigax_result_free(sigax_result* r) {
+  if (!r) return;
+  free(r->block_offs);
+  free(r->blocks);
+  free(r->substring);
+  free(r->edges);
+  memset(r, 0, sizeof(*r));
+}
+
+extern "C" int sigax_batch_download(sigax_batch* b, sigax_result* out) {
+  if (!b || !out) return fail(SIGAX_E_ARG, "NULL argument");
+  if (!b->finished) return fail(SIGAX_E_STATE, "batch not finished");
+  HIP_TRY(hipSetDevice(b->ix->device));
+  memset(out, 0, sizeof(*out));
+  uint32_t n = b->n_reads;
+  out->n_reads = n;
+  out->stats = b->last;
+  out->block_offs = (uint64_t*)malloc(((size_t)n + 1) * 8);
+  out->blocks = (sigax_block*)malloc(std::max<size_t>(1, b->last_total_blocks) * sizeof(sigax_block));
+  out->substring = (uint8_t*)malloc(std::max<size_t>(1, n));
+  out->n_edges = b->last_total_edges;
+  out->edges = (sigax_edge*)malloc(std::max<size_t>(1, b->last_total_edges) * sizeof(sigax_edge));
+  if (!out->block_offs || !out->blocks || !out->substring || !out->edges) {
+    sigax_result_free(out);
+    return fail(SIGAX_E_ARG, "host allocation failed");
+  }
+  HIP_TRY(hipMemcpy(out->block_offs, b->block_offs.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost));
+  if (b->last_total_blocks)
+    HIP_TRY(hipMemcpy(out->blocks, b->outb.p, b->last_total_blocks * sizeof(sigax_block), hipMemcpyDeviceToHost));
+  if (n) HIP_TRY(hipMemcpy(out->substring, b->substring.p, n, hipMemcpyDeviceToHost));
+  if (b->last_total_edges)
+    HIP_TRY(hipMemcpy(out->edges, b->edges.p, b->last_total_edges * sizeof(sigax_edge), hipMemcpyDeviceToHost));
+  return SIGAX_OK;
+}
+
+extern "C" int sigax_batch_kernel_ms(sigax_batch* b, float ms[5]) {
+  if (!b || !ms) return fail(SIGAX_E_ARG, "NULL argument");
+  if (!b->finished) return fail(SIGAX_E_STATE, "batch not finished");
+  for (int i = 0; i < 5; ++i) {
+    ms[i] = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms[i], b->ev[i], b->ev[i + 1]));
+  }
+  return SIGAX_OK;
+}
+
+extern "C" int sigax_overlap_batch(sigax_index* ix, const char* seqs, const uint64_t* offs, uint32_t n_reads,
+                                   uint32_t read_base, uint32_t min_overlap, uint32_t flags, sigax_result* out) {
+  if (!ix || !out) return fail(SIGAX_E_ARG, "NULL argument");
+  sigax_batch* b = nullptr;
+  int rc = sigax_batch_create(ix, n_reads, n_reads ? offs[n_reads] : 0, 0, &b);
+  if (rc != SIGAX_OK) return rc;
+  rc = sigax_batch_upload(b, seqs, offs, n_reads, nullptr);
+  if (rc == SIGAX_OK) rc = sigax_batch_run(b, read_base, min_overlap, flags, nullptr);
+  if (rc == SIGAX_OK) rc = sigax_batch_finish(b, nullptr, nullptr);
+  if (rc == SIGAX_OK) rc = sigax_batch_download(b, out);
+  sigax_batch_destroy(b);
+  return rc;
+}

@@ -1,0 +1,101 @@
+// siga_amd/csrc/sigax_kernels.h -- argument blocks and launch wrappers shared by sigax_kernels.hip and sigax_api.cpp
+#ifndef SIGA_AMD_SIGAX_KERNELS_H_
+#define SIGA_AMD_SIGAX_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sigax.h"
+#include "fm_layout.h"
+
+static_assert(sizeof(sigax_block) == 80, "sigax_block must be 5 x 16 bytes");
+static_assert(sizeof(sigax_edge) == 16, "sigax_edge must be 16 bytes");
+
+// slots of the per-batch device statistics / allocator block (u64 each, zeroed before every run)
+enum {
+  DS_OCC_FIND = 0,
+  DS_CAND_BLOCKS,
+  DS_FIND_OVERFLOW,
+  DS_OCC_EXTRACT,
+  DS_EXTRACT_ERRORS,
+  DS_POOL_OVERFLOW,
+  DS_SUBSTRING,
+  DS_FIN_TOP,      // bump allocator of the unordered final-block arena (may run past fin_cap: needed size)
+  DS_TOTAL_BLOCKS, // written by the scan: sum of per-read block counts
+  DS_TOTAL_EDGES,  // written by the edge scan
+  DS_SLOW_READS,
+  DS_COUNT = 16
+};
+
+struct Ent;  // defined in sigax_kernels.hip (48 bytes)
+#define SIGAX_ENT_BYTES 48
+
+struct FindArgs {
+  FmStrand fwd, rev;
+  const unsigned char* seqs;
+  const unsigned long long* offs;
+  uint32_t n_reads, minov, rc, cap;  // cap = slots per chain; the last one holds the containment block
+  sigax_block* arena;                // [n_reads][4][cap]
+  uint32_t* chain_cnt;               // [n_reads][4]
+  unsigned long long* dstat;
+};
+
+struct FxArgs {
+  FmStrand fwd, rev;
+  const unsigned long long* offs;
+  uint32_t n_reads, cap, irreducible;
+  const sigax_block* arena;
+  const uint32_t* chain_cnt;
+  Ent* pool;          // [lanes][pool_cap]
+  uint32_t pool_cap;
+  const uint32_t* work;  // optional list of read ids; NULL = all reads
+  unsigned long long n_work;
+  sigax_block* fin;   // unordered final blocks
+  uint32_t* fin_read;
+  uint32_t* fin_seq;
+  unsigned long long fin_cap;
+  uint32_t* fin_cnt;  // [n_reads]
+  uint8_t* substring; // [n_reads]
+  unsigned long long* dstat;
+};
+
+struct OrderArgs {
+  const sigax_block* fin;
+  const uint32_t* fin_read;
+  const uint32_t* fin_seq;
+  unsigned long long fin_cap;
+  const unsigned long long* block_offs;
+  sigax_block* out;
+  unsigned long long out_cap;
+  const unsigned long long* dstat;
+};
+
+struct EdgeArgs {
+  const sigax_block* blocks;
+  const unsigned long long* block_offs;  // [n_reads+1]
+  uint32_t n_reads, read_base;
+  const uint32_t* sai;
+  const uint32_t* rsai;
+  unsigned long long n_sai;
+  const uint32_t* read_len;
+  const uint32_t* name_rank;
+  uint32_t* edge_cnt;                    // per block (count pass); entries past the last block are zeroed
+  unsigned long long cnt_cap;
+  const unsigned long long* edge_offs;   // per block (fill pass)
+  sigax_edge* edges;
+  unsigned long long edge_cap;
+};
+
+void launch_occ_batch(const FmStrand& s, bool wide, const unsigned long long* pos, unsigned long long n,
+                      unsigned long long* out, hipStream_t st);
+void launch_kmer_count(const FmStrand& s, bool wide, const unsigned char* kmers, uint32_t k, unsigned long long n,
+                       unsigned long long* out, hipStream_t st);
+void launch_find(const FindArgs& a, bool wide, hipStream_t st);
+void launch_filter_extract(const FxArgs& a, bool wide, unsigned grid, hipStream_t st);
+void launch_scan(const uint32_t* cnt, unsigned long long n, unsigned long long* partial, unsigned long long* offs,
+                 unsigned long long* total_out, hipStream_t st);
+unsigned long long scan_partials_needed(unsigned long long n);
+void launch_order_scatter(const OrderArgs& a, unsigned long long max_items, hipStream_t st);
+void launch_edges(const EdgeArgs& a, bool fill, unsigned long long max_blocks, hipStream_t st);
+
+#endif

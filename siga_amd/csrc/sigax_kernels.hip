@@ -1,0 +1,861 @@
+// siga_amd/csrc/sigax_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) of the `siga overlap` hot path.
+//
+//   k_find            OverlapBlockFinder::find for 4 orientations per read   (src/overlap_builder.cpp:838-912)
+//   k_filter_extract  SubMaximalBlockFilter + ContainmentBlockRemover + IrreducibleBlockListExtractor +
+//                     the list plumbing of OverlapBuilder::overlap           (src/overlap_builder.cpp:706-836,
+//                                                                             914-1182)
+//   k_order_*         ordered compaction of the per-read block lists (replaces the hits text round trip,
+//                     src/overlap_builder.cpp:234-254,269-280)
+//   k_edge_*          Hit2OverlapConverter::convert                          (src/overlap_builder.cpp:345-375)
+//   k_occ_batch       FMIndex::getOcc                                        (src/fmindex.cpp:188-231,320-323)
+//   k_kmer_count      FMIndex::Interval::occurrences                         (src/fmindex.h:67-86)
+//
+// Integer / index work only: HBM- and latency-bound gathers of 64-byte rank granules (fm_layout.h); no MFMA.
+#include <hip/hip_runtime.h>
+
+#include "sigax_kernels.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// -------------------------------------------------------------------------------------------------------
+// rank: number of A,C,G,T in BWT[0, p)   == FMIndex::getOcc(p - 1) without the '$' column
+// -------------------------------------------------------------------------------------------------------
+struct Cnt4 {
+  u64 a, c, g, t;
+};
+
+__device__ __forceinline__ void chunk_count(const uint4& k, int take, u32& a, u32& c, u32& g, u32& t) {
+  u32 m = take >= 32 ? 0xFFFFFFFFu : (take <= 0 ? 0u : ((1u << take) - 1u));
+  u32 x0 = k.y & m, x1 = k.z & m, x2 = k.w & m;
+  a += __popc(x0 & ~x1);
+  c += __popc(x1 & ~x0);
+  g += __popc(x0 & x1);
+  t += __popc(x2);
+}
+
+// By-value view of one strand: granule table, superblock table, length, and which LDS row holds its C[]/totals.
+struct FmRef {
+  const uint4* g;
+  const u64* super;
+  u64 n;
+  u32 which;
+};
+__device__ __forceinline__ FmRef fm_ref(const FmStrand& s, u32 which) {
+  FmRef r;
+  r.g = reinterpret_cast<const uint4*>(s.granules);
+  r.super = s.super;
+  r.n = s.n;
+  r.which = which;
+  return r;
+}
+__device__ __forceinline__ FmRef fm_pick(bool first, const FmRef& a, const FmRef& b) {
+  FmRef r;
+  r.g = first ? a.g : b.g;
+  r.super = first ? a.super : b.super;
+  r.n = first ? a.n : b.n;
+  r.which = first ? a.which : b.which;
+  return r;
+}
+// C[] and symbol totals of both strands staged in LDS: [which][rank]
+struct FmTables {
+  u64 C[2][5];
+  u64 T[2][5];
+};
+__device__ __forceinline__ void fm_tables_load(FmTables& t, const FmStrand& fwd, const FmStrand& rev) {
+  if (threadIdx.x < 5) {
+    t.C[0][threadIdx.x] = fwd.C[threadIdx.x];
+    t.C[1][threadIdx.x] = rev.C[threadIdx.x];
+    t.T[0][threadIdx.x] = fwd.total[threadIdx.x];
+    t.T[1][threadIdx.x] = rev.total[threadIdx.x];
+  }
+  __syncthreads();
+}
+
+template <bool WIDE>
+__device__ __forceinline__ Cnt4 fm_rank(const FmRef& s, u64 p) {
+  p = p > s.n ? s.n : p;  // never leave the table, whatever an invalid interval holds
+  u64 gi = p >> 7;
+  int r = (int)(p & 127u);
+  const uint4* q = s.g + gi * 4;
+  uint4 k0 = q[0], k1 = q[1], k2 = q[2], k3 = q[3];
+  u32 a = k0.x, c = k1.x, g = k2.x, t = k3.x;
+  chunk_count(k0, r, a, c, g, t);
+  chunk_count(k1, r - 32, a, c, g, t);
+  chunk_count(k2, r - 64, a, c, g, t);
+  chunk_count(k3, r - 96, a, c, g, t);
+  Cnt4 o;
+  o.a = a; o.c = c; o.g = g; o.t = t;
+  if (WIDE) {
+    const u64* sb = s.super + (p >> SIGAX_SUPER_SHIFT) * 4;
+    o.a += sb[0]; o.c += sb[1]; o.g += sb[2]; o.t += sb[3];
+  }
+  return o;
+}
+
+// all five columns; v[0] = '$'
+template <bool WIDE>
+__device__ __forceinline__ void fm_rank5(const FmRef& s, u64 p, u64 v[5]) {
+  u64 pc = p > s.n ? s.n : p;
+  Cnt4 k = fm_rank<WIDE>(s, pc);
+  v[1] = k.a; v[2] = k.c; v[3] = k.g; v[4] = k.t;
+  v[0] = pc - (k.a + k.c + k.g + k.t);
+}
+
+// BWT symbol at position i (FMIndex::getChar, src/fmindex.cpp:233-246)
+__device__ __forceinline__ u32 fm_char(const FmRef& s, u64 i) {
+  const u32* q = reinterpret_cast<const u32*>(s.g) + (i >> 7) * 16 + ((i >> 5) & 3) * 4;
+  u32 b = (u32)i & 31u;
+  return ((q[1] >> b) & 1u) | (((q[2] >> b) & 1u) << 1) | (((q[3] >> b) & 1u) << 2);
+}
+
+// alphabet.h:19-39 and kseq.cpp:18-27: byte -> rank; complement in rank space (non-ACGT -> 0 either way)
+__device__ __forceinline__ u32 base_rank(u32 ch) {
+  return ch == 'A' ? 1u : ch == 'C' ? 2u : ch == 'G' ? 3u : ch == 'T' ? 4u : 0u;
+}
+__device__ __forceinline__ u32 comp_rank(u32 r) { return r ? 5u - r : 0u; }
+
+__device__ __forceinline__ u64 wave_sum(u64 v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// -------------------------------------------------------------------------------------------------------
+// k_occ_batch / k_kmer_count
+// -------------------------------------------------------------------------------------------------------
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_occ_batch(FmStrand s, const u64* pos, u64 n, u64* out) {
+  u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  u64 v[5];
+  fm_rank5<WIDE>(fm_ref(s, 0), pos[i] + 1, v);  // fmindex.cpp:191: ++i, so 2^64-1 wraps to the empty prefix
+  for (int k = 0; k < 5; ++k) out[i * 5 + k] = v[k];
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_kmer_count(FmStrand s, const unsigned char* kmers, u32 k, u64 n, u64* out) {
+  u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned char* w = kmers + i * k;
+  FmRef f = fm_ref(s, 0);
+  u64 C[5] = {s.C[0], s.C[1], s.C[2], s.C[3], s.C[4]};
+  u64 T[5] = {s.total[0], s.total[1], s.total[2], s.total[3], s.total[4]};
+  auto sel = [](const u64 v[5], u32 r) { return r == 0 ? v[0] : r == 1 ? v[1] : r == 2 ? v[2] : r == 3 ? v[3] : v[4]; };
+  // Interval::get (fmindex.h:67-79): init with the last symbol, update while valid
+  u32 r = base_rank(w[k - 1]);
+  u64 lo = sel(C, r), hi = lo + sel(T, r) - 1;
+  for (u32 j = k - 1; j > 0; --j) {
+    if (!(hi != ~0ull && hi >= lo)) break;
+    r = base_rank(w[j - 1]);
+    u64 l[5], u[5];
+    fm_rank5<WIDE>(f, lo, l);       // getOcc(c, lower - 1)
+    fm_rank5<WIDE>(f, hi + 1, u);   // getOcc(c, upper)
+    lo = sel(C, r) + sel(l, r);
+    hi = sel(C, r) + sel(u, r) - 1;
+  }
+  out[i] = (hi != ~0ull && hi >= lo) ? hi - lo + 1 : 0;
+}
+
+// -------------------------------------------------------------------------------------------------------
+// k_find: one lane per (read, orientation) chain.  Per step: two rank granules on the chain's primary index
+// (positions lower-1 and upper of IntervalPair::updateL, src/overlap_builder.cpp:95-122); the '$' probe of
+// src/overlap_builder.cpp:861-871 reuses them.  Blocks go to the chain's slots of the candidate arena in
+// increasing overlap length = the reference's push order.
+// -------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_block(sigax_block* dst, u64 c0lo, u64 c0hi, u64 c1lo, u64 c1hi, u64 r0lo, u64 r0hi,
+                                            u64 r1lo, u64 r1hi, u32 len, u32 af) {
+  ulonglong2* d = reinterpret_cast<ulonglong2*>(dst);
+  d[0] = make_ulonglong2(c0lo, c0hi);
+  d[1] = make_ulonglong2(c1lo, c1hi);
+  d[2] = make_ulonglong2(r0lo, r0hi);
+  d[3] = make_ulonglong2(r1lo, r1hi);
+  d[4] = make_ulonglong2((u64)len | ((u64)af << 32), 0ull);
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_find(FindArgs A) {
+  __shared__ FmTables tb;
+  fm_tables_load(tb, A.fwd, A.rev);
+
+  u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+  u32 read = (u32)(gid >> 2), o = (u32)gid & 3u;
+  u64 nocc = 0;
+  u32 nb = 0, flagbits = 0;
+  bool live = read < A.n_reads && ((o & 1u) == 0 || A.rc);  // chains 1 and 3 are the opposite-strand finds
+  u64 b0 = 0, L = 0;
+  if (live) {
+    b0 = A.offs[read];
+    L = A.offs[read + 1] - b0;
+    live = L > 0;
+  }
+  if (live) {
+    const bool pf = o < 2;  // primary index: fmi for chains 0,1; rfmi for 2,3 (overlap_builder.cpp:1120-1132)
+    const FmRef F = fm_ref(A.fwd, 0), R = fm_ref(A.rev, 1);
+    const FmRef P = fm_pick(pf, F, R);
+    const FmRef O = fm_pick(pf, R, F);
+    const u64* CP = tb.C[P.which];
+    const u64* CO = tb.C[O.which];
+    const bool comp = (o & 1u) != 0;            // chains 1 (revcomp) and 3 (complement)
+    const bool fromStart = (o == 1 || o == 2);  // reversed strings are consumed from the read's first base
+    const u32 af = o == 0 ? SIGAX_AF_CHAIN0 : o == 1 ? SIGAX_AF_CHAIN1 : o == 2 ? SIGAX_AF_CHAIN2 : SIGAX_AF_CHAIN3;
+    const unsigned char* sq = A.seqs + b0;
+    sigax_block* slots = A.arena + ((u64)read * 4 + o) * A.cap;
+
+    u32 r = base_rank(sq[fromStart ? 0 : L - 1]);
+    if (comp) r = comp_rank(r);
+    // IntervalPair::init (overlap_builder.cpp:91-94, fmindex.h:90-93)
+    u64 lo0 = CP[r], sz = tb.T[P.which][r], lo1 = CO[r];
+    u32 s = 1;
+    for (; s < L; ++s) {
+      if (sz == 0) break;  // an empty range stays empty, nothing more can be emitted
+      Cnt4 l = fm_rank<WIDE>(P, lo0);
+      Cnt4 u = fm_rank<WIDE>(P, lo0 + sz);
+      nocc += 2;
+      u32 ch = sq[fromStart ? s : L - 1 - s];
+      u64 da = u.a - l.a, dc = u.c - l.c, dg = u.g - l.g, dt = u.t - l.t;
+      u64 dd = sz - (da + dc + dg + dt);  // '$' extensions
+      if (s >= A.minov && dd > 0) {
+        // probe = ranges; probe.updateL('$') (overlap_builder.cpp:861-865): valid <=> dd > 0
+        u64 ld = lo0 - (l.a + l.c + l.g + l.t);
+        if (nb < A.cap - 1) {
+          store_block(slots + nb, ld, ld + dd - 1, lo1, lo1 + dd - 1, lo0, lo0 + sz - 1, lo1, lo1 + sz - 1, s, af);
+        } else {
+          flagbits |= 1u;  // cannot happen when cap was sized from the longest read
+        }
+        ++nb;
+      }
+      r = base_rank(ch);
+      if (comp) r = comp_rank(r);
+      // ranges.updateL(c) (overlap_builder.cpp:112-122)
+      u64 acc, lc, dcur;
+      if (r == 0)      { acc = 0;                 lc = lo0 - (l.a + l.c + l.g + l.t); dcur = dd; }
+      else if (r == 1) { acc = dd;                lc = l.a; dcur = da; }
+      else if (r == 2) { acc = dd + da;           lc = l.c; dcur = dc; }
+      else if (r == 3) { acc = dd + da + dc;      lc = l.g; dcur = dg; }
+      else             { acc = dd + da + dc + dg; lc = l.t; dcur = dt; }
+      lo1 += acc;
+      lo0 = CP[r] + lc;
+      sz = dcur;
+    }
+    if (sz != 0 && s >= L) {
+      // full-length interval: substring test and containment block (overlap_builder.cpp:889-904)
+      Cnt4 l = fm_rank<WIDE>(P, lo0);
+      Cnt4 u = fm_rank<WIDE>(P, lo0 + sz);
+      Cnt4 lp = fm_rank<WIDE>(O, lo1);
+      Cnt4 up = fm_rank<WIDE>(O, lo1 + sz);
+      nocc += 4;
+      bool dna = (u.a - l.a) | (u.c - l.c) | (u.g - l.g) | (u.t - l.t) | (up.a - lp.a) | (up.c - lp.c) | (up.g - lp.g) |
+                 (up.t - lp.t);
+      if (dna) {
+        flagbits |= SIGAX_CC_SUBSTRING;
+      } else {
+        // no DNA extension on either side: all sz extensions are '$', so probe.updateL('$') keeps the whole
+        // range and probe.updateR('$') reuses the two positions of rext.
+        u64 ld = lo0 - (l.a + l.c + l.g + l.t);
+        u64 lpd = lo1 - (lp.a + lp.c + lp.g + lp.t);
+        store_block(slots + (A.cap - 1), ld, ld + sz - 1, lpd, lpd + sz - 1, lo0, lo0 + sz - 1, lo1, lo1 + sz - 1, (u32)L, af);
+        flagbits |= SIGAX_CC_CONTAIN;
+      }
+    }
+  }
+  if (read < A.n_reads) {
+    u32 word = (nb & SIGAX_CC_COUNT_MASK) | (flagbits & (SIGAX_CC_SUBSTRING | SIGAX_CC_CONTAIN));
+    A.chain_cnt[(u64)read * 4 + o] = word;
+  }
+  u64 tot_occ = wave_sum(nocc);
+  u64 tot_blk = wave_sum((u64)nb + ((flagbits & SIGAX_CC_CONTAIN) ? 1u : 0u));
+  u64 tot_err = wave_sum((u64)(flagbits & 1u));
+  if ((threadIdx.x & 63) == 0) {
+    if (tot_occ) atomicAdd(&A.dstat[DS_OCC_FIND], tot_occ);
+    if (tot_blk) atomicAdd(&A.dstat[DS_CAND_BLOCKS], tot_blk);
+    if (tot_err) atomicAdd(&A.dstat[DS_FIND_OVERFLOW], tot_err);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
+// k_filter_extract (general form): one lane per read, literal list emulation in a per-lane pool.
+// -------------------------------------------------------------------------------------------------------
+struct Ent {  // a block whose capped pair may have been rewritten; raw/length/af live in the candidate arena
+  u64 c0lo, c0hi, c1lo, c1hi;
+  u32 src, len;
+  u32 pad0, pad1;
+};
+
+__device__ __forceinline__ bool iv_valid(u64 lo, u64 hi) { return hi != ~0ull && hi >= lo; }  // fmindex.h:87-89
+__device__ __forceinline__ bool intersecting(u64 s1, u64 e1, u64 s2, u64 e2) { return !(s1 > e2 || s2 > e1); }  // coord.h:37-40
+
+template <bool WIDE>
+struct Fx {
+  const FxArgs& A;
+  const FmTables& tb;
+  FmRef F, R;     // forward / reverse strand
+  Ent* pool;
+  u32 top;        // bump pointer (entries)
+  bool overflow;  // pool exhausted
+  bool xerror;    // extract() returned false
+  u64 nocc;
+  u32 read, nout;
+  const sigax_block* slots;  // this read's 4*cap candidate slots
+
+  __device__ Fx(const FxArgs& a, const FmTables& t, Ent* p)
+      : A(a), tb(t), F(fm_ref(a.fwd, 0)), R(fm_ref(a.rev, 1)), pool(p), top(0), overflow(false), xerror(false), nocc(0),
+        read(0), nout(0), slots(nullptr) {}
+
+  __device__ u32 af_of(u32 src) const {
+    u32 ch = src / A.cap;
+    return ch == 0 ? SIGAX_AF_CHAIN0 : ch == 1 ? SIGAX_AF_CHAIN1 : ch == 2 ? SIGAX_AF_CHAIN2 : SIGAX_AF_CHAIN3;
+  }
+  // OverlapBlock::index (overlap_builder.cpp:177-179): !TARGETREV ? rfmi : fmi.  Chains 0,1 are !TARGETREV.
+  __device__ FmRef ext_index(u32 src) const { return fm_pick((src / A.cap) < 2, R, F); }
+
+  __device__ bool need(u32 upto) {
+    if (upto > A.pool_cap) { overflow = true; return false; }
+    return true;
+  }
+
+  __device__ void load_ent(Ent& e, u32 src) const {
+    const sigax_block& b = slots[src];
+    e.c0lo = b.capped0_lo; e.c0hi = b.capped0_hi; e.c1lo = b.capped1_lo; e.c1hi = b.capped1_hi;
+    e.src = src; e.len = b.length; e.pad0 = e.pad1 = 0;
+  }
+
+  // outblocks->push_back (order tag = position in the read's hit)
+  __device__ void emit(const Ent& e) {
+    u64 slot = atomicAdd(&A.dstat[DS_FIN_TOP], 1ull);
+    if (slot < A.fin_cap) {
+      const sigax_block& b = slots[e.src];
+      store_block(A.fin + slot, e.c0lo, e.c0hi, e.c1lo, e.c1hi, b.raw0_lo, b.raw0_hi, b.raw1_lo, b.raw1_hi, b.length, b.af);
+      A.fin_read[slot] = read;
+      A.fin_seq[slot] = nout;
+    }
+    ++nout;
+  }
+
+  // IntervalPair::updateR(c, index) on the capped pair (overlap_builder.cpp:101-106,123-133)
+  __device__ void updateR(Ent& e, u32 r, const FmRef& ix) {
+    u64 l[5], u[5];
+    fm_rank5<WIDE>(ix, e.c1lo, l);
+    fm_rank5<WIDE>(ix, e.c1hi + 1, u);
+    u64 acc = 0, lr = 0, ur = 0;
+    for (u32 b = 0; b < 5; ++b) {
+      if (b < r) acc += u[b] - l[b];
+      if (b == r) { lr = l[b]; ur = u[b]; }
+    }
+    u64 pb = tb.C[ix.which][r];
+    e.c0lo += acc;
+    e.c0hi = e.c0lo + (ur - lr) - 1;
+    e.c1lo = pb + lr;
+    e.c1hi = pb + ur - 1;
+  }
+  // IntervalPair::updateL(c, index) (overlap_builder.cpp:95-100,112-122)
+  __device__ void updateL(Ent& e, u32 r, const FmRef& ix) {
+    u64 l[5], u[5];
+    fm_rank5<WIDE>(ix, e.c0lo, l);
+    fm_rank5<WIDE>(ix, e.c0hi + 1, u);
+    u64 acc = 0, lr = 0, ur = 0;
+    for (u32 b = 0; b < 5; ++b) {
+      if (b < r) acc += u[b] - l[b];
+      if (b == r) { lr = l[b]; ur = u[b]; }
+    }
+    u64 pb = tb.C[ix.which][r];
+    e.c1lo += acc;
+    e.c1hi = e.c1lo + (ur - lr) - 1;
+    e.c0lo = pb + lr;
+    e.c0hi = pb + ur - 1;
+  }
+  // OverlapBlock::ext (overlap_builder.cpp:181-187)
+  __device__ void ext(const Ent& e, u64 x[5]) {
+    FmRef ix = ext_index(e.src);
+    u64 l[5], u[5];
+    fm_rank5<WIDE>(ix, e.c1lo, l);
+    fm_rank5<WIDE>(ix, e.c1hi + 1, u);
+    for (int k = 0; k < 5; ++k) x[k] = u[k] - l[k];
+    if (af_of(e.src) & 4u) {  // QUERYCOMP: AlphaCount::complement (alphabet.h:68-71)
+      u64 t = x[1]; x[1] = x[4]; x[4] = t;
+      t = x[2]; x[2] = x[3]; x[3] = t;
+    }
+  }
+
+  // stable insertion sorts (std::list::sort is a stable merge sort)
+  __device__ void sort_left(u32 base, u32 n) {
+    for (u32 i = 1; i < n; ++i) {
+      Ent k = pool[base + i];
+      u32 j = i;
+      while (j > 0 && k.c0lo < pool[base + j - 1].c0lo) { pool[base + j] = pool[base + j - 1]; --j; }
+      pool[base + j] = k;
+    }
+  }
+  __device__ void sort_len_desc(u32 base, u32 n) {
+    for (u32 i = 1; i < n; ++i) {
+      Ent k = pool[base + i];
+      u32 j = i;
+      while (j > 0 && k.len > pool[base + j - 1].len) { pool[base + j] = pool[base + j - 1]; --j; }
+      pool[base + j] = k;
+    }
+  }
+
+  // SubMaximalBlockFilter::resolve (overlap_builder.cpp:965-1082).  Writes the resolved list to pool[rb..) and
+  // returns its size.  Pfm/Ofm are the filter's (_fmi,_rfmi): swapped for the reverse lists (:1147-1151).
+  __device__ u32 resolve(const Ent& x, const Ent& y, u32 rb, u32 rcap, const FmRef& Pfm, const FmRef& Ofm) {
+    const Ent* higher = &x;
+    const Ent* lower = &y;
+    if (higher->len < lower->len) { const Ent* t = higher; higher = lower; lower = t; }
+    u32 k = 0;
+    pool[rb + k++] = *higher;
+    if (higher->len == lower->len) return k;  // equal lengths: same coordinates (else the reference only logs)
+    if (!(lower->c0lo < higher->c0lo || lower->c0hi > higher->c0hi)) return k;
+    // re-map every reverse position of the lower block to its forward position by walking the BWT
+    const sigax_block& lb = slots[lower->src];
+    u64* used = reinterpret_cast<u64*>(pool + rb + rcap);  // pairs (key, next); room checked by the caller
+    u32 nused = 0;
+    for (u64 j = lower->c1lo; j <= lower->c1hi; ++j) {
+      Ent ti;  // ti.ranges = lower->raw
+      ti.c0lo = lb.raw0_lo; ti.c0hi = lb.raw0_hi; ti.c1lo = lb.raw1_lo; ti.c1hi = lb.raw1_hi;
+      ti.src = lower->src; ti.len = lower->len; ti.pad0 = ti.pad1 = 0;
+      u64 tlo = j, thi = j;
+      bool done = false;
+      u32 guard = 0;
+      while (!done) {
+        u32 c = fm_char(Ofm, tlo);
+        if (c == 0) {
+          updateL(ti, 0, Pfm);
+          nocc += 2;
+          done = true;
+        }
+        // tracing.update(c, _rfmi) (fmindex.h:94-98)
+        u64 l[5], u[5];
+        fm_rank5<WIDE>(Ofm, tlo, l);
+        fm_rank5<WIDE>(Ofm, thi + 1, u);
+        u64 lr = 0, ur = 0;
+        for (u32 b = 0; b < 5; ++b)
+          if (b == c) { lr = l[b]; ur = u[b]; }
+        u64 pb = tb.C[Ofm.which][c];
+        tlo = pb + lr;
+        thi = pb + ur - 1;
+        updateR(ti, c, Ofm);
+        nocc += 4;
+        if (++guard > (1u << 20)) { overflow = true; return k; }
+      }
+      u64 forward;
+      if (ti.c0lo == ti.c0hi) {
+        forward = ti.c0lo;
+      } else {  // duplicated read: next unused forward row (std::map usedmappig, :1050-1059)
+        u64 key = ti.c0lo, idx = key;
+        u32 f = 0;
+        for (; f < nused; ++f)
+          if (used[2 * f] == key) break;
+        if (f < nused) idx = used[2 * f + 1];
+        forward = idx;
+        if (f == nused) { used[2 * f] = key; ++nused; }
+        used[2 * f + 1] = idx + 1;
+      }
+      if (!intersecting(forward, forward, higher->c0lo, higher->c0hi)) {
+        if (k >= rcap) { overflow = true; return k; }
+        Ent sp = *lower;
+        sp.c0lo = forward; sp.c0hi = forward; sp.c1lo = j; sp.c1hi = j;
+        pool[rb + k++] = sp;
+      }
+    }
+    return k;
+  }
+
+  // SubMaximalBlockFilter::filter (overlap_builder.cpp:919-954) on pool[base, base+n); returns the new size
+  __device__ u32 filter(u32 base, u32 n, const FmRef& Pfm, const FmRef& Ofm) {
+    if (n == 0) return 0;
+    sort_left(base, n);
+    u32 prev = 0, curr = 1;
+    u32 guard = 0;
+    while (curr < n) {
+      Ent a = pool[base + prev];
+      Ent b = pool[base + curr];
+      if (intersecting(a.c0lo, a.c0hi, b.c0lo, b.c0hi)) {
+        const Ent& lower = (a.len < b.len) ? a : b;  // resolve() keeps the longer whole and splits the other
+        u64 w = lower.c1hi - lower.c1lo + 1;
+        if (w > A.pool_cap) { overflow = true; return n; }
+        u32 rcap = (u32)w + 1;
+        u32 rb = base + n + rcap;  // leave room for the list to grow by the resolved entries
+        if (!need(rb + rcap + (rcap * 16 + (u32)sizeof(Ent) - 1) / (u32)sizeof(Ent))) return n;
+        u32 k = resolve(a, b, rb, rcap, Pfm, Ofm);
+        if (overflow) return n;
+        // resolved.sort(sorter)
+        for (u32 i = 1; i < k; ++i) {
+          Ent key = pool[rb + i];
+          u32 j = i;
+          while (j > 0 && key.c0lo < pool[rb + j - 1].c0lo) { pool[rb + j] = pool[rb + j - 1]; --j; }
+          pool[rb + j] = key;
+        }
+        // blocks->erase(curr); blocks->erase(prev)   (adjacent)
+        for (u32 i = prev; i + 2 < n; ++i) pool[base + i] = pool[base + i + 2];
+        n -= 2;
+        // blocks->merge(resolved, sorter): stable, *this before equivalent incoming
+        int i = (int)n - 1, j = (int)k - 1;
+        u32 dst = n + k;
+        while (j >= 0) {
+          if (i >= 0 && pool[rb + j].c0lo < pool[base + i].c0lo) pool[base + --dst] = pool[base + i--];
+          else pool[base + --dst] = pool[rb + j--];
+        }
+        n += k;
+        prev = 0;
+        if (++guard > (1u << 16)) { overflow = true; return n; }
+      } else {
+        ++prev;
+      }
+      curr = prev + 1;
+    }
+    return n;
+  }
+
+  // updateR(c, &blocklist) (overlap_builder.cpp:818-832): update, drop invalid, keep order
+  __device__ u32 updateR_list(u32 off, u32 cnt, u32 c) {
+    u32 w = 0;
+    for (u32 i = 0; i < cnt; ++i) {
+      Ent e = pool[off + i];
+      u32 b = (af_of(e.src) & 4u) ? comp_rank(c) : c;
+      updateR(e, b, ext_index(e.src));
+      if (iv_valid(e.c0lo, e.c0hi) && iv_valid(e.c1lo, e.c1hi)) pool[off + w++] = e;
+    }
+    return w;
+  }
+
+  // IrreducibleBlockListExtractor::extract (overlap_builder.cpp:711-809) on pool[base, base+n)
+  __device__ bool extract(u32 base, u32 n) {
+    sort_len_desc(base, n);
+    top = base + n;
+    // group table (list order) + this pass's incomings; sized with the pool so that a regrown pool also
+    // admits more simultaneous branches
+    const u32 GMAX = A.pool_cap / 12 > 32 ? A.pool_cap / 12 : 32;
+    u32 dents = (GMAX * 2 * (u32)sizeof(uint2) + (u32)sizeof(Ent) - 1) / (u32)sizeof(Ent);
+    if (!need(top + dents)) return true;
+    uint2* D = reinterpret_cast<uint2*>(pool + top);  // groups (off, cnt) in list order
+    uint2* I = D + GMAX;                              // incomings of the current pass
+    top += dents;
+    u32 ng = 1;
+    D[0] = make_uint2(base, n);
+    u32 guard = 0;
+    while (ng > 0) {
+      u32 ni = 0;
+      u32 p = 0;
+      while (p != ng) {
+        u32 off = D[p].x, cnt = D[p].y;
+        bool eraseGroup = true;
+        if (cnt > 0) {
+          u64 exts[5] = {0, 0, 0, 0, 0};
+          u32 topLen = pool[off].len;
+          u32 ntop = 0;
+          for (; ntop < cnt && pool[off + ntop].len == topLen; ++ntop) {
+            u64 x[5];
+            ext(pool[off + ntop], x);
+            nocc += 2;
+            for (int k = 0; k < 5; ++k) exts[k] += x[k];
+          }
+          if (exts[0] > 0) {
+            for (u32 j = 0; j < ntop; ++j) {
+              u64 x[5];
+              ext(pool[off + j], x);
+              if (x[0] == 0) { xerror = true; return false; }  // "substring read found" (:754-757)
+              Ent br = pool[off + j];
+              updateR(br, 0, ext_index(br.src));
+              emit(br);
+            }
+          } else {
+            for (u32 j = ntop; j < cnt; ++j) {
+              u64 x[5];
+              ext(pool[off + j], x);
+              nocc += 2;
+              for (int k = 0; k < 5; ++k) exts[k] += x[k];
+            }
+            int nz = 0, first = -1;
+            for (int k = 0; k < 5; ++k)
+              if (exts[k] > 0) { ++nz; if (first < 0) first = k; }
+            if (nz == 1) {
+              D[p].y = updateR_list(off, cnt, (u32)first);
+              eraseGroup = false;
+            } else {
+              for (int k = 0; k < 5; ++k) {
+                if (exts[k] > 0) {
+                  if (!need(top + cnt) || ni >= GMAX) { overflow = true; return true; }
+                  for (u32 j = 0; j < cnt; ++j) pool[top + j] = pool[off + j];
+                  u32 c2 = updateR_list(top, cnt, (u32)k);
+                  I[ni++] = make_uint2(top, c2);
+                  top += cnt;
+                }
+              }
+            }
+          }
+        }
+        // body `i = erase(i)` / `++i`, then the loop header's `++i`: stride-2 walk of the ring [g0..g(k-1), end]
+        if (eraseGroup) {
+          for (u32 i = p; i + 1 < ng; ++i) D[i] = D[i + 1];
+          --ng;
+        } else {
+          p = (p + 1) % (ng + 1);
+        }
+        p = (p + 1) % (ng + 1);
+        if (++guard > (1u << 22)) { overflow = true; return true; }
+      }
+      if (ng + ni > GMAX) { overflow = true; return true; }
+      for (u32 i = 0; i < ni; ++i) D[ng++] = I[i];
+    }
+    return true;
+  }
+
+  // gather one find's blocks + the containment copies into pool[top..), filter, drop containments
+  __device__ u32 build_list(u32 chain, u32 c_a, u32 c_b, const u32 cc[4], u64 L, const FmRef& Pfm, const FmRef& Ofm) {
+    u32 base = top;
+    u32 nchain = cc[chain] & SIGAX_CC_COUNT_MASK;
+    if (!need(base + nchain + 2)) return 0;
+    u32 n = 0;
+    for (u32 k = 0; k < nchain; ++k) load_ent(pool[base + n++], chain * A.cap + k);
+    if (cc[c_a] & SIGAX_CC_CONTAIN) load_ent(pool[base + n++], c_a * A.cap + (A.cap - 1));
+    if (cc[c_b] & SIGAX_CC_CONTAIN) load_ent(pool[base + n++], c_b * A.cap + (A.cap - 1));
+    n = filter(base, n, Pfm, Ofm);
+    if (overflow) return 0;
+    u32 w = 0;  // ContainmentBlockRemover (overlap_builder.cpp:1094-1111)
+    for (u32 i = 0; i < n; ++i)
+      if (pool[base + i].len != L) pool[base + w++] = pool[base + i];
+    top = base + w;
+    return w;
+  }
+
+  // OverlapBuilder::overlap from the list plumbing on (overlap_builder.cpp:1135-1181)
+  __device__ void run(u32 r) {
+    read = r;
+    nout = 0;
+    top = 0;
+    overflow = false;
+    xerror = false;
+    slots = A.arena + (u64)r * 4 * A.cap;
+    u64 L = A.offs[r + 1] - A.offs[r];
+    u32 cc[4];
+    for (int o = 0; o < 4; ++o) cc[o] = A.chain_cnt[(u64)r * 4 + o];
+    // containfwd = {chain 0, chain 1}, containrev = {chain 2, chain 3} go out first, unfiltered (:1161-1162)
+    for (int o = 0; o < 4; ++o) {
+      if (cc[o] & SIGAX_CC_CONTAIN) {
+        Ent e;
+        load_ent(e, o * A.cap + (A.cap - 1));
+        emit(e);
+      }
+    }
+    // The four filters are independent, so build prefix lists first and suffix lists on top: `suffixfwd +=
+    // suffixrev` and `prefixfwd += prefixrev` are then contiguous ranges, and extract() of the suffix lists can
+    // grow the pool above itself without touching the prefix lists.
+    u32 pBase = top;
+    u32 nPF = build_list(1, 0, 1, cc, L, F, R);
+    u32 nPR = overflow ? 0 : build_list(2, 2, 3, cc, L, R, F);
+    u32 sBase = top;
+    u32 nSF = overflow ? 0 : build_list(0, 0, 1, cc, L, F, R);
+    u32 nSR = overflow ? 0 : build_list(3, 2, 3, cc, L, R, F);
+    if (overflow) return;
+    u32 nS = nSF + nSR, nP = nPF + nPR;
+    if (A.irreducible) {
+      extract(sBase, nS);  // result.aborted |= ...: the second extract runs whatever the first returned
+      if (overflow) return;
+      extract(pBase, nP);
+    } else {
+      for (u32 i = 0; i < nS; ++i) emit(pool[sBase + i]);
+      for (u32 i = 0; i < nP; ++i) emit(pool[pBase + i]);
+    }
+  }
+};
+
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_filter_extract(FxArgs A) {
+  __shared__ FmTables tb;
+  fm_tables_load(tb, A.fwd, A.rev);
+  u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+  u64 nlanes = (u64)gridDim.x * 256;
+  Fx<WIDE> fx(A, tb, A.pool + gid * A.pool_cap);
+  u64 nocc = 0, nerr = 0, nover = 0, nsub = 0;
+  for (u64 w = gid; w < A.n_work; w += nlanes) {
+    u32 r = A.work ? A.work[w] : (u32)w;
+    fx.nocc = 0;
+    fx.run(r);
+    nocc += fx.nocc;
+    if (fx.overflow) { ++nover; A.fin_cnt[r] = 0; }
+    else A.fin_cnt[r] = fx.nout;
+    if (fx.xerror) ++nerr;
+    u32 sub = 0;
+    for (int o = 0; o < 4; ++o) sub |= A.chain_cnt[(u64)r * 4 + o] & SIGAX_CC_SUBSTRING;
+    A.substring[r] = sub ? 1 : 0;
+    if (sub) ++nsub;
+  }
+  nocc = wave_sum(nocc); nerr = wave_sum(nerr); nover = wave_sum(nover); nsub = wave_sum(nsub);
+  if ((threadIdx.x & 63) == 0) {
+    if (nocc) atomicAdd(&A.dstat[DS_OCC_EXTRACT], nocc);
+    if (nerr) atomicAdd(&A.dstat[DS_EXTRACT_ERRORS], nerr);
+    if (nover) atomicAdd(&A.dstat[DS_POOL_OVERFLOW], nover);
+    if (nsub) atomicAdd(&A.dstat[DS_SUBSTRING], nsub);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
+// exclusive scan of u32 counts into u64 offsets (three small kernels), ordered scatter of the final blocks
+// -------------------------------------------------------------------------------------------------------
+#define SCAN_ITEMS 2048  // per workgroup of 256 threads
+
+__device__ __forceinline__ u64 block_exclusive_scan(u64 v, u64* total) {
+  __shared__ u64 wsum[4];
+  u32 lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  u64 x = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    u64 y = __shfl_up(x, off, 64);
+    if (lane >= (u32)off) x += y;
+  }
+  if (lane == 63) wsum[wid] = x;
+  __syncthreads();
+  u64 base = 0;
+  for (u32 w = 0; w < wid; ++w) base += wsum[w];
+  u64 tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  __syncthreads();
+  *total = tot;
+  return base + x - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_partials(const u32* cnt, u64 n, u64* partial) {
+  u64 base = (u64)blockIdx.x * SCAN_ITEMS + (u64)threadIdx.x * 8;
+  u64 s = 0;
+  for (int k = 0; k < 8; ++k)
+    if (base + k < n) s += cnt[base + k];
+  u64 tot;
+  block_exclusive_scan(s, &tot);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_scan_top(u64* partial, u64 nparts, u64* total_out) {
+  u64 carry = 0;
+  for (u64 base = 0; base < nparts; base += 256) {
+    u64 i = base + threadIdx.x;
+    u64 v = i < nparts ? partial[i] : 0;
+    u64 tot;
+    u64 ex = block_exclusive_scan(v, &tot);
+    if (i < nparts) partial[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const u32* cnt, u64 n, const u64* partial, u64* offs) {
+  u64 base = (u64)blockIdx.x * SCAN_ITEMS + (u64)threadIdx.x * 8;
+  u64 v[8], s = 0;
+  for (int k = 0; k < 8; ++k) {
+    v[k] = (base + k < n) ? cnt[base + k] : 0;
+    s += v[k];
+  }
+  u64 tot;
+  u64 ex = block_exclusive_scan(s, &tot) + partial[blockIdx.x];
+  for (int k = 0; k < 8; ++k) {
+    if (base + k < n) offs[base + k] = ex;
+    ex += v[k];
+  }
+  if (base <= n && n < base + 8) offs[n] = ex;  // the thread owning position n writes the grand total
+}
+
+__global__ __launch_bounds__(256) void k_order_scatter(OrderArgs A) {
+  u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  u64 n = A.dstat[DS_FIN_TOP];
+  if (n > A.fin_cap) n = A.fin_cap;
+  if (i >= n) return;
+  u64 dst = A.block_offs[A.fin_read[i]] + A.fin_seq[i];
+  if (dst >= A.out_cap) return;  // only after an overflow, whose results the host discards
+  const ulonglong2* s = reinterpret_cast<const ulonglong2*>(A.fin + i);
+  ulonglong2* d = reinterpret_cast<ulonglong2*>(A.out + dst);
+  d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3]; d[4] = s[4];
+}
+
+// -------------------------------------------------------------------------------------------------------
+// edges: Hit2OverlapConverter::convert (overlap_builder.cpp:345-375), one lane per final block
+// -------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool edge_kept(const EdgeArgs& A, u32 q, u32 t, u32 len, u32 af) {
+  u32 nq = A.name_rank[q], nt = A.name_rank[t];
+  if (nq == nt) return false;                       // query.name != target.name (:358)
+  bool contained = (len == A.read_len[q]) || (len == A.read_len[t]);  // Match::isContainment (coord.h:150-152)
+  if (nq < nt || (contained && (af & 1u))) return false;              // dedup rule (:365)
+  return true;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_edges(EdgeArgs A) {
+  u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  u64 nblocks = A.block_offs[A.n_reads];
+  if (i >= nblocks) {
+    if (!FILL && i < A.cnt_cap) A.edge_cnt[i] = 0;
+    return;
+  }
+  // which read owns block i: binary search in block_offs
+  u32 lo = 0, hi = A.n_reads;
+  while (hi - lo > 1) {
+    u32 mid = lo + (hi - lo) / 2;
+    if (A.block_offs[mid] <= i) lo = mid; else hi = mid;
+  }
+  u32 q = A.read_base + lo;
+  const sigax_block& b = A.blocks[i];
+  const u32* sa = (b.af & 2u) ? A.rsai : A.sai;
+  u64 w = FILL ? A.edge_offs[i] : 0;
+  u32 kept = 0;
+  for (u64 j = b.capped0_lo; j <= b.capped0_hi && j < A.n_sai; ++j) {
+    u32 t = sa[j];
+    if (edge_kept(A, q, t, b.length, b.af)) {
+      if (FILL) {
+        if (w < A.edge_cap) {
+          sigax_edge e;
+          e.query = q; e.target = t; e.length = b.length; e.af = b.af;
+          A.edges[w] = e;
+        }
+        ++w;
+      }
+      ++kept;
+    }
+  }
+  if (!FILL) A.edge_cnt[i] = kept;
+}
+
+// -------------------------------------------------------------------------------------------------------
+// launch wrappers
+// -------------------------------------------------------------------------------------------------------
+static inline unsigned nblk(u64 n, u64 per) { return (unsigned)((n + per - 1) / per); }
+
+void launch_occ_batch(const FmStrand& s, bool wide, const u64* pos, u64 n, u64* out, hipStream_t st) {
+  if (n == 0) return;
+  if (wide) hipLaunchKernelGGL(k_occ_batch<true>, dim3(nblk(n, 256)), dim3(256), 0, st, s, pos, n, out);
+  else hipLaunchKernelGGL(k_occ_batch<false>, dim3(nblk(n, 256)), dim3(256), 0, st, s, pos, n, out);
+}
+
+void launch_kmer_count(const FmStrand& s, bool wide, const unsigned char* kmers, u32 k, u64 n, u64* out, hipStream_t st) {
+  if (n == 0) return;
+  if (wide) hipLaunchKernelGGL(k_kmer_count<true>, dim3(nblk(n, 256)), dim3(256), 0, st, s, kmers, k, n, out);
+  else hipLaunchKernelGGL(k_kmer_count<false>, dim3(nblk(n, 256)), dim3(256), 0, st, s, kmers, k, n, out);
+}
+
+void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
+  if (a.n_reads == 0) return;
+  unsigned g = nblk((u64)a.n_reads * 4, 256);
+  if (wide) hipLaunchKernelGGL(k_find<true>, dim3(g), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_find<false>, dim3(g), dim3(256), 0, st, a);
+}
+
+void launch_filter_extract(const FxArgs& a, bool wide, unsigned grid, hipStream_t st) {
+  if (a.n_work == 0) return;
+  if (wide) hipLaunchKernelGGL(k_filter_extract<true>, dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_filter_extract<false>, dim3(grid), dim3(256), 0, st, a);
+}
+
+void launch_scan(const u32* cnt, u64 n, u64* partial, u64* offs, u64* total_out, hipStream_t st) {
+  // offs has n+1 entries; offs[n] = total
+  unsigned g = nblk(n + 1, SCAN_ITEMS);
+  hipLaunchKernelGGL(k_scan_partials, dim3(g), dim3(256), 0, st, cnt, n, partial);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, st, partial, (u64)g, total_out);
+  hipLaunchKernelGGL(k_scan_apply, dim3(g), dim3(256), 0, st, cnt, n, (const u64*)partial, offs);
+}
+
+u64 scan_partials_needed(u64 n) { return (n + 1 + SCAN_ITEMS - 1) / SCAN_ITEMS + 1; }
+
+void launch_order_scatter(const OrderArgs& a, u64 max_items, hipStream_t st) {
+  if (max_items == 0) return;
+  hipLaunchKernelGGL(k_order_scatter, dim3(nblk(max_items, 256)), dim3(256), 0, st, a);
+}
+
+void launch_edges(const EdgeArgs& a, bool fill, u64 max_blocks, hipStream_t st) {
+  if (max_blocks == 0) return;
+  if (fill) hipLaunchKernelGGL(k_edges<true>, dim3(nblk(max_blocks, 256)), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_edges<false>, dim3(nblk(max_blocks, 256)), dim3(256), 0, st, a);
+}

@@ -16,3 +16,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def tmp_session(tmp_path_factory):
     return tmp_path_factory.mktemp("siga")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_libs():
+    """Build (if stale) the product library and the oracle before any test runs."""
+    from oracle import pyoracle
+    from siga_amd import build as sbuild
+    sbuild.build_libsigax()
+    pyoracle.build()

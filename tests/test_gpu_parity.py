@@ -1,0 +1,110 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI, include/sigax.h) against the oracle on the same inputs.
+Bit-exact: Occ values, per-read block lists IN ORDER (hits text), substring flags, ASQG text."""
+import numpy as np
+import pytest
+
+from tests.fixtures import GOLDEN, ed_lines, fixture, md5_prefix
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import siga_amd
+    return siga_amd
+
+
+def _pair(sa, fx):
+    return sa.FMIndexPair.load(fx.prefix)
+
+
+@pytest.mark.parametrize("name", ["corner", "tiny", "dup", "toy"])
+def test_occ_bit_exact(sa, name):
+    fx = fixture(name)
+    pair = _pair(sa, fx)
+    n = len(fx.fwd)
+    rng = np.random.default_rng(1)
+    pos = np.concatenate([np.arange(min(n, 300), dtype=np.uint64), rng.integers(0, n, 2000, dtype=np.uint64),
+                          np.array([n - 1, max(n - 2, 0), 2**64 - 1], dtype=np.uint64)])
+    for which, orc in ((0, fx.fwd), (1, fx.rev)):
+        got = pair.occ(pos, which)
+        for k, p in enumerate(pos):
+            assert list(got[k]) == list(orc.occ(int(p))), (name, which, int(p))
+    assert pair.info()["pred"] == list(map(int, fx.fwd.pred()))
+
+
+CASES = [
+    ("corner", 10, True, True), ("corner", 10, False, True), ("corner", 30, True, True),
+    ("rep", 10, True, True), ("rep", 10, False, True),
+    ("dup", 8, True, True), ("dup", 8, False, True), ("dup", 8, True, False),
+    ("tiny", 20, True, True), ("tiny", 20, False, True), ("tiny", 59, True, True), ("tiny", 1, True, True),
+    ("ragged", 15, True, True), ("ragged", 15, False, False),
+    ("toy", 45, True, True), ("toy", 45, False, True), ("toy", 45, True, False),
+]
+
+
+@pytest.mark.parametrize("name,m,irr,rc", CASES)
+def test_hits_and_asqg_bit_exact(sa, name, m, irr, rc):
+    from siga_amd.overlap import format_hits
+    fx = fixture(name)
+    pair = _pair(sa, fx)
+    want_asqg, want_hits, st = fx.oracle_asqg(m, irreducible=irr, rc=rc, hits=True)
+    builder = sa.OverlapBuilder(pair, fx.prefix, irreducible=irr, rc=rc)
+    got_asqg, res = builder.build(fx.fa, m)
+    got_hits = format_hits(res)
+    if got_hits != want_hits:
+        gl, wl = got_hits.split("\n"), want_hits.split("\n")
+        bad = [i for i in range(min(len(gl), len(wl))) if gl[i] != wl[i]]
+        raise AssertionError("hits differ for %d reads; first read %d:\n got  %s\n want %s" % (
+            len(bad), bad[0], gl[bad[0]][:600], wl[bad[0]][:600]))
+    assert got_asqg == want_asqg
+    s = res["stats"]
+    assert s["n_blocks"] == st["blocks"]
+    assert s["n_occ_find"] + s["n_occ_extract"] == st["n_occ_min"]
+    assert s["n_edges"] == len(ed_lines(want_asqg))
+
+
+def test_non_acgt_reads_block_parity(sa):
+    """Reads holding an N: per-read block lists must still equal the oracle's (no edges: see fixtures.py)."""
+    from oracle import pyoracle as po
+    fx = fixture("ragged_n")
+    pair = _pair(sa, fx)
+    res = sa.OverlapBuilder(pair).overlap(fx.seqs, 15)
+    offs = res["block_offs"]
+    for r, seq in enumerate(fx.seqs):
+        want, sub, _, _ = po.overlap(fx.fwd, fx.rev, seq, 15)
+        got = res["blocks"][int(offs[r]):int(offs[r + 1])]
+        cols = ["capped0_lo", "capped0_hi", "capped1_lo", "capped1_hi", "raw0_lo", "raw0_hi", "raw1_lo", "raw1_hi",
+                "length", "af"]
+        gl = [[int(b[c]) for c in cols] for b in got]
+        assert gl == [list(map(int, w)) for w in want], r
+        assert bool(res["substring"][r]) == sub
+
+
+def test_toy_asqg_matches_reference_md5(sa):
+    """End of the chain: GPU ASQG md5 == the md5 prefix of the reference's own output."""
+    fx = fixture("toy")
+    pair = _pair(sa, fx)
+    text, _ = sa.OverlapBuilder(pair, fx.prefix).build(fx.fa, GOLDEN["toy"]["min_overlap"])
+    assert md5_prefix(text) == GOLDEN["toy"]["md5"]["asqg_t1"]
+
+
+def test_kmer_counts(sa):
+    fx = fixture("tiny")
+    pair = _pair(sa, fx)
+    seqs = fx.seqs
+    kmers = [s[i:i + 21] for s in seqs[:40] for i in (0, 7, 30)] + ["A" * 21, "ACGT" * 5 + "N"]
+    got = pair.kmer_counts(kmers)
+    want = [fx.fwd.occurrences(k) for k in kmers]
+    assert list(map(int, got)) == want
+
+
+def test_empty_batch_and_errors(sa):
+    fx = fixture("tiny")
+    pair = _pair(sa, fx)
+    res = sa.OverlapBuilder(pair).overlap([], 20)
+    assert len(res["blocks"]) == 0 and list(res["block_offs"]) == [0]
+    with pytest.raises(sa.SigaxError):
+        sa.FMIndexPair.load("/nonexistent/prefix")
+    with pytest.raises(sa.SigaxError):  # edges without read metadata
+        sa.OverlapBuilder(_pair(sa, fx)).overlap(fx.seqs[:3], 20, edges=True)
