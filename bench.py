@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s overlapped by the MI355X-native `siga overlap` path (BASELINE.json metric).
+
+A "step" is one pass of the whole hot path (block finder -> sub-maximal filter / irreducible extraction ->
+ordered compaction -> edge records) over this rank's shard of reads, inputs already resident in HBM, followed (for
+N > 1) by the RCCL gather of the edge records to rank 0.  Workload at N = 1: BASELINE configs[1], synthetic
+1M x 150 bp reads from a 5 Mb genome, min-overlap 45, irreducible, both strands.  For N > 1 the per-GPU share is
+kept (weak scaling): N x 1M reads from an N x 5 Mb genome, index replicated on every GPU, reads sharded.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+KERNELS = ["k_find", "k_filter_extract_fast", "k_filter_extract", "k_order", "k_edges"]
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads-per-gpu", type=int, default=1000000)
+    ap.add_argument("--genome-per-gpu", type=int, default=5000000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--min-overlap", type=int, default=45)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU restatement (0 = skip)")
+    ap.add_argument("--workdir", default=None)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log("WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the overlap path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import datetime
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=60),
+                                device_id=dev)
+
+    from siga_amd import _lib, host
+    from siga_amd import build as sbuild
+    from siga_amd.overlap import FMIndexPair
+    from siga_amd.sharding import gather_edges, shard_range
+    from tests.golden.make_reads import fast_reads
+
+    n_total = args.reads_per_gpu * world
+    G = args.genome_per_gpu * world
+    L = args.read_len
+    workdir = args.workdir or os.path.join(tempfile.gettempdir(), "siga_bench_%d_%d_%d_%d" % (n_total, G, L, args.seed))
+    prefix = os.path.join(workdir, "reads")
+
+    # ---- synthetic reads (every rank draws the same set) and the index (rank 0 builds, everyone loads) ----
+    t0 = time.time()
+    reads, _ = fast_reads(G, L, n_total, args.seed)  # uint8 [n_total, L]
+    if rank == 0:
+        sbuild.build_all()
+        os.makedirs(workdir, exist_ok=True)
+        if not all(os.path.exists(prefix + e) for e in (".bwt", ".rbwt", ".sai", ".rsai")):
+            offs_all = np.arange(0, (n_total + 1) * L, L, dtype=np.uint64)
+            host.index_build(reads.reshape(-1), offs_all, prefix, threads=2)
+        log("reads + index ready in %.1f s (%d reads, %d symbols per strand)" % (time.time() - t0, n_total, n_total * (L + 1)))
+    if world > 1:
+        dist.barrier()
+    pair = FMIndexPair.load(prefix, device=local_rank)
+    info = pair.info()
+    # ReadInfo{name,length}: names r<i>; rank of a name under std::string operator<
+    names = np.char.add("r", np.arange(n_total).astype(str))
+    order = np.argsort(names, kind="stable")
+    name_rank = np.empty(n_total, dtype=np.uint32)
+    name_rank[order] = np.arange(n_total, dtype=np.uint32)
+    pair.set_reads(np.full(n_total, L, dtype=np.uint32), name_rank)
+    log("index on GPU: %.1f MB, wide=%d (%.1f s since start)" % (info["device_bytes"] / 1e6, info["wide"], time.time() - t0))
+
+    lo, hi = shard_range(n_total, rank, world)
+    n_local = hi - lo
+    d_seqs = torch.from_numpy(reads[lo:hi].reshape(-1).copy()).to(dev)
+    d_offs = torch.arange(0, (n_local + 1) * L, L, dtype=torch.int64, device=dev)
+    lib = _lib.lib()
+    batch = C.c_void_p()
+    rc = lib.sigax_batch_create(pair.handle, n_local, n_local * L, L, C.byref(batch))
+    if rc != 0:
+        raise SystemExit("sigax_batch_create: " + _lib.last_error())
+    rc = lib.sigax_batch_set_device_reads(batch, d_seqs.data_ptr(), d_offs.data_ptr(), n_local, n_local * L, L)
+    assert rc == 0, _lib.last_error()
+    flags = _lib.SIGAX_IRREDUCIBLE | _lib.SIGAX_RC | _lib.SIGAX_EDGES
+    stream = torch.cuda.current_stream(dev)
+    sptr = C.c_void_p(stream.cuda_stream)
+
+    class _EdgeView:  # zero-copy view of the library's device edge buffer for torch.distributed
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n, 4), "typestr": "<i4", "data": (ptr, True), "version": 2}
+
+    stats = _lib.Stats()
+    kms = (C.c_float * 5)()
+
+    def step():
+        rc = lib.sigax_batch_run(batch, lo, args.min_overlap, flags, sptr)
+        if rc == 0:
+            rc = lib.sigax_batch_finish(batch, sptr, C.byref(stats))
+        if rc != 0:
+            raise SystemExit("overlap step failed: " + _lib.last_error())
+        if world > 1:
+            d_edges = C.c_void_p()
+            lib.sigax_batch_device_outputs(batch, None, None, None, C.byref(d_edges))
+            ne = int(stats.n_edges)
+            local = torch.as_tensor(_EdgeView(d_edges.value, ne), device=dev) if ne else torch.zeros((0, 4), dtype=torch.int32, device=dev)
+            allv, counts = gather_edges(local)
+            return sum(counts)
+        return int(stats.n_edges)
+
+    for _ in range(args.warmup):
+        step()
+    ksum = np.zeros(5)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t_start = time.perf_counter()
+    total_edges = 0
+    for _ in range(args.steps):
+        total_edges = step()
+        lib.sigax_batch_kernel_ms(batch, C.byref(kms))  # HIP events recorded on the run's stream
+        ksum += np.array(list(kms))
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kavg = ksum / max(args.steps, 1)
+    st = stats.as_dict()
+
+    out = None
+    if rank == 0:
+        reads_per_s = n_total * args.steps / elapsed
+        # algorithmic bytes: 64 B per distinct Occ evaluation + L per read + 64 B per block out
+        n_occ = st["n_occ_find"] + st["n_occ_extract"]
+        bytes_find = 64 * st["n_occ_find"] + n_local * L + 64 * st["n_candidate_blocks"]
+        bytes_read = (64 * n_occ + n_local * L + 64 * st["n_blocks"]) / max(n_local, 1)
+        find_ms = float(kavg[0])
+        achieved = bytes_find / (find_ms * 1e-3) / 1e9 if find_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = "k_find/%d/%d/%d" % (args.reads_per_gpu, args.genome_per_gpu, L)
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "reads/sec overlapped (ASQG bit-exact)", "value": reads_per_s, "unit": "reads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "synthetic %dx%d bp reads from %d bp genome, min-overlap %d, irreducible, both strands; "
+                                   "FM-index (both strands) resident in HBM, reads sharded over %d GPU(s)" % (
+                                       n_total, L, G, args.min_overlap, world),
+                       "reads_per_gpu": n_local, "edges": total_edges, "blocks_per_read": st["n_blocks"] / max(n_local, 1),
+                       "n_occ_min_per_read": n_occ / max(n_local, 1), "algorithmic_bytes_per_read": bytes_read,
+                       "slow_path_reads": st["n_slow_reads"]},
+            "kernel_ms": {k: float(v) for k, v in zip(KERNELS, kavg)},
+            "roofline": {"bound": "hbm", "kernel": "k_find", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_find, "avg_launch_ms": find_ms,
+                         "whole_path_achieved": bytes_read * n_local / (float(kavg.sum()) * 1e-3) / 1e9 if kavg.sum() > 0 else 0.0},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(prefix, reads, min(args.cpu_sample, n_total), args.min_overlap, st, lib, batch)
+
+    lib.sigax_batch_destroy(batch)
+    pair.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(prefix, reads, sample, min_overlap, st, lib, batch):
+    """The oracle (CPU restatement of the reference's OverlapBuilder::overlap, same RL-BWT + marker structures)
+    timed on the first `sample` reads of the workload against the full index, OpenMP over reads on all host
+    cores.  Checker/baseline only: nothing here feeds the GPU path."""
+    from oracle import pyoracle as po
+    po.build()
+    t0 = time.time()
+    fwd = po.Index.load(prefix + ".bwt", prefix + ".sai")
+    rev = po.Index.load(prefix + ".rbwt", prefix + ".rsai")
+    log("oracle index loaded in %.1f s" % (time.time() - t0))
+    seqs = [bytes(r) for r in reads[:sample]]
+    threads = po.max_threads()
+    sec, o = po.overlap_batch_timed(fwd, rev, seqs, min_overlap, True, True, threads)
+    sec1, _ = po.overlap_batch_timed(fwd, rev, seqs[: max(sample // 20, 1)], min_overlap, True, True, 1)
+    return {"value": sample / sec, "unit": "reads/s", "cores": threads, "kind": "port",
+            "sample": "first %d reads of the workload against the full index; OverlapBuilder::overlap only (no I/O); "
+                      "OpenMP over reads" % sample,
+            "seconds": sec, "single_thread_reads_per_s": max(sample // 20, 1) / sec1,
+            "blocks_per_read": o["blocks"] / sample, "n_occ_min_per_read": o["n_occ_min"] / sample}
+
+
+if __name__ == "__main__":
+    main()

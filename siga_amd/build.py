@@ -33,5 +33,36 @@ def build_libsigax(force=False, verbose=False):
     return LIB
 
 
+HOST = os.path.join(HERE, "host")
+HOSTLIB = os.path.join(HERE, "lib", "libsiga_host.so")
+CLI = os.path.join(HERE, "lib", "siga")
+CXX = os.environ.get("CXX", "g++")
+
+
+def build_host(force=False, verbose=False):
+    """libsiga_host.so (host C++ mirror of the reference classes over the C-ABI) and the `siga` CLI."""
+    build_libsigax(force=force, verbose=verbose)
+    deps = [os.path.join(HOST, f) for f in ("siga_host.cpp", "siga_host.hpp", "sais.hpp", "siga_main.cpp")] + [LIB]
+    libdir = os.path.dirname(LIB)
+    common = [CXX, "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-sign-compare", "-pthread"]
+    link = ["-L" + libdir, "-lsigax", "-lz", "-Wl,-rpath,$ORIGIN"]
+    if force or _stale(HOSTLIB, deps):
+        cmd = common + ["-shared", "-o", HOSTLIB, os.path.join(HOST, "siga_host.cpp")] + link
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    if force or _stale(CLI, deps + [HOSTLIB]):
+        cmd = common + ["-o", CLI, os.path.join(HOST, "siga_main.cpp"), "-lsiga_host"] + link
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HOSTLIB, CLI
+
+
+def build_all(force=False, verbose=False):
+    build_libsigax(force, verbose)
+    return build_host(force, verbose)
+
+
 if __name__ == "__main__":
-    print(build_libsigax(force="--force" in sys.argv, verbose=True))
+    print(build_all(force="--force" in sys.argv, verbose=True))

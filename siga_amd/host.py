@@ -1,0 +1,55 @@
+"""ctypes bindings of libsiga_host.so (host C++ mirror of the reference classes: `siga index`, OverlapBuilder::build)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsiga_host.so")
+CLI_PATH = os.path.join(HERE, "lib", "siga")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("siga_amd host library missing: %s (python -m siga_amd.build)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.sigah_index_build.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_int, C.c_char_p, C.c_uint64]
+        L.sigah_index_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_uint64]
+        L.sigah_overlap_file.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_int, C.c_int, C.c_uint64,
+                                         C.c_uint64, C.c_int, C.c_char_p, C.c_uint64]
+        L.sigah_stem.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64]
+        _lib = L
+    return _lib
+
+
+def index_build(seq_bytes, offs, prefix, threads=2):
+    """`siga index` for in-memory reads: writes <prefix>.{bwt,sai,rbwt,rsai}."""
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    err = C.create_string_buffer(512)
+    buf = seq_bytes if isinstance(seq_bytes, (bytes, bytearray)) else np.ascontiguousarray(seq_bytes).tobytes()
+    if lib().sigah_index_build(buf, offs.ctypes.data, len(offs) - 1, prefix.encode(), threads, err, 512) != 0:
+        raise RuntimeError("siga index failed: " + err.value.decode())
+
+
+def index_file(reads_path, prefix, threads=2):
+    err = C.create_string_buffer(512)
+    if lib().sigah_index_file(reads_path.encode(), prefix.encode(), threads, err, 512) != 0:
+        raise RuntimeError("siga index failed: " + err.value.decode())
+
+
+def overlap_file(reads_path, prefix, min_overlap, output, irreducible=True, rc=True, threads=1, batch=10000, device=0):
+    """FMIndex::load + OverlapBuilder::build in the host C++ library (GPU compute)."""
+    err = C.create_string_buffer(512)
+    r = lib().sigah_overlap_file(reads_path.encode(), prefix.encode(), min_overlap, output.encode(), int(irreducible), int(rc),
+                                 threads, batch, device, err, 512)
+    if r != 0:
+        raise RuntimeError("siga overlap failed: " + err.value.decode())
+
+
+def stem(path):
+    out = C.create_string_buffer(1024)
+    lib().sigah_stem(path.encode(), out, 1024)
+    return out.value.decode()

@@ -1,0 +1,627 @@
+// siga_amd/host/siga_host.cpp -- see siga_host.hpp.  Host C++ above the C-ABI; all overlap compute happens in
+// libsigax.so on the GPU.
+#include "siga_host.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <thread>
+
+#include "sais.hpp"
+
+namespace sigah {
+
+// ------------------------------------------------------------------------------------------------------
+// line source / sequence readers
+// ------------------------------------------------------------------------------------------------------
+class LineSource {
+ public:
+  explicit LineSource(const std::string& path) : _pos(0), _len(0), _eof(false) { _f = gzopen(path.c_str(), "rb"); }
+  ~LineSource() {
+    if (_f) gzclose(_f);
+  }
+  bool ok() const { return _f != nullptr; }
+  int peek() {
+    if (_pos >= _len && !fill()) return -1;
+    return (unsigned char)_buf[_pos];
+  }
+  // std::getline semantics: false only when nothing at all could be read
+  bool getline(std::string& line) {
+    line.clear();
+    bool any = false;
+    while (true) {
+      if (_pos >= _len && !fill()) return any;
+      any = true;
+      const char* b = _buf + _pos;
+      const char* nl = (const char*)memchr(b, '\n', _len - _pos);
+      if (nl) {
+        line.append(b, nl - b);
+        _pos += (nl - b) + 1;
+        return true;
+      }
+      line.append(b, _len - _pos);
+      _pos = _len;
+    }
+  }
+  void rewind() {
+    gzrewind(_f);
+    _pos = _len = 0;
+    _eof = false;
+  }
+
+ private:
+  bool fill() {
+    if (_eof) return false;
+    int n = gzread(_f, _buf, sizeof(_buf));
+    if (n <= 0) {
+      _eof = true;
+      return false;
+    }
+    _pos = 0;
+    _len = (size_t)n;
+    return true;
+  }
+  gzFile _f;
+  char _buf[1 << 16];
+  size_t _pos, _len;
+  bool _eof;
+};
+
+static void trim(std::string& s) {  // boost::algorithm::trim
+  auto sp = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; };
+  size_t b = 0, e = s.size();
+  while (b < e && sp(s[b])) ++b;
+  while (e > b && sp(s[e - 1])) --e;
+  if (b > 0 || e < s.size()) s = s.substr(b, e - b);
+}
+
+static void make_seq_name(std::string& name, std::string& comment) {  // src/kseq.cpp:71-79
+  size_t i = name.find_first_of(" \t");
+  if (i != std::string::npos) {
+    comment = name.substr(i + 1);
+    name.resize(i);
+  } else {
+    comment.clear();
+  }
+}
+
+DNASeqReader::DNASeqReader() : _fastq(false) {}
+DNASeqReader::~DNASeqReader() {}
+
+DNASeqReader* DNASeqReader::create(const std::string& path) {
+  std::unique_ptr<LineSource> src(new LineSource(path));
+  if (!src->ok()) return nullptr;
+  int c = src->peek();  // src/kseq.cpp:127-138
+  if (c != '@' && c != '>') return nullptr;
+  DNASeqReader* r = new DNASeqReader();
+  r->_fastq = c == '@';
+  r->_src = std::move(src);
+  return r;
+}
+
+void DNASeqReader::reset() {
+  _name.clear();
+  _src->rewind();
+}
+
+bool DNASeqReader::read(DNASeq& sequence) {
+  std::string line;
+  if (_fastq) {  // src/kseq.cpp:140-185
+    int state = 0;
+    while (_src->getline(line)) {
+      trim(line);
+      if (line.empty()) continue;
+      if (state == 0) {
+        if (line[0] != '@') return false;
+        sequence.name = line.substr(1);
+        state = 1;
+      } else if (state == 1) {
+        sequence.seq = line;
+        state = 2;
+      } else if (state == 2) {
+        const std::string& nm = sequence.name;
+        bool ends = line.size() >= nm.size() && line.compare(line.size() - nm.size(), nm.size(), nm) == 0;
+        if (line[0] == '+' && (line.length() == 1 || ends)) state = 3;
+        else return false;
+      } else {
+        if (line.length() != sequence.seq.length()) return false;
+        sequence.quality = line;
+        make_seq_name(sequence.name, sequence.comment);
+        return true;
+      }
+    }
+    return false;
+  }
+  // src/kseq.cpp:187-228
+  std::string seq;
+  while (_src->getline(line)) {
+    trim(line);
+    if (line.empty()) continue;
+    if (line[0] == '>') {
+      if (!seq.empty() && !_name.empty()) {
+        sequence.name = _name;
+        make_seq_name(sequence.name, sequence.comment);
+        sequence.seq.swap(seq);
+        sequence.quality.clear();
+        _name = line.substr(1);
+        return true;
+      } else if (!_name.empty()) {
+        return false;
+      }
+      _name = line.substr(1);
+    } else {
+      seq += line;
+    }
+  }
+  if (!seq.empty() && !_name.empty()) {
+    sequence.name = _name;
+    make_seq_name(sequence.name, sequence.comment);
+    sequence.seq.swap(seq);
+    sequence.quality.clear();
+    _name.clear();  // the reference's stream is at EOF here and never reads again
+    return true;
+  }
+  return false;
+}
+
+bool ReadDNASequences(const std::string& file, DNASeqList& sequences, uint32_t flags) {  // src/kseq.cpp:230-256
+  std::unique_ptr<DNASeqReader> reader(DNASeqReader::create(file));
+  if (!reader) return false;
+  DNASeq seq;
+  while (reader->read(seq)) {
+    if (!(flags & kSeqWithQuality)) seq.quality.clear();
+    if (!(flags & kSeqWithComment)) seq.comment.clear();
+    sequences.push_back(seq);
+  }
+  return true;
+}
+
+std::string Utils::stem(const std::string& filename) {  // src/utils.cpp:128-135
+  auto ends = [](const std::string& s, const char* suf) {
+    size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+  };
+  if (ends(filename, ".gz")) return stem(filename.substr(0, filename.size() - 3));
+  if (ends(filename, ".bz2")) return stem(filename.substr(0, filename.size() - 4));
+  size_t slash = filename.find_last_of('/');
+  std::string base = slash == std::string::npos ? filename : filename.substr(slash + 1);
+  if (base == "." || base == "..") return base;
+  size_t dot = base.find_last_of('.');
+  return dot == std::string::npos ? base : base.substr(0, dot);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// index construction
+// ------------------------------------------------------------------------------------------------------
+static inline int torank(char c) {  // src/alphabet.h:19-39
+  switch (c) {
+    case 'A': return 1;
+    case 'C': return 2;
+    case 'G': return 3;
+    case 'T': return 4;
+    default: return 0;
+  }
+}
+
+template <typename I>
+static bool build_strand(const char* seqs, const uint64_t* offs, uint64_t nReads, bool reverse, StrandIndex* out) {
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < nReads; ++i) total += (offs[i + 1] - offs[i]) + 1;
+  // text over {terminator 0, $ 1, A 2, C 3, G 4, T 5}; one '$' after every read, unique terminator at the end
+  std::vector<uint8_t> T(total + 1);
+  std::vector<uint64_t> starts(nReads);
+  uint64_t p = 0;
+  for (uint64_t i = 0; i < nReads; ++i) {
+    starts[i] = p;
+    uint64_t b = offs[i], e = offs[i + 1];
+    if (!reverse) {
+      for (uint64_t k = b; k < e; ++k) T[p++] = (uint8_t)(torank(seqs[k]) + 1);
+    } else {  // src/indexer.cpp:60-64: reads reversed, not complemented
+      for (uint64_t k = e; k > b; --k) T[p++] = (uint8_t)(torank(seqs[k - 1]) + 1);
+    }
+    T[p++] = 1;
+  }
+  T[p] = 0;
+  std::vector<I> SA(total + 1);
+  sais<uint8_t, I>(T.data(), SA.data(), (I)(total + 1), (I)6);
+  out->runs.clear();
+  out->sai.clear();
+  out->sai.reserve(nReads);
+  out->nStrings = nReads;
+  out->nSymbols = total;
+  // BWT(sa, reads): src/bwt.cpp:7-32 (run == c && !full -> ++run; else flush)
+  uint8_t run = 0;
+  auto push = [&](uint32_t rank) {
+    if (run) {
+      if ((uint32_t)(run >> 5) == rank && (run & 31) != 31) {
+        ++run;
+        return;
+      }
+      out->runs.push_back(run);
+    }
+    run = (uint8_t)((rank << 5) | 1u);
+  };
+  for (uint64_t k = 1; k <= total; ++k) {  // SA[0] is the terminator
+    uint64_t pos = (uint64_t)SA[k];
+    uint32_t prevCode = pos == 0 ? 1u : T[pos - 1];
+    push(prevCode - 1);
+    if (prevCode == 1) {  // suffix starts a read: SA row with j == 0 (src/suffix_array_builder.cpp:520-531)
+      uint64_t id = std::upper_bound(starts.begin(), starts.end(), pos) - starts.begin() - 1;
+      out->sai.push_back((uint32_t)id);
+    }
+  }
+  if (run) out->runs.push_back(run);
+  return true;
+}
+
+bool BuildStrandIndex(const char* seqs, const uint64_t* offs, uint64_t nReads, bool reverse, StrandIndex* out,
+                      std::string* error) {
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < nReads; ++i) {
+    if (offs[i + 1] < offs[i]) {
+      if (error) *error = "bad read offsets";
+      return false;
+    }
+    total += (offs[i + 1] - offs[i]) + 1;
+  }
+  if (nReads >= 0xFFFFFFFFull) {  // SuffixArray::Elem is uint32 (src/suffix_array.h:33-34)
+    if (error) *error = "too many reads for the .sai format";
+    return false;
+  }
+  try {
+    if (total + 1 < 0x7FFFFFF0ull) return build_strand<int32_t>(seqs, offs, nReads, reverse, out);
+    return build_strand<int64_t>(seqs, offs, nReads, reverse, out);
+  } catch (const std::bad_alloc&) {
+    if (error) *error = "out of memory building the suffix array";
+    return false;
+  }
+}
+
+bool StrandIndex::writeBWT(const std::string& path) const {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return false;
+  uint16_t magic = 0xCACA;
+  uint64_t nruns = runs.size();
+  int32_t flag = 0;
+  bool ok = fwrite(&magic, 2, 1, f) == 1 && fwrite(&nStrings, 8, 1, f) == 1 && fwrite(&nSymbols, 8, 1, f) == 1 &&
+            fwrite(&nruns, 8, 1, f) == 1 && fwrite(&flag, 4, 1, f) == 1 &&
+            (nruns == 0 || fwrite(runs.data(), 1, nruns, f) == nruns);
+  return fclose(f) == 0 && ok;
+}
+
+bool StrandIndex::writeSAI(const std::string& path) const {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return false;
+  std::string buf;
+  buf.reserve(1 << 20);
+  char tmp[64];
+  snprintf(tmp, sizeof(tmp), "%u\n%llu\n%llu\n", 0xCACAu, (unsigned long long)sai.size(), (unsigned long long)sai.size());
+  buf += tmp;
+  bool ok = true;
+  for (uint32_t id : sai) {
+    int n = snprintf(tmp, sizeof(tmp), "%u 0\n", id);
+    buf.append(tmp, n);
+    if (buf.size() > (1 << 20) - 64) {
+      ok = ok && fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+      buf.clear();
+    }
+  }
+  ok = ok && fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+  return fclose(f) == 0 && ok;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// FMIndex handle
+// ------------------------------------------------------------------------------------------------------
+FMIndex::~FMIndex() {
+  if (_h) sigax_index_close(_h);
+}
+
+bool FMIndex::load(const std::string& prefix, FMIndex& fmi, int device) {
+  if (fmi._h) {
+    sigax_index_close(fmi._h);
+    fmi._h = nullptr;
+  }
+  int rc = sigax_index_open((prefix + ".bwt").c_str(), (prefix + ".rbwt").c_str(), (prefix + ".sai").c_str(),
+                            (prefix + ".rsai").c_str(), device, &fmi._h);
+  return rc == SIGAX_OK;
+}
+
+uint64_t FMIndex::length() const {
+  sigax_index_info inf;
+  if (!_h || sigax_index_info_get(_h, &inf) != SIGAX_OK) return 0;
+  return inf.n_symbols;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// ASQG output
+// ------------------------------------------------------------------------------------------------------
+class OutFile {  // Utils::ofstream (src/utils.cpp:92-126): gzip when the name ends with .gz
+ public:
+  explicit OutFile(const std::string& path) : _gz(nullptr), _f(nullptr) {
+    if (path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0) _gz = gzopen(path.c_str(), "wb");
+    else _f = fopen(path.c_str(), "wb");
+    _buf.reserve(1 << 22);
+  }
+  ~OutFile() { close(); }
+  bool ok() const { return _gz || _f; }
+  void write(const char* p, size_t n) {
+    _buf.append(p, n);
+    if (_buf.size() >= (1 << 22)) flush();
+  }
+  void write(const std::string& s) { write(s.data(), s.size()); }
+  void flush() {
+    if (_buf.empty()) return;
+    if (_gz) gzwrite(_gz, _buf.data(), (unsigned)_buf.size());
+    else if (_f) fwrite(_buf.data(), 1, _buf.size(), _f);
+    _buf.clear();
+  }
+  bool close() {
+    flush();
+    bool ok = true;
+    if (_gz) ok = gzclose(_gz) == Z_OK;
+    if (_f) ok = fclose(_f) == 0;
+    _gz = nullptr;
+    _f = nullptr;
+    return ok;
+  }
+
+ private:
+  gzFile _gz;
+  FILE* _f;
+  std::string _buf;
+};
+
+static void append_u64(std::string& s, uint64_t v) {
+  char tmp[24];
+  int n = 0;
+  do {
+    tmp[n++] = (char)('0' + v % 10);
+    v /= 10;
+  } while (v);
+  while (n) s.push_back(tmp[--n]);
+}
+
+// TagValue<T>::fromstring (src/asqg.h:43-56): exactly three ':'-separated tokens, one-letter type code
+static bool tag_tokens(const std::string& text, char code, std::string* value) {
+  size_t a = text.find(':');
+  if (a == std::string::npos) return false;
+  size_t b = text.find(':', a + 1);
+  if (b == std::string::npos) return false;
+  if (text.find(':', b + 1) != std::string::npos) return false;
+  if (b - a - 1 != 1 || text[a + 1] != code) return false;
+  *value = text.substr(b + 1);
+  return true;
+}
+static std::string first_word(const std::string& s) {  // std::istream >> std::string
+  size_t b = 0;
+  auto sp = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; };
+  while (b < s.size() && sp(s[b])) ++b;
+  size_t e = b;
+  while (e < s.size() && !sp(s[e])) ++e;
+  return s.substr(b, e - b);
+}
+static int parse_int(const std::string& s) {  // std::istream >> int (0 on failure, clamped on overflow)
+  size_t i = 0;
+  auto sp = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; };
+  while (i < s.size() && sp(s[i])) ++i;
+  bool neg = false;
+  if (i < s.size() && (s[i] == '+' || s[i] == '-')) neg = s[i++] == '-';
+  if (i >= s.size() || s[i] < '0' || s[i] > '9') return 0;
+  long long v = 0;
+  while (i < s.size() && s[i] >= '0' && s[i] <= '9') {
+    v = v * 10 + (s[i++] - '0');
+    if (v > 4000000000LL) v = 4000000000LL;
+  }
+  if (neg) v = -v;
+  if (v > 2147483647LL) v = 2147483647LL;
+  if (v < -2147483648LL) v = -2147483648LL;
+  return (int)v;
+}
+
+// OverlapPostProcess::operator() + VertexRecord << (src/overlap_builder.cpp:301-322, src/asqg.cpp:171-186)
+static void write_vertex(std::string& o, const DNASeq& read, bool substring) {
+  bool hasCov = false, hasBar = false, hasExt = false;
+  int cov = 0;
+  std::string bar, ext, val;
+  if (!read.comment.empty()) {
+    size_t b = 0;
+    while (true) {
+      size_t e = read.comment.find(' ', b);
+      std::string tok = read.comment.substr(b, e == std::string::npos ? std::string::npos : e - b);
+      if (tok.compare(0, 2, "BX") == 0) {
+        if (tag_tokens(tok, 'Z', &val)) { bar = first_word(val); hasBar = true; }
+      } else if (tok.compare(0, 2, "CR") == 0) {
+        if (tag_tokens(tok, 'i', &val)) { cov = parse_int(val); hasCov = true; }
+      } else if (tok.compare(0, 2, "EX") == 0) {
+        if (tag_tokens(tok, 'Z', &val)) { ext = first_word(val); hasExt = true; }
+      }
+      if (e == std::string::npos) break;
+      b = e + 1;
+    }
+  }
+  o += "VT\t";
+  o += read.name;
+  o += '\t';
+  o += read.seq;
+  o += substring ? "\tSS:i:1" : "\tSS:i:0";
+  if (hasCov) { o += "\tCR:i:"; o += std::to_string(cov); }
+  if (hasBar) { o += "\tBX:Z:"; o += bar; }
+  if (hasExt) { o += "\tEX:Z:"; o += ext; }
+  o += '\n';
+}
+
+// EdgeRecord << (src/asqg.cpp:228-237, src/coord.cpp:4-80) with OverlapBlock::overlap's coordinates
+// (src/overlap_builder.cpp:158-175)
+static void write_edge(std::string& o, const sigax_edge& e, const DNASeqList& reads) {
+  uint64_t ql = reads[e.query].seq.size(), tl = reads[e.target].seq.size(), len = e.length;
+  uint64_t s0 = ql - len, e0 = ql - 1, s1 = 0, e1 = len - 1;
+  if (e.af & 1u) { uint64_t t = s0; s0 = ql - e0 - 1; e0 = ql - t - 1; }
+  if (e.af & 2u) { uint64_t t = s1; s1 = tl - e1 - 1; e1 = tl - t - 1; }
+  o += "ED\t";
+  o += reads[e.query].name;
+  o += ' ';
+  o += reads[e.target].name;
+  o += ' ';
+  append_u64(o, s0); o += ' ';
+  append_u64(o, e0); o += ' ';
+  append_u64(o, ql); o += ' ';
+  append_u64(o, s1); o += ' ';
+  append_u64(o, e1); o += ' ';
+  append_u64(o, tl); o += ' ';
+  o += (e.af & 4u) ? '1' : '0';
+  o += " 0\n";
+}
+
+bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const std::string& output, size_t threads,
+                           size_t batch, size_t* processed) const {
+  (void)processed;  // accepted and never written, like the reference (src/overlap_builder.cpp:423-424)
+  _error.clear();
+  if (!_fmi || !_fmi->handle()) {
+    _error = "FMIndex not loaded";
+    return false;
+  }
+  DNASeqList reads;
+  if (!ReadDNASequences(input, reads)) {
+    _error = "Failed to read file " + input;
+    return false;
+  }
+  OutFile out(output);
+  if (!out.ok()) {
+    _error = "Failed to create ASQG " + output;
+    return false;
+  }
+  // header: src/overlap_builder.cpp:428-437 (the IN tag is never written: :494-495)
+  {
+    std::string h = "HT\tVN:i:1\tOL:i:" + std::to_string((int)minOverlap) + "\tCN:i:1\n";
+    out.write(h);
+  }
+  const size_t n = reads.size();
+  // ReadInfo{name,length} for the edge converter (src/overlap_builder.cpp:333-343) as lengths + name ranks
+  std::vector<uint32_t> lengths(n), ranks(n), order(n);
+  for (size_t i = 0; i < n; ++i) lengths[i] = (uint32_t)reads[i].seq.size();
+  std::iota(order.begin(), order.end(), 0u);
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return reads[a].name < reads[b].name; });
+  uint32_t rk = 0;
+  for (size_t k = 0; k < n; ++k) {
+    if (k > 0 && reads[order[k]].name != reads[order[k - 1]].name) ++rk;
+    ranks[order[k]] = rk;
+  }
+  if (n > 0 && sigax_index_set_reads(_fmi->handle(), lengths.data(), ranks.data(), n) != SIGAX_OK) {
+    _error = std::string("failed to load suffix array index ") + _prefix + ": " + sigax_last_error();
+    return false;
+  }
+  uint32_t flags = SIGAX_EDGES | (_irreducible ? SIGAX_IRREDUCIBLE : 0u) | (_rc ? SIGAX_RC : 0u);
+  size_t per = std::max<size_t>(std::max<size_t>(threads, 1) * std::max<size_t>(batch, 1), 131072);
+  std::vector<sigax_edge> edges;
+  std::string seqs, text;
+  std::vector<uint64_t> offs;
+  for (size_t base = 0; base < n; base += per) {
+    size_t cnt = std::min(per, n - base);
+    seqs.clear();
+    offs.assign(1, 0);
+    for (size_t i = 0; i < cnt; ++i) {
+      seqs += reads[base + i].seq;
+      offs.push_back(seqs.size());
+    }
+    sigax_result res;
+    int rc = sigax_overlap_batch(_fmi->handle(), seqs.data(), offs.data(), (uint32_t)cnt, (uint32_t)base,
+                                 (uint32_t)minOverlap, flags, &res);
+    if (rc != SIGAX_OK) {
+      _error = std::string("overlap failed: ") + sigax_last_error();
+      return false;
+    }
+    text.clear();
+    for (size_t i = 0; i < cnt; ++i) write_vertex(text, reads[base + i], res.substring[i] != 0);
+    out.write(text);
+    edges.insert(edges.end(), res.edges, res.edges + res.n_edges);
+    sigax_result_free(&res);
+  }
+  text.clear();
+  for (const sigax_edge& e : edges) {
+    write_edge(text, e, reads);
+    if (text.size() > (1 << 22)) {
+      out.write(text);
+      text.clear();
+    }
+  }
+  out.write(text);
+  if (!out.close()) {
+    _error = "Failed to write ASQG " + output;
+    return false;
+  }
+  return true;
+}
+
+}  // namespace sigah
+
+// ------------------------------------------------------------------------------------------------------
+// C entry points for tests/bench (ctypes)
+// ------------------------------------------------------------------------------------------------------
+extern "C" {
+
+// `siga index` for in-memory reads: writes <prefix>.{bwt,sai,rbwt,rsai}; returns 0 or -1 (message in err)
+int sigah_index_build(const char* seqs, const uint64_t* offs, uint64_t n_reads, const char* prefix, int threads, char* err,
+                      uint64_t errcap) {
+  sigah::StrandIndex fwd, rev;
+  std::string e1, e2;
+  bool ok1 = false, ok2 = false;
+  if (threads > 1) {
+    std::thread t([&] { ok2 = sigah::BuildStrandIndex(seqs, offs, n_reads, true, &rev, &e2); });
+    ok1 = sigah::BuildStrandIndex(seqs, offs, n_reads, false, &fwd, &e1);
+    t.join();
+  } else {
+    ok1 = sigah::BuildStrandIndex(seqs, offs, n_reads, false, &fwd, &e1);
+    ok2 = sigah::BuildStrandIndex(seqs, offs, n_reads, true, &rev, &e2);
+  }
+  std::string p(prefix);
+  if (ok1 && ok2) {
+    ok1 = fwd.writeSAI(p + ".sai") && fwd.writeBWT(p + ".bwt");
+    ok2 = rev.writeSAI(p + ".rsai") && rev.writeBWT(p + ".rbwt");
+    if (!ok1 || !ok2) e1 = "cannot write index files with prefix " + p;
+  }
+  if (!(ok1 && ok2)) {
+    if (err && errcap) snprintf(err, errcap, "%s", (e1.empty() ? e2 : e1).c_str());
+    return -1;
+  }
+  return 0;
+}
+
+// `siga index READS`
+int sigah_index_file(const char* reads_path, const char* prefix, int threads, char* err, uint64_t errcap) {
+  sigah::DNASeqList reads;
+  if (!sigah::ReadDNASequences(reads_path, reads, 0)) {
+    if (err && errcap) snprintf(err, errcap, "Failed to open input file %s", reads_path);
+    return -1;
+  }
+  std::string seqs;
+  std::vector<uint64_t> offs(1, 0);
+  for (auto& r : reads) {
+    seqs += r.seq;
+    offs.push_back(seqs.size());
+  }
+  return sigah_index_build(seqs.data(), offs.data(), reads.size(), prefix, threads, err, errcap);
+}
+
+// `siga overlap`: FMIndex::load + OverlapBuilder::build
+int sigah_overlap_file(const char* reads_path, const char* prefix, uint64_t min_overlap, const char* output, int irreducible,
+                       int rc, uint64_t threads, uint64_t batch, int device, char* err, uint64_t errcap) {
+  sigah::FMIndex fmi;
+  if (!sigah::FMIndex::load(prefix, fmi, device)) {
+    if (err && errcap) snprintf(err, errcap, "Failed to load FMIndex from %s: %s", prefix, sigax_last_error());
+    return -1;
+  }
+  sigah::OverlapBuilder builder(&fmi, prefix, irreducible != 0, rc != 0);
+  if (!builder.build(reads_path, min_overlap, output, threads, batch)) {
+    if (err && errcap) snprintf(err, errcap, "%s", builder.error().c_str());
+    return -1;
+  }
+  return 0;
+}
+
+void sigah_stem(const char* path, char* out, uint64_t cap) { snprintf(out, cap, "%s", sigah::Utils::stem(path).c_str()); }
+
+}  // extern "C"

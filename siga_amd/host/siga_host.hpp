@@ -1,0 +1,100 @@
+// siga_amd/host/siga_host.hpp -- host side of the drop-in: the reference's classes for this path, re-implemented
+// over the C-ABI (include/sigax.h).  Same names, argument meaning and error behaviour as the reference so that a
+// maintainer can swap them in: DNASeq / readers (src/kseq.h), FMIndex (src/fmindex.h, here a handle pair living
+// on the GPU), SuffixArray + BWT writers (src/suffix_array.cpp, src/bwt.cpp), OverlapBuilder
+// (src/overlap_builder.h:19-45), Utils::stem (src/utils.cpp:128-135).
+#ifndef SIGA_AMD_HOST_SIGA_HOST_HPP_
+#define SIGA_AMD_HOST_SIGA_HOST_HPP_
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/sigax.h"
+
+namespace sigah {
+
+// src/kseq.h: DNASeq
+struct DNASeq {
+  std::string name, comment, seq, quality;
+};
+typedef std::vector<DNASeq> DNASeqList;
+
+// gz-aware line source (Utils::ifstream, src/utils.cpp:50-90; bz2 is not supported by this build)
+class LineSource;
+
+// DNASeqReader / FASTAReader / FASTQReader (src/kseq.h:60-150, src/kseq.cpp:127-228)
+class DNASeqReader {
+ public:
+  static DNASeqReader* create(const std::string& path);  // DNASeqReaderFactory::create; nullptr on failure
+  ~DNASeqReader();
+  bool read(DNASeq& sequence);
+  void reset();
+
+ private:
+  DNASeqReader();
+  std::unique_ptr<LineSource> _src;
+  bool _fastq;
+  std::string _name;
+};
+
+enum { kSeqWithQuality = 1, kSeqWithComment = 2 };
+bool ReadDNASequences(const std::string& file, DNASeqList& sequences, uint32_t flags = kSeqWithQuality | kSeqWithComment);
+
+namespace Utils {
+std::string stem(const std::string& filename);
+}
+
+// One strand's index as `siga index` writes it (src/indexer.cpp:80-104): RL-BWT + the full-read SA rows.
+struct StrandIndex {
+  std::vector<uint8_t> runs;   // RLUnit bytes (src/rlstring.h:10-63), 31-cap (src/bwt.cpp:17)
+  std::vector<uint32_t> sai;   // read ids of the j==0 suffixes in SA order (src/suffix_array.cpp:17-44)
+  uint64_t nStrings, nSymbols;
+  bool writeBWT(const std::string& path) const;  // src/bwt.cpp:121-178
+  bool writeSAI(const std::string& path) const;  // src/suffix_array.cpp:17-44
+};
+
+// SuffixArrayBuilder "sais2" + BWT(sa, reads) (src/suffix_array_builder.cpp:472-674, src/bwt.cpp:7-32)
+bool BuildStrandIndex(const char* seqs, const uint64_t* offs, uint64_t nReads, bool reverse, StrandIndex* out,
+                      std::string* error);
+
+// FMIndex pair resident on a GPU (FMIndex::load x2, src/overlap.cpp:41-42)
+class FMIndex {
+ public:
+  FMIndex() : _h(nullptr) {}
+  ~FMIndex();
+  static bool load(const std::string& prefix, FMIndex& fmi, int device = 0);
+  sigax_index* handle() const { return _h; }
+  uint64_t length() const;
+
+ private:
+  FMIndex(const FMIndex&);
+  FMIndex& operator=(const FMIndex&);
+  sigax_index* _h;
+};
+
+// src/overlap_builder.h:19-45.  The reference takes (fmi, rfmi); here one FMIndex object holds both strands.
+class OverlapBuilder {
+ public:
+  OverlapBuilder(const FMIndex* fmi, const std::string& prefix = "default", bool irreducible = true, bool rc = true)
+      : _fmi(fmi), _prefix(prefix), _irreducible(irreducible), _rc(rc) {}
+
+  // HT, VT (input order), ED (hits order) to `output` (gz when the name ends with .gz).  `threads` is accepted for
+  // signature compatibility (the GPU replaces the OpenMP loop); `batch` = reads per device batch.
+  bool build(const std::string& input, size_t minOverlap, const std::string& output, size_t threads = 1,
+             size_t batch = 1000, size_t* processed = nullptr) const;
+
+  const std::string& error() const { return _error; }
+
+ private:
+  const FMIndex* _fmi;
+  std::string _prefix;
+  bool _irreducible;
+  bool _rc;
+  mutable std::string _error;
+};
+
+}  // namespace sigah
+
+#endif

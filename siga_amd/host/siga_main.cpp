@@ -1,0 +1,159 @@
+// siga_amd/host/siga_main.cpp -- `siga index` / `siga overlap` command line, option for option as the reference
+// (src/main.cpp:17-83, src/indexer.cpp:119-156, src/overlap.cpp:66-105).  Exit codes follow the reference:
+// a runner returning -1 exits 255; printing help returns 256, i.e. exit status 0.
+#include <getopt.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "siga_host.hpp"
+
+extern "C" int sigah_index_file(const char*, const char*, int, char*, uint64_t);
+
+static int usage() {
+  printf("siga [index|overlap] [OPTION] ... READSFILE\n"
+         "  index     build the FM-index (.sai/.bwt/.rsai/.rbwt) of READSFILE\n"
+         "  overlap   compute pairwise overlaps between all the sequences in READSFILE (GPU)\n");
+  return 256;
+}
+
+static int index_help() {
+  printf("siga index [OPTION] ... READSFILE\n"
+         "Index the reads in READSFILE using a suffixarray/bwt\n"
+         "\n"
+         "      -h, --help                       display this help and exit\n"
+         "\n"
+         "      -a, --algorithm=STR              BWT construction algorithm. Only sais2 (the reference default) is built\n"
+         "      -t, --threads=NUM                use NUM threads to construct the index (default: 1)\n"
+         "      -p, --prefix=PREFIX              write index to file using PREFIX instead of prefix of READSFILE\n"
+         "          --no-reverse                 suppress construction of the reverse BWT\n"
+         "          --no-forward                 suppress construction of the forward BWT\n"
+         "\n");
+  return 256;
+}
+
+static int overlap_help() {
+  // help text of src/overlap.cpp:66-82 (the defaults it prints differ from the code defaults 10 / 10000, :44)
+  printf("siga overlap [OPTION] ... READSFILE\n"
+         "Compute pairwise overlap between all the sequences in READS\n"
+         "\n"
+         "      -h, --help                       display this help and exit\n"
+         "\n"
+         "      -t, --threads=NUM                use NUM threads to construct the index (default: 1)\n"
+         "          --batch-size=NUM             use NUM batches for each thread (default: 1000)\n"
+         "      -m, --min-overlap=LEN            minimum overlap required between two reads (default: 45)\n"
+         "      -p, --prefix=PREFIX              write index to file using PREFIX instead of prefix of READSFILE\n"
+         "      -x, --exhaustive                 output all overlaps, including transitive edges\n"
+         "          --no-opposite-strand         treat all reads as forward strand\n"
+         "          --device=NUM                 GPU to use (default: 0)\n"
+         "\n");
+  return 256;
+}
+
+static int run_index(int argc, char** argv) {
+  enum { OPT_NO_REVERSE = 1, OPT_NO_FORWARD };
+  static const option longopts[] = {{"prefix", required_argument, nullptr, 'p'},   {"algorithm", required_argument, nullptr, 'a'},
+                                    {"threads", required_argument, nullptr, 't'},  {"no-reverse", no_argument, nullptr, OPT_NO_REVERSE},
+                                    {"no-forward", no_argument, nullptr, OPT_NO_FORWARD}, {"help", no_argument, nullptr, 'h'},
+                                    {nullptr, 0, nullptr, 0}};
+  std::string prefix, algorithm = "sais2";
+  int threads = 1, c;
+  bool help = false, nofwd = false, norev = false;
+  while ((c = getopt_long(argc, argv, "c:s:a:t:p:h", longopts, nullptr)) != -1) {
+    switch (c) {
+      case 'p': prefix = optarg; break;
+      case 'a': algorithm = optarg; break;
+      case 't': threads = atoi(optarg); break;
+      case OPT_NO_REVERSE: norev = true; break;
+      case OPT_NO_FORWARD: nofwd = true; break;
+      case 'h': help = true; break;
+      default: break;
+    }
+  }
+  if (help || argc - optind != 1) return index_help();
+  std::string input = argv[optind];
+  if (prefix.empty()) prefix = sigah::Utils::stem(input);
+  if (algorithm != "sais2") {
+    fprintf(stderr, "Failed to create suffix array builder algorithm %s\n", algorithm.c_str());
+    return -1;
+  }
+  if (nofwd || norev) {
+    sigah::DNASeqList reads;
+    if (!sigah::ReadDNASequences(input, reads, 0)) {
+      fprintf(stderr, "Failed to open input file %s\n", input.c_str());
+      return -1;
+    }
+    std::string seqs;
+    std::vector<uint64_t> offs(1, 0);
+    for (auto& r : reads) { seqs += r.seq; offs.push_back(seqs.size()); }
+    std::string err;
+    sigah::StrandIndex ix;
+    if (!nofwd) {
+      if (!sigah::BuildStrandIndex(seqs.data(), offs.data(), reads.size(), false, &ix, &err) || !ix.writeSAI(prefix + ".sai") ||
+          !ix.writeBWT(prefix + ".bwt")) return -1;
+    }
+    if (!norev) {
+      if (!sigah::BuildStrandIndex(seqs.data(), offs.data(), reads.size(), true, &ix, &err) || !ix.writeSAI(prefix + ".rsai") ||
+          !ix.writeBWT(prefix + ".rbwt")) return -1;
+    }
+    return 0;
+  }
+  char err[512] = "";
+  if (sigah_index_file(input.c_str(), prefix.c_str(), threads, err, sizeof(err)) != 0) {
+    fprintf(stderr, "%s\n", err);
+    return -1;
+  }
+  return 0;
+}
+
+static int run_overlap(int argc, char** argv) {
+  enum { OPT_BATCH_SIZE = 1, OPT_NO_RC, OPT_DEVICE };
+  static const option longopts[] = {{"log4cxx", required_argument, nullptr, 'c'},     {"ini", required_argument, nullptr, 's'},
+                                    {"prefix", required_argument, nullptr, 'p'},      {"threads", required_argument, nullptr, 't'},
+                                    {"batch-size", required_argument, nullptr, OPT_BATCH_SIZE},
+                                    {"min-overlap", required_argument, nullptr, 'm'}, {"exhaustive", no_argument, nullptr, 'x'},
+                                    {"no-opposite-strand", no_argument, nullptr, OPT_NO_RC},
+                                    {"device", required_argument, nullptr, OPT_DEVICE}, {"help", no_argument, nullptr, 'h'},
+                                    {nullptr, 0, nullptr, 0}};
+  std::string prefix;
+  size_t threads = 1, batch = 10000, minOverlap = 10;  // code defaults of src/overlap.cpp:44
+  bool exhaustive = false, norc = false, help = false;
+  int device = 0, c;
+  while ((c = getopt_long(argc, argv, "c:s:t:p:m:xh", longopts, nullptr)) != -1) {
+    switch (c) {
+      case 'p': prefix = optarg; break;
+      case 't': threads = strtoull(optarg, nullptr, 10); break;
+      case 'm': minOverlap = strtoull(optarg, nullptr, 10); break;
+      case 'x': exhaustive = true; break;
+      case OPT_BATCH_SIZE: batch = strtoull(optarg, nullptr, 10); break;
+      case OPT_NO_RC: norc = true; break;
+      case OPT_DEVICE: device = atoi(optarg); break;
+      case 'h': help = true; break;
+      default: break;
+    }
+  }
+  if (help || argc - optind != 1) return overlap_help();
+  std::string input = argv[optind];
+  if (prefix.empty()) prefix = sigah::Utils::stem(input);
+  sigah::FMIndex fmi;
+  if (!sigah::FMIndex::load(prefix, fmi, device)) {
+    fprintf(stderr, "Failed to load FMIndex from %s: %s\n", input.c_str(), sigax_last_error());
+    return -1;
+  }
+  sigah::OverlapBuilder builder(&fmi, prefix, !exhaustive, !norc);
+  if (!builder.build(input, minOverlap, prefix + ".asqg.gz", threads, batch)) {
+    fprintf(stderr, "Failed to build overlaps from reads %s: %s\n", input.c_str(), builder.error().c_str());
+    return -1;
+  }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) return usage();
+  std::string cmd = argv[1];
+  if (cmd == "index") return run_index(argc - 1, argv + 1);
+  if (cmd == "overlap") return run_overlap(argc - 1, argv + 1);
+  return usage();
+}
