@@ -363,8 +363,8 @@ struct sigax_batch {
   uint32_t read_base, minov, flags;
   bool ran;
   // arenas
-  DevBuf arena, chain_cnt, pool, fin, fin_read, fin_seq, fin_cnt, substring, block_offs, outb, edge_cnt, edge_offs, edges,
-      partial, dstat;
+  DevBuf arena, chain_cnt, pool, wpool, work, fin, fin_read, fin_seq, fin_cnt, substring, block_offs, outb, edge_cnt,
+      edge_offs, edges, partial, dstat;
   uint32_t cap;
   uint32_t pool_cap;
   unsigned fx_grid;
@@ -378,7 +378,7 @@ struct sigax_batch {
 extern "C" void sigax_batch_destroy(sigax_batch* b) {
   if (!b) return;
   hipSetDevice(b->ix->device);
-  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->fin, &b->fin_read, &b->fin_seq,
+  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->fin, &b->fin_read, &b->fin_seq,
                    &b->fin_cnt, &b->substring, &b->block_offs, &b->outb, &b->edge_cnt, &b->edge_offs, &b->edges,
                    &b->partial, &b->dstat};
   for (DevBuf* d : all)
@@ -485,8 +485,13 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   if ((rc = ensure(&b->fin_cnt, ((size_t)n + 1) * 4)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->substring, (size_t)n + 16)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->block_offs, ((size_t)n + 2) * 8)) != SIGAX_OK) return rc;
-  // general filter/extract kernel: persistent lanes with a private pool each
-  unsigned want_grid = (unsigned)std::min<u64>(512, ((u64)n + 255) / 256);
+  // fast filter/extract kernel: persistent waves (one read at a time per wave) with a private pool each
+  unsigned fast_grid = (unsigned)std::min<u64>(2048, ((u64)n + 3) / 4);
+  if (fast_grid == 0) fast_grid = 1;
+  if ((rc = ensure(&b->wpool, (size_t)fast_grid * 4 * fast_pool_entries_per_wave() * SIGAX_ENT_BYTES)) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->work, ((size_t)n + 1) * 4)) != SIGAX_OK) return rc;
+  // general filter/extract kernel (reads the fast kernel queued): persistent lanes with a private pool each
+  unsigned want_grid = (unsigned)std::min<u64>(128, ((u64)n + 255) / 256);
   if (want_grid == 0) want_grid = 1;
   uint32_t want_pool = std::max<uint32_t>(b->pool_cap, 4u * (b->cap + 2u) + 128u);
   b->fx_grid = want_grid;
@@ -523,7 +528,6 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   fa.dstat = dstat;
   launch_find(fa, ix->wide, st);
   HIP_TRY(hipEventRecord(b->ev[EV_FIND], st));
-  HIP_TRY(hipEventRecord(b->ev[EV_FX_FAST], st));  // the fast filter/extract kernel slots in here
 
   FxArgs xa;
   xa.fwd = ix->st[0];
@@ -538,6 +542,9 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   xa.pool_cap = b->pool_cap;
   xa.work = nullptr;
   xa.n_work = n;
+  xa.n_work_ptr = nullptr;
+  xa.wpool = (Ent*)b->wpool.p;
+  xa.work_out = (uint32_t*)b->work.p;
   xa.fin = (sigax_block*)b->fin.p;
   xa.fin_read = (uint32_t*)b->fin_read.p;
   xa.fin_seq = (uint32_t*)b->fin_seq.p;
@@ -545,6 +552,14 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   xa.fin_cnt = (uint32_t*)b->fin_cnt.p;
   xa.substring = (uint8_t*)b->substring.p;
   xa.dstat = dstat;
+  static const bool only_general = getenv("SIGAX_GENERAL_ONLY") != nullptr;  // debugging aid: skip the fast kernel
+  if (!only_general) {
+    launch_filter_extract_fast(xa, ix->wide, fast_grid, st);
+    xa.work = (const uint32_t*)b->work.p;  // the general kernel redoes what the fast one queued
+    xa.n_work = 0;
+    xa.n_work_ptr = dstat + DS_SLOW_READS;
+  }
+  HIP_TRY(hipEventRecord(b->ev[EV_FX_FAST], st));
   launch_filter_extract(xa, ix->wide, b->fx_grid, st);
   HIP_TRY(hipEventRecord(b->ev[EV_FX_GEN], st));
 

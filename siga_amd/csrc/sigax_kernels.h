@@ -50,6 +50,9 @@ struct FxArgs {
   uint32_t pool_cap;
   const uint32_t* work;  // optional list of read ids; NULL = all reads
   unsigned long long n_work;
+  const unsigned long long* n_work_ptr;  // if set, the list length is read from device memory
+  Ent* wpool;         // fast kernel: [waves][fast_pool_entries_per_wave()]
+  uint32_t* work_out; // fast kernel: reads queued for the general kernel (count in dstat[DS_SLOW_READS])
   sigax_block* fin;   // unordered final blocks
   uint32_t* fin_read;
   uint32_t* fin_seq;
@@ -92,6 +95,8 @@ void launch_kmer_count(const FmStrand& s, bool wide, const unsigned char* kmers,
                        unsigned long long* out, hipStream_t st);
 void launch_find(const FindArgs& a, bool wide, hipStream_t st);
 void launch_filter_extract(const FxArgs& a, bool wide, unsigned grid, hipStream_t st);
+void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid, hipStream_t st);
+unsigned long long fast_pool_entries_per_wave();
 void launch_scan(const uint32_t* cnt, unsigned long long n, unsigned long long* partial, unsigned long long* offs,
                  unsigned long long* total_out, hipStream_t st);
 unsigned long long scan_partials_needed(unsigned long long n);

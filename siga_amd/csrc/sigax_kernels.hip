@@ -666,7 +666,8 @@ __global__ __launch_bounds__(256) void k_filter_extract(FxArgs A) {
   u64 nlanes = (u64)gridDim.x * 256;
   Fx<WIDE> fx(A, tb, A.pool + gid * A.pool_cap);
   u64 nocc = 0, nerr = 0, nover = 0, nsub = 0;
-  for (u64 w = gid; w < A.n_work; w += nlanes) {
+  const u64 n_work = A.n_work_ptr ? *A.n_work_ptr : A.n_work;
+  for (u64 w = gid; w < n_work; w += nlanes) {
     u32 r = A.work ? A.work[w] : (u32)w;
     fx.nocc = 0;
     fx.run(r);
@@ -684,6 +685,352 @@ __global__ __launch_bounds__(256) void k_filter_extract(FxArgs A) {
     if (nocc) atomicAdd(&A.dstat[DS_OCC_EXTRACT], nocc);
     if (nerr) atomicAdd(&A.dstat[DS_EXTRACT_ERRORS], nerr);
     if (nover) atomicAdd(&A.dstat[DS_POOL_OVERFLOW], nover);
+    if (nsub) atomicAdd(&A.dstat[DS_SUBSTRING], nsub);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
+// k_filter_extract_fast: one wave per read, one lane per overlap block.
+//
+// Same algorithm as Fx above, parallelised over the blocks of a list.  A group of the extractor
+// (overlap_builder.cpp:720-722) is a 64-bit alive mask over fixed lane slots: block order inside a group is lane
+// order, so "top-level blocks" are the alive lanes whose length equals the first alive lane's, erasing an invalid
+// block clears its bit, and a branch copies the lanes' entries to a fresh 64-entry slot of the wave's pool.  The
+// group being worked on lives in registers; with a single group (the common case: every overlapping read agrees on
+// the next base) a whole extraction runs without touching the pool.  Symbol tests ("exts[k] > 0") are wave ballots.
+// Reads that need SubMaximalBlockFilter::resolve, have more than 64 blocks on a side, or outgrow the wave's pool
+// are queued for the general kernel; nothing global is written for a read before it has completed here.
+// -------------------------------------------------------------------------------------------------------
+#define FX_NSLOT 24
+#define FX_OUTCAP 192
+#define FX_WPOOL (FX_NSLOT * 64 + FX_OUTCAP)
+
+struct WaveSh {
+  u64 alive[FX_NSLOT];
+  u64 ivlo[64], ivhi[64];
+  unsigned short perm[64];
+  unsigned char D[FX_NSLOT], I[FX_NSLOT];
+};
+
+__device__ __forceinline__ u64 readlane64(u64 v, u32 l) {
+  u32 lo = __builtin_amdgcn_readlane((u32)v, l), hi = __builtin_amdgcn_readlane((u32)(v >> 32), l);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ u64 sel5(const u64 v[5], u32 k) {
+  return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : k == 3 ? v[3] : v[4];
+}
+
+template <bool WIDE>
+struct FastFx {
+  const FxArgs& A;
+  const FmTables& tb;
+  WaveSh& sh;
+  FmRef F, R;
+  Ent* wpool;  // FX_NSLOT group slots of 64 entries, then FX_OUTCAP emitted entries
+  u32 lane;
+  u64 lt;      // lanes below this one
+  const sigax_block* slots;
+  u32 nout;
+  u64 nocc;
+  bool xerror;
+
+  __device__ FastFx(const FxArgs& a, const FmTables& t, WaveSh& s, Ent* wp)
+      : A(a), tb(t), sh(s), F(fm_ref(a.fwd, 0)), R(fm_ref(a.rev, 1)), wpool(wp), lane(threadIdx.x & 63u),
+        lt((1ull << (threadIdx.x & 63u)) - 1ull), slots(nullptr), nout(0), nocc(0), xerror(false) {}
+
+  __device__ u32 af_of(u32 src) const {
+    u32 ch = src / A.cap;
+    return ch == 0 ? SIGAX_AF_CHAIN0 : ch == 1 ? SIGAX_AF_CHAIN1 : ch == 2 ? SIGAX_AF_CHAIN2 : SIGAX_AF_CHAIN3;
+  }
+  __device__ FmRef ext_index(u32 src) const { return fm_pick((src / A.cap) < 2, R, F); }
+
+  __device__ void load_ent(Ent& e, u32 src) const {
+    const ulonglong2* b = reinterpret_cast<const ulonglong2*>(slots + src);
+    ulonglong2 c0 = b[0], c1 = b[1], t = b[4];
+    e.c0lo = c0.x; e.c0hi = c0.y; e.c1lo = c1.x; e.c1hi = c1.y;
+    e.src = src; e.len = (u32)t.x; e.pad0 = e.pad1 = 0;
+  }
+  __device__ void put(Ent* dst, const Ent& e) const {
+    ulonglong2* d = reinterpret_cast<ulonglong2*>(dst);
+    d[0] = make_ulonglong2(e.c0lo, e.c0hi);
+    d[1] = make_ulonglong2(e.c1lo, e.c1hi);
+    d[2] = make_ulonglong2((u64)e.src | ((u64)e.len << 32), 0ull);
+  }
+  __device__ void get(Ent& e, const Ent* src) const {
+    const ulonglong2* d = reinterpret_cast<const ulonglong2*>(src);
+    ulonglong2 a = d[0], b = d[1], c = d[2];
+    e.c0lo = a.x; e.c0hi = a.y; e.c1lo = b.x; e.c1hi = b.y;
+    e.src = (u32)c.x; e.len = (u32)(c.x >> 32); e.pad0 = e.pad1 = 0;
+  }
+
+  // IntervalPair::updateR(b, index) from the two rank vectors already in registers
+  __device__ void apply_updateR(Ent& e, u32 b, u32 which, const u64 l[5], const u64 u[5]) const {
+    u64 d0 = u[0] - l[0], d1 = u[1] - l[1], d2 = u[2] - l[2], d3 = u[3] - l[3];
+    u64 acc = b == 0 ? 0 : b == 1 ? d0 : b == 2 ? d0 + d1 : b == 3 ? d0 + d1 + d2 : d0 + d1 + d2 + d3;
+    u64 lb = sel5(l, b), ub = sel5(u, b);
+    u64 pb = tb.C[which][b];
+    e.c0lo += acc;
+    e.c0hi = e.c0lo + (ub - lb) - 1;
+    e.c1lo = pb + lb;
+    e.c1hi = pb + ub - 1;
+  }
+
+  // IrreducibleBlockListExtractor::extract over the n entries held one per lane (already sorted by length desc).
+  // Returns false when the read has to go to the general kernel.
+  __device__ bool extract(Ent e, u32 n) {
+    if (n == 0) return true;
+    u32 cur = 0, ng = 1, nslot = 1;
+    sh.alive[0] = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    sh.D[0] = 0;
+    u32 guard = 0;
+    while (ng > 0) {
+      u32 ni = 0, p = 0;
+      while (p != ng) {
+        u32 slot = sh.D[p];
+        u64 alive = sh.alive[slot];
+        if (slot != cur) {
+          if ((sh.alive[cur] >> lane) & 1ull) put(wpool + cur * 64 + lane, e);
+          if ((alive >> lane) & 1ull) get(e, wpool + slot * 64 + lane);
+          cur = slot;
+        }
+        bool eraseGroup = true;
+        if (alive) {
+          const bool mine = (alive >> lane) & 1ull;
+          const u32 first = (u32)__ffsll((long long)alive) - 1u;
+          const u32 topLen = __builtin_amdgcn_readlane(e.len, first);
+          const bool isTop = mine && e.len == topLen;
+          const FmRef ix = ext_index(e.src);
+          const bool qcomp = (af_of(e.src) & 4u) != 0;
+          u64 l[5] = {0, 0, 0, 0, 0}, u[5] = {0, 0, 0, 0, 0};
+          if (mine) {
+            fm_rank5<WIDE>(ix, e.c1lo, l);
+            fm_rank5<WIDE>(ix, e.c1hi + 1, u);
+          }
+          // OverlapBlock::ext, complemented for QUERYCOMP blocks: x[k] > 0 in the query's frame
+          const bool x0 = mine && (u[0] - l[0]) > 0;
+          const bool xa = mine && (qcomp ? (u[4] - l[4]) : (u[1] - l[1])) > 0;
+          const bool xc = mine && (qcomp ? (u[3] - l[3]) : (u[2] - l[2])) > 0;
+          const bool xg = mine && (qcomp ? (u[2] - l[2]) : (u[3] - l[3])) > 0;
+          const bool xt = mine && (qcomp ? (u[1] - l[1]) : (u[4] - l[4])) > 0;
+          const u64 topMask = __ballot(isTop);
+          if (__ballot(isTop && x0)) {
+            // the top-level block has ended: emit the top-level blocks in list order (:747-766)
+            u64 bad = __ballot(isTop && !x0);
+            u64 emitMask = topMask;
+            if (bad) emitMask &= (1ull << ((u32)__ffsll((long long)bad) - 1u)) - 1ull;
+            nocc += 2ull * (u64)__popcll(topMask);
+            u32 ne = (u32)__popcll(emitMask);
+            if (nout + ne > FX_OUTCAP) return false;
+            if ((emitMask >> lane) & 1ull) {
+              Ent br = e;
+              apply_updateR(br, 0, ix.which, l, u);
+              put(wpool + FX_NSLOT * 64 + nout + (u32)__popcll(emitMask & lt), br);
+            }
+            nout += ne;
+            if (bad) {
+              xerror = true;  // "substring read found during overlap computation" (:754-757): extract() returns
+              return true;
+            }
+          } else {
+            nocc += 2ull * (u64)__popcll(alive);
+            u64 any0 = __ballot(x0), any1 = __ballot(xa), any2 = __ballot(xc), any3 = __ballot(xg), any4 = __ballot(xt);
+            u32 nz = (any0 != 0) + (any1 != 0) + (any2 != 0) + (any3 != 0) + (any4 != 0);
+            if (nz == 1) {
+              u32 c = any0 ? 0u : any1 ? 1u : any2 ? 2u : any3 ? 3u : 4u;
+              u32 b = qcomp ? comp_rank(c) : c;
+              if (mine) apply_updateR(e, b, ix.which, l, u);
+              bool ok = mine && iv_valid(e.c0lo, e.c0hi) && iv_valid(e.c1lo, e.c1hi);
+              sh.alive[slot] = __ballot(ok);
+              eraseGroup = false;
+            } else {
+              const u64 anyk[5] = {any0, any1, any2, any3, any4};
+              for (u32 c = 0; c < 5; ++c) {
+                u64 ak = c == 0 ? anyk[0] : c == 1 ? anyk[1] : c == 2 ? anyk[2] : c == 3 ? anyk[3] : anyk[4];
+                if (!ak) continue;
+                if (nslot >= FX_NSLOT || ni >= FX_NSLOT) return false;
+                u32 ns = nslot++;
+                Ent br = e;
+                u32 b = qcomp ? comp_rank(c) : c;
+                if (mine) apply_updateR(br, b, ix.which, l, u);
+                bool ok = mine && iv_valid(br.c0lo, br.c0hi) && iv_valid(br.c1lo, br.c1hi);
+                if (ok) put(wpool + ns * 64 + lane, br);
+                sh.alive[ns] = __ballot(ok);
+                sh.I[ni++] = (unsigned char)ns;
+              }
+            }
+          }
+        }
+        // body `i = erase(i)` / `++i`, then the loop header's `++i` on the ring [g0..g(k-1), end]
+        if (eraseGroup) {
+          for (u32 i = p; i + 1 < ng; ++i) sh.D[i] = sh.D[i + 1];
+          --ng;
+        } else {
+          p = (p + 1) % (ng + 1);
+        }
+        p = (p + 1) % (ng + 1);
+        if (++guard > (1u << 20)) return false;
+      }
+      if (ng + ni > FX_NSLOT) return false;
+      for (u32 i = 0; i < ni; ++i) sh.D[ng++] = sh.I[i];
+    }
+    return true;
+  }
+
+  // One side of OverlapBuilder::overlap: side 0 = suffix lists (chains 0 and 3), side 1 = prefix lists (1 and 2).
+  __device__ bool side(u32 sd, const u32 cc[4], u64 L) {
+    const u32 chA = sd == 0 ? 0u : 1u, chB = sd == 0 ? 3u : 2u;
+    const u32 nA = cc[chA] & SIGAX_CC_COUNT_MASK, nB = cc[chB] & SIGAX_CC_COUNT_MASK;
+    const u32 c0 = (cc[0] & SIGAX_CC_CONTAIN) ? 1u : 0u, c1 = (cc[1] & SIGAX_CC_CONTAIN) ? 1u : 0u;
+    const u32 c2 = (cc[2] & SIGAX_CC_CONTAIN) ? 1u : 0u, c3 = (cc[3] & SIGAX_CC_CONTAIN) ? 1u : 0u;
+    // list X = chain A's blocks + containfwd {0,1}; list Y = chain B's blocks + containrev {2,3} (:1137-1140)
+    const u32 nX = nA + c0 + c1, nY = nB + c2 + c3, T = nX + nY;
+    if (T > 64) return false;
+    if (T == 0) return true;
+    const bool active = lane < T;
+    const u32 list = lane >= nX ? 1u : 0u;
+    const u32 k = list ? lane - nX : lane;
+    u32 src = 0;
+    if (active) {
+      if (!list) src = k < nA ? chA * A.cap + k : ((k == nA && c0) ? 0u : 1u) * A.cap + (A.cap - 1);
+      else src = k < nB ? chB * A.cap + k : ((k == nB && c2) ? 2u : 3u) * A.cap + (A.cap - 1);
+    }
+    Ent e;
+    e.c0lo = e.c0hi = e.c1lo = e.c1hi = 0; e.src = 0; e.len = 0; e.pad0 = e.pad1 = 0;
+    if (active) load_ent(e, src);
+    // stable rank by capped[0].lower inside the own list (SubMaximalBlockFilter::filter's sort, :930-931)
+    u32 rank = 0;
+    for (u32 j = 0; j < T; ++j) {
+      u64 loj = readlane64(e.c0lo, j);
+      u32 lj = j >= nX ? 1u : 0u, kj = lj ? j - nX : j;
+      if (active && lj == list && (loj < e.c0lo || (loj == e.c0lo && kj < k))) ++rank;
+    }
+    // adjacent blocks in that order must not intersect (:936-937), else resolve() is needed: general kernel
+    const u32 lbase = list ? nX : 0u, nlist = list ? nY : nX;
+    if (active) {
+      sh.ivlo[lbase + rank] = e.c0lo;
+      sh.ivhi[lbase + rank] = e.c0hi;
+    }
+    wave_lds_sync();
+    bool inter = false;
+    if (active && rank + 1 < nlist) {
+      u64 nlo = sh.ivlo[lbase + rank + 1], nhi = sh.ivhi[lbase + rank + 1];
+      inter = intersecting(e.c0lo, e.c0hi, nlo, nhi);
+    }
+    wave_lds_sync();
+    if (__ballot(inter)) return false;
+    const bool member = active && e.len != L;  // ContainmentBlockRemover (:1094-1111)
+    const u32 nm = (u32)__popcll(__ballot(member));
+    u32 pos = 0;
+    if (A.irreducible) {
+      // suffixfwd += suffixrev; stable sort by length descending (:715-716,1169): ties keep list X first
+      for (u32 j = 0; j < T; ++j) {
+        u32 lenj = __builtin_amdgcn_readlane(e.len, j);
+        u32 lj = j >= nX ? 1u : 0u;
+        bool mj = lenj != L;
+        if (mj && (lenj > e.len || (lenj == e.len && lj < list))) ++pos;
+      }
+      if (member) sh.perm[pos] = (unsigned short)src;
+      wave_lds_sync();
+      Ent g;
+      g.c0lo = g.c0hi = g.c1lo = g.c1hi = 0; g.src = 0; g.len = 0; g.pad0 = g.pad1 = 0;
+      if (lane < nm) load_ent(g, sh.perm[lane]);
+      wave_lds_sync();
+      return extract(g, nm);
+    }
+    // exhaustive: the filtered lists go out as they are, X then Y, each in capped[0].lower order (:1175-1178)
+    for (u32 j = 0; j < T; ++j) {
+      u32 lenj = __builtin_amdgcn_readlane(e.len, j);
+      u32 rj = __builtin_amdgcn_readlane(rank, j);
+      u32 lj = j >= nX ? 1u : 0u;
+      if (lenj != L && (lj < list || (lj == list && rj < rank))) ++pos;
+    }
+    if (nout + nm > FX_OUTCAP) return false;
+    if (member) put(wpool + FX_NSLOT * 64 + nout + pos, e);
+    nout += nm;
+    return true;
+  }
+
+  // returns false when the read must be redone by the general kernel
+  __device__ bool run(u32 r) {
+    nout = 0;
+    xerror = false;
+    slots = A.arena + (u64)r * 4 * A.cap;
+    u64 L = A.offs[r + 1] - A.offs[r];
+    u32 cc[4];
+    for (int o = 0; o < 4; ++o) cc[o] = A.chain_cnt[(u64)r * 4 + o];
+    // containfwd, containrev first (:1161-1162)
+    {
+      bool has = lane < 4 && (cc[lane & 3] & SIGAX_CC_CONTAIN);
+      u64 m = __ballot(has);
+      if (has) {
+        Ent e;
+        load_ent(e, lane * A.cap + (A.cap - 1));
+        put(wpool + FX_NSLOT * 64 + (u32)__popcll(m & lt), e);
+      }
+      nout = (u32)__popcll(m);
+    }
+    if (A.irreducible) {
+      if (!side(0, cc, L)) return false;  // extract(&suffixfwd, blocks) first, then the prefix lists (:1169-1173)
+      if (!side(1, cc, L)) return false;
+    } else {
+      if (!side(0, cc, L)) return false;
+      if (!side(1, cc, L)) return false;
+    }
+    // flush: one allocation per read, blocks tagged (read, position in hit)
+    u64 base = 0;
+    if (lane == 0) base = atomicAdd(&A.dstat[DS_FIN_TOP], (u64)nout);
+    base = readlane64(base, 0);
+    for (u32 i = lane; i < nout; i += 64) {
+      u64 slot = base + i;
+      if (slot < A.fin_cap) {
+        Ent e;
+        get(e, wpool + FX_NSLOT * 64 + i);
+        const sigax_block& b = slots[e.src];
+        store_block(A.fin + slot, e.c0lo, e.c0hi, e.c1lo, e.c1hi, b.raw0_lo, b.raw0_hi, b.raw1_lo, b.raw1_hi, b.length, b.af);
+        A.fin_read[slot] = r;
+        A.fin_seq[slot] = i;
+      }
+    }
+    return true;
+  }
+};
+
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_filter_extract_fast(FxArgs A) {
+  __shared__ FmTables tb;
+  __shared__ WaveSh shm[4];
+  fm_tables_load(tb, A.fwd, A.rev);
+  const u32 wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const u64 wave = (u64)blockIdx.x * 4 + wid, nwaves = (u64)gridDim.x * 4;
+  FastFx<WIDE> fx(A, tb, shm[wid], A.wpool + wave * FX_WPOOL);
+  u64 nerr = 0, nsub = 0;
+  for (u64 r = wave; r < A.n_reads; r += nwaves) {
+    u64 occ_before = fx.nocc;
+    bool done = fx.run((u32)r);
+    if (!done) {
+      fx.nocc = occ_before;  // the general kernel recounts this read
+      if (lane == 0) {
+        u64 w = atomicAdd(&A.dstat[DS_SLOW_READS], 1ull);
+        A.work_out[w] = (u32)r;
+      }
+      continue;
+    }
+    if (fx.xerror) ++nerr;
+    if (lane == 0) {
+      u32 sub = 0;
+      for (int o = 0; o < 4; ++o) sub |= A.chain_cnt[r * 4 + o] & SIGAX_CC_SUBSTRING;
+      A.fin_cnt[r] = fx.nout;
+      A.substring[r] = sub ? 1 : 0;
+      if (sub) ++nsub;
+    }
+  }
+  if (lane == 0) {
+    if (fx.nocc) atomicAdd(&A.dstat[DS_OCC_EXTRACT], fx.nocc);
+    if (nerr) atomicAdd(&A.dstat[DS_EXTRACT_ERRORS], nerr);
     if (nsub) atomicAdd(&A.dstat[DS_SUBSTRING], nsub);
   }
 }
@@ -833,8 +1180,16 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
   else hipLaunchKernelGGL(k_find<false>, dim3(g), dim3(256), 0, st, a);
 }
 
+void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid, hipStream_t st) {
+  if (a.n_reads == 0) return;
+  if (wide) hipLaunchKernelGGL(k_filter_extract_fast<true>, dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_filter_extract_fast<false>, dim3(grid), dim3(256), 0, st, a);
+}
+
+unsigned long long fast_pool_entries_per_wave() { return FX_WPOOL; }
+
 void launch_filter_extract(const FxArgs& a, bool wide, unsigned grid, hipStream_t st) {
-  if (a.n_work == 0) return;
+  if (a.n_work == 0 && !a.n_work_ptr) return;
   if (wide) hipLaunchKernelGGL(k_filter_extract<true>, dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_filter_extract<false>, dim3(grid), dim3(256), 0, st, a);
 }
