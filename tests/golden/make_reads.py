@@ -88,12 +88,12 @@ def fast_reads(G, L, N, seed):
     npos = G - L + 1
     if 2 * npos < N:
         raise ValueError("not enough distinct (pos,strand) draws")
-    # unique (pos, strand) keys, in random order
-    keys = rng.choice(2 * npos, size=N, replace=False) if 2 * npos < (1 << 31) else None
-    if keys is None:
-        keys = np.unique(rng.integers(0, 2 * npos, size=int(N * 1.1), dtype=np.int64))
-        rng.shuffle(keys)
-        keys = keys[:N]
+    # unique (pos, strand) keys in random order: oversample, de-duplicate, shuffle, cut
+    keys = np.unique(rng.integers(0, 2 * npos, size=int(N * 1.25) + 64, dtype=np.int64))
+    while len(keys) < N:
+        keys = np.unique(np.concatenate([keys, rng.integers(0, 2 * npos, size=N, dtype=np.int64)]))
+    rng.shuffle(keys)
+    keys = keys[:N]
     pos = (keys >> 1).astype(np.int64)
     strand = (keys & 1).astype(bool)
     idx = pos[:, None] + np.arange(L, dtype=np.int64)[None, :]

@@ -1,0 +1,110 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/sigax.h declares, refuses to
+run without a device (no CPU fallback), and the host logic (index builder, readers, stem, formatters) matches the
+oracle and the reference's KATs."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from siga_amd import _lib, host
+from siga_amd import overlap as ov
+from tests.fixtures import GOLDEN, ROOT, fixture, md5_prefix
+
+
+def test_header_symbols_all_exported():
+    hdr = open(os.path.join(ROOT, "include", "sigax.h")).read()
+    declared = set(re.findall(r"\b(sigax_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = _lib.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (sigax_[a-z_0-9]+)", out))
+    assert declared <= exported
+
+
+def test_struct_sizes_match_header():
+    assert _lib.BLOCK_DTYPE.itemsize == 80 and _lib.EDGE_DTYPE.itemsize == 16
+    assert C.sizeof(_lib.Stats) == 9 * 8
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    fx = fixture("corner")
+    with pytest.raises(ov.SigaxError) as e:
+        ov.FMIndexPair.load(fx.prefix)
+    assert e.value.code == -3  # SIGAX_E_DEVICE
+    n = C.c_int(-1)
+    assert _lib.lib().sigax_device_count(C.byref(n)) != 0 or n.value == 0
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "siga_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.replace("the oracle", "").replace("oracle-", ""), os.path.join(dirpath, f)
+
+
+@pytest.mark.parametrize("name", ["corner", "rep", "dup", "tiny", "toy"])
+def test_siga_index_matches_oracle_builder(name, tmp_path):
+    """`siga index` (own SA-IS, siga_amd/host) is byte-identical to the oracle's naive suffix sort (model B)."""
+    fx = fixture(name)
+    prefix = str(tmp_path / name)
+    host.index_file(fx.fa, prefix, threads=2)
+    for ext in (".bwt", ".rbwt", ".sai", ".rsai"):
+        assert open(prefix + ext, "rb").read() == open(fx.prefix + ext, "rb").read(), ext
+    if name == "toy":
+        assert md5_prefix(open(prefix + ".bwt", "rb").read()) == GOLDEN["toy"]["md5"]["bwt"]
+        assert md5_prefix(open(prefix + ".sai", "rb").read()) == GOLDEN["toy"]["md5"]["sai"]
+
+
+def test_cli_index_and_help(tmp_path):
+    fx = fixture("corner")
+    cwd = str(tmp_path)
+    fa = os.path.join(cwd, "reads.fa.gz")
+    import gzip
+    with gzip.open(fa, "wb") as f:
+        f.write(open(fx.fa, "rb").read())
+    r = subprocess.run([host.CLI_PATH, "index", "-t", "2", fa], cwd=cwd)
+    assert r.returncode == 0
+    for ext in (".bwt", ".rbwt", ".sai", ".rsai"):  # Utils::stem("reads.fa.gz") == "reads"; outputs land in the CWD
+        assert open(os.path.join(cwd, "reads" + ext), "rb").read() == open(fx.prefix + ext, "rb").read()
+    h = subprocess.run([host.CLI_PATH, "overlap", "--help"], capture_output=True)
+    assert h.returncode == 0 and b"--min-overlap" in h.stdout  # help returns 256 -> exit status 0
+    bad = subprocess.run([host.CLI_PATH, "index", "/nonexistent.fa"], cwd=cwd, capture_output=True)
+    assert bad.returncode == 255  # runner returned -1
+
+
+def test_stem_rule():  # test/utils_test.cpp:32-36
+    for p in ("a.txt", "a.txt.gz", "a.txt.bz2", "/x/y/a.fa", "a"):
+        assert host.stem(p) == "a"
+
+
+def test_reader_semantics(tmp_path):  # src/kseq.cpp:127-228, test/preprocess_test.cpp:30-43
+    fa = tmp_path / "x.fa"
+    fa.write_text(">r1 BX:Z:ACGT CR:i:7\nACGT\nAC\n\n>r2\tcomment\n  GGTT  \n>r3\nTT\n")
+    recs = ov.read_sequences(str(fa))
+    assert recs == [("r1", "BX:Z:ACGT CR:i:7", "ACGTAC"), ("r2", "comment", "GGTT"), ("r3", "", "TT")]
+    fq = tmp_path / "x.fq"
+    fq.write_text("@q1 c\nACGT\n+\nIIII\n@q2\nGG\n+q2\nII\n")
+    assert ov.read_sequences(str(fq)) == [("q1", "c", "ACGT"), ("q2", "", "GG")]
+
+
+def test_vertex_tags_and_edge_coords():
+    assert ov._vertex_tags("BX:Z:ACGT CR:i:7 EX:Z:foo") == "\tCR:i:7\tBX:Z:ACGT\tEX:Z:foo"  # asqg.cpp:171-186 order
+    assert ov._vertex_tags("CR:i:x") == "\tCR:i:0" and ov._vertex_tags("CR:Z:7") == ""
+    # OverlapBlock::overlap (overlap_builder.cpp:158-175) on the corner fixture's first ED line "b a 0 20 30 9 29 30"
+    assert ov.edge_coords(21, 3, 30, 30) == (0, 20, 9, 29)
+    assert ov.edge_coords(21, 0, 30, 30) == (9, 29, 0, 20)
+
+
+def test_name_ranks_are_string_order():
+    r = ov.name_ranks(["r10", "r9", "r1", "r10"])
+    assert list(r) == [1, 2, 0, 1]  # "r1" < "r10" < "r9"; equal names share a rank (overlap_builder.cpp:358,365)

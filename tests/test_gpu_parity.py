@@ -108,3 +108,61 @@ def test_empty_batch_and_errors(sa):
         sa.FMIndexPair.load("/nonexistent/prefix")
     with pytest.raises(sa.SigaxError):  # edges without read metadata
         sa.OverlapBuilder(_pair(sa, fx)).overlap(fx.seqs[:3], 20, edges=True)
+
+
+# ---- host C++ side (siga_amd/host): OverlapBuilder::build and the CLI, drop-in file naming -----------------------
+def test_cli_overlap_writes_reference_asqg_gz(sa, tmp_path):
+    """`siga overlap -m 45 toy.fa` in a scratch CWD: <stem>.asqg.gz must gunzip to the oracle's ASQG bytes
+    (= the reference's own output by md5)."""
+    import gzip
+    import shutil
+    import subprocess
+    from siga_amd import host
+    fx = fixture("toy")
+    cwd = str(tmp_path)
+    for ext in (".fa", ".bwt", ".rbwt", ".sai", ".rsai"):
+        shutil.copy(fx.prefix + ext, cwd)
+    r = subprocess.run([host.CLI_PATH, "overlap", "-m", "45", "-t", "4", "toy.fa"], cwd=cwd, capture_output=True)
+    assert r.returncode == 0, r.stderr
+    got = gzip.open(cwd + "/toy.asqg.gz", "rb").read().decode()
+    want, _, _ = fx.oracle_asqg(45)
+    assert got == want
+    assert md5_prefix(got) == GOLDEN["toy"]["md5"]["asqg_t1"]
+    x = subprocess.run([host.CLI_PATH, "overlap", "-m", "45", "-x", "--no-opposite-strand", "-p", "toy", "toy.fa"], cwd=cwd)
+    assert x.returncode == 0
+    wantx, _, _ = fx.oracle_asqg(45, irreducible=False, rc=False)
+    assert gzip.open(cwd + "/toy.asqg.gz", "rb").read().decode() == wantx
+    bad = subprocess.run([host.CLI_PATH, "overlap", "-p", "nosuchprefix", "toy.fa"], cwd=cwd, capture_output=True)
+    assert bad.returncode == 255
+
+
+def test_host_builder_vertex_tags_and_fastq(sa, tmp_path):
+    """VT tags from FASTA comments (CR/BX/EX) and FASTQ input through the C++ OverlapBuilder::build."""
+    from siga_amd import host
+    from oracle import pyoracle as po
+    fx = fixture("tiny")
+    reads = fx.reads[:60]
+    fq = tmp_path / "t.fq"
+    with open(fq, "w") as f:
+        for i, (n, s) in enumerate(reads):
+            c = " BX:Z:AC%d CR:i:%d junk EX:Z:e" % (i, i) if i % 3 == 0 else (" CR:i:oops" if i % 3 == 1 else "")
+            f.write("@%s%s\n%s\n+\n%s\n" % (n, c, s, "I" * len(s)))
+    prefix = str(tmp_path / "t")
+    host.index_file(str(fq), prefix)
+    out = str(tmp_path / "t.asqg")
+    host.overlap_file(str(fq), prefix, 20, out)
+    fwd = po.Index.load(prefix + ".bwt", prefix + ".sai")
+    rev = po.Index.load(prefix + ".rbwt", prefix + ".rsai")
+    po.build_asqg(fwd, rev, str(fq), 20, str(tmp_path / "o.asqg"))
+    assert open(out).read() == open(tmp_path / "o.asqg").read()
+
+
+def test_mid_fixture_through_gpu_matches_reference_md5(sa, tmp_path):
+    """40 000 x 150 bp (SURVEY.md App. C `mid`): GPU ASQG md5 == the reference's recorded md5 prefix."""
+    from siga_amd import host
+    fx = fixture("mid")
+    out = str(tmp_path / "mid.asqg")
+    host.overlap_file(fx.fa, fx.prefix, GOLDEN["mid"]["min_overlap"], out)
+    text = open(out).read()
+    assert md5_prefix(text) == GOLDEN["mid"]["md5"]["asqg_t1"]
+    assert len(ed_lines(text)) == GOLDEN["mid"]["ed_irreducible"]
