@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU restatement (0 = skip)")
     ap.add_argument("--workdir", default=None)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 flow on fewer GPUs than ranks (edge records gathered via host)")
     args = ap.parse_args()
 
     import torch
@@ -57,13 +59,17 @@ def main():
         log("WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the overlap path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=60),
-                                device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=60),
+                                    device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=60))
 
     from siga_amd import _lib, host
     from siga_amd import build as sbuild
@@ -89,7 +95,7 @@ def main():
         log("reads + index ready in %.1f s (%d reads, %d symbols per strand)" % (time.time() - t0, n_total, n_total * (L + 1)))
     if world > 1:
         dist.barrier()
-    pair = FMIndexPair.load(prefix, device=local_rank)
+    pair = FMIndexPair.load(prefix, device=dev_index)
     info = pair.info()
     # ReadInfo{name,length}: names r<i>; rank of a name under std::string operator<
     names = np.char.add("r", np.arange(n_total).astype(str))
@@ -116,7 +122,7 @@ def main():
 
     class _EdgeView:  # zero-copy view of the library's device edge buffer for torch.distributed
         def __init__(self, ptr, n):
-            self.__cuda_array_interface__ = {"shape": (n, 4), "typestr": "<i4", "data": (ptr, True), "version": 2}
+            self.__cuda_array_interface__ = {"shape": (n, 4), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
     stats = _lib.Stats()
     kms = (C.c_float * 5)()
@@ -132,6 +138,8 @@ def main():
             lib.sigax_batch_device_outputs(batch, None, None, None, C.byref(d_edges))
             ne = int(stats.n_edges)
             local = torch.as_tensor(_EdgeView(d_edges.value, ne), device=dev) if ne else torch.zeros((0, 4), dtype=torch.int32, device=dev)
+            if args.backend == "gloo":
+                local = local.cpu()
             allv, counts = gather_edges(local)
             return sum(counts)
         return int(stats.n_edges)
@@ -153,7 +161,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kavg = ksum / max(args.steps, 1)

@@ -96,9 +96,7 @@ def fast_reads(G, L, N, seed):
     keys = keys[:N]
     pos = (keys >> 1).astype(np.int64)
     strand = (keys & 1).astype(bool)
-    idx = pos[:, None] + np.arange(L, dtype=np.int64)[None, :]
-    codes = genome[idx]
-    rc = (3 - codes)[:, ::-1]
-    codes = np.where(strand[:, None], rc, codes)
+    codes = np.lib.stride_tricks.sliding_window_view(genome, L)[pos]  # [N, L] copy
+    codes[strand] = (3 - codes[strand])[:, ::-1]
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
     return lut[codes], genome
