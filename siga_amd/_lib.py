@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libsigax.so")
+LIB_PATH = os.environ.get("SIGAX_LIB", os.path.join(HERE, "lib", "libsigax.so"))
 
 SIGAX_IRREDUCIBLE = 1
 SIGAX_RC = 2

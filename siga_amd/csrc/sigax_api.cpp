@@ -346,7 +346,9 @@ static int ensure(DevBuf* b, size_t bytes) {
   return SIGAX_OK;
 }
 
-enum { EV_START = 0, EV_FIND, EV_FX_FAST, EV_FX_GEN, EV_ORDER, EV_EDGES, EV_COUNT };
+enum { EV_START = 0, EV_FX_DONE, EV_ORDER, EV_EDGES, EV_COUNT };
+// per sub-batch: find begin/end on the find stream, fast begin/end and general end on the filter/extract stream
+enum { SV_F0 = 0, SV_F1, SV_X0, SV_X1, SV_G1, SV_COUNT };
 
 struct sigax_batch {
   sigax_index* ix;
@@ -363,13 +365,17 @@ struct sigax_batch {
   uint32_t read_base, minov, flags;
   bool ran;
   // arenas
-  DevBuf arena, chain_cnt, pool, wpool, work, fin, fin_read, fin_seq, fin_cnt, substring, block_offs, outb, edge_cnt,
+  DevBuf arena, chain_cnt, pool, wpool, work, occ_side, slow_flag, offs2, item_base, fin, fin_cnt, substring, block_offs, outb, edge_cnt,
       edge_offs, edges, partial, dstat;
   uint32_t cap;
   uint32_t pool_cap;
   unsigned fx_grid;
   u64 fin_cap, edge_cap;
+  bool fin_grown;
   hipEvent_t ev[EV_COUNT];
+  hipEvent_t sev[SIGAX_MAX_SUB][SV_COUNT];
+  hipStream_t s_find, s_fx;  // internal pipeline: sub-batch i's filter/extract overlaps sub-batch i+1's find
+  unsigned nsub;
   sigax_stats last;
   u64 last_total_blocks, last_total_edges;
   bool finished;
@@ -378,13 +384,18 @@ struct sigax_batch {
 extern "C" void sigax_batch_destroy(sigax_batch* b) {
   if (!b) return;
   hipSetDevice(b->ix->device);
-  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->fin, &b->fin_read, &b->fin_seq,
+  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin,
                    &b->fin_cnt, &b->substring, &b->block_offs, &b->outb, &b->edge_cnt, &b->edge_offs, &b->edges,
                    &b->partial, &b->dstat};
   for (DevBuf* d : all)
     if (d->p) hipFree(d->p);
   for (int i = 0; i < EV_COUNT; ++i)
     if (b->ev[i]) hipEventDestroy(b->ev[i]);
+  for (int i = 0; i < SIGAX_MAX_SUB; ++i)
+    for (int j = 0; j < SV_COUNT; ++j)
+      if (b->sev[i][j]) hipEventDestroy(b->sev[i][j]);
+  if (b->s_find) hipStreamDestroy(b->s_find);
+  if (b->s_fx) hipStreamDestroy(b->s_fx);
   delete b;
 }
 
@@ -409,14 +420,24 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
   b->pool_cap = 0;
   b->fx_grid = 0;
   b->fin_cap = b->edge_cap = 0;
+  b->fin_grown = false;
   memset(&b->last, 0, sizeof(b->last));
   b->last_total_blocks = b->last_total_edges = 0;
   for (int i = 0; i < EV_COUNT; ++i) b->ev[i] = nullptr;
-  for (int i = 0; i < EV_COUNT; ++i) {
-    hipError_t e = hipEventCreate(&b->ev[i]);
+  for (int i = 0; i < SIGAX_MAX_SUB; ++i)
+    for (int j = 0; j < SV_COUNT; ++j) b->sev[i][j] = nullptr;
+  b->s_find = b->s_fx = nullptr;
+  b->nsub = 1;
+  {
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < EV_COUNT && e == hipSuccess; ++i) e = hipEventCreate(&b->ev[i]);
+    for (int i = 0; i < SIGAX_MAX_SUB && e == hipSuccess; ++i)
+      for (int j = 0; j < SV_COUNT && e == hipSuccess; ++j) e = hipEventCreate(&b->sev[i][j]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->s_find, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->s_fx, hipStreamNonBlocking);
     if (e != hipSuccess) {
       sigax_batch_destroy(b);
-      return fail(SIGAX_E_DEVICE, "hipEventCreate: %s", hipGetErrorString(e));
+      return fail(SIGAX_E_DEVICE, "creating events/streams: %s", hipGetErrorString(e));
     }
   }
   int rc = ensure(&b->dstat, DS_COUNT * 8);
@@ -479,14 +500,18 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   // slots per chain: overlaps of length max(m,1)..L-1, plus one for the containment block
   uint32_t mm = std::max<uint32_t>(b->minov, 1u);
   b->cap = (b->cur_max_len > mm ? b->cur_max_len - mm : 0u) + 1u;
+  if (const char* ov = getenv("SIGAX_CAP_EXPERIMENT")) b->cap = (uint32_t)atoi(ov);  // measurement aid only
   int rc;
   if ((rc = ensure(&b->arena, (size_t)n * 4 * b->cap * sizeof(sigax_block))) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->chain_cnt, (size_t)n * 4 * 4)) != SIGAX_OK) return rc;
-  if ((rc = ensure(&b->fin_cnt, ((size_t)n + 1) * 4)) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->fin_cnt, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->occ_side, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->slow_flag, ((size_t)n + 1) * 4)) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->offs2, (2 * (size_t)n + 4) * 8)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->substring, (size_t)n + 16)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->block_offs, ((size_t)n + 2) * 8)) != SIGAX_OK) return rc;
   // fast filter/extract kernel: persistent waves (one read at a time per wave) with a private pool each
-  unsigned fast_grid = (unsigned)std::min<u64>(2048, ((u64)n + 3) / 4);
+  unsigned fast_grid = (unsigned)std::min<u64>(2048, (2 * (u64)n + 3) / 4);
   if (fast_grid == 0) fast_grid = 1;
   if ((rc = ensure(&b->wpool, (size_t)fast_grid * 4 * fast_pool_entries_per_wave() * SIGAX_ENT_BYTES)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->work, ((size_t)n + 1) * 4)) != SIGAX_OK) return rc;
@@ -497,12 +522,14 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   b->fx_grid = want_grid;
   b->pool_cap = want_pool;
   if ((rc = ensure(&b->pool, (size_t)want_grid * 256 * want_pool * SIGAX_ENT_BYTES)) != SIGAX_OK) return rc;
-  if (b->fin_cap == 0) b->fin_cap = (b->flags & SIGAX_IRREDUCIBLE) ? (u64)n * 8 + 1024 : (u64)n * 64 + 1024;
+  // the unordered arena is handed out in chunks (one atomic per chunk): leave room for every wave's / lane's tail
+  u64 chunk_slack = (u64)fast_grid * 4 * fast_fin_chunk() + (u64)want_grid * 256 * 64 + 1024;
+  u64 want_fin = ((b->flags & SIGAX_IRREDUCIBLE) ? (u64)n * 8 : (u64)n * 64) + chunk_slack;
+  b->fin_cap = std::max<u64>(b->fin_cap, want_fin);
   if ((rc = ensure(&b->fin, b->fin_cap * sizeof(sigax_block))) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->outb, b->fin_cap * sizeof(sigax_block))) != SIGAX_OK) return rc;
-  if ((rc = ensure(&b->fin_read, b->fin_cap * 4)) != SIGAX_OK) return rc;
-  if ((rc = ensure(&b->fin_seq, b->fin_cap * 4)) != SIGAX_OK) return rc;
-  u64 scan_n = std::max<u64>(n, b->fin_cap);
+  if ((rc = ensure(&b->item_base, (2 * (size_t)n + 2) * 8)) != SIGAX_OK) return rc;
+  u64 scan_n = std::max<u64>(2 * (u64)n, b->fin_cap);
   if ((rc = ensure(&b->partial, scan_partials_needed(scan_n) * 8)) != SIGAX_OK) return rc;
   if (edges) {
     if (b->edge_cap == 0) b->edge_cap = b->fin_cap * 2 + 1024;
@@ -512,68 +539,103 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   }
   u64* dstat = (u64*)b->dstat.p;
   HIP_TRY(hipMemsetAsync(dstat, 0, DS_COUNT * 8, st));
+  HIP_TRY(hipMemsetAsync(b->occ_side.p, 0, (2 * (size_t)n + 2) * 4, st));
+  HIP_TRY(hipMemsetAsync(b->slow_flag.p, 0, ((size_t)n + 1) * 4, st));
   HIP_TRY(hipEventRecord(b->ev[EV_START], st));
 
-  FindArgs fa;
-  fa.fwd = ix->st[0];
-  fa.rev = ix->st[1];
-  fa.seqs = b->d_seqs;
-  fa.offs = b->d_offs;
-  fa.n_reads = n;
-  fa.minov = b->minov;
-  fa.rc = (b->flags & SIGAX_RC) ? 1u : 0u;
-  fa.cap = b->cap;
-  fa.arena = (sigax_block*)b->arena.p;
-  fa.chain_cnt = (uint32_t*)b->chain_cnt.p;
-  fa.dstat = dstat;
-  launch_find(fa, ix->wide, st);
-  HIP_TRY(hipEventRecord(b->ev[EV_FIND], st));
-
-  FxArgs xa;
-  xa.fwd = ix->st[0];
-  xa.rev = ix->st[1];
-  xa.offs = b->d_offs;
-  xa.n_reads = n;
-  xa.cap = b->cap;
-  xa.irreducible = (b->flags & SIGAX_IRREDUCIBLE) ? 1u : 0u;
-  xa.arena = (const sigax_block*)b->arena.p;
-  xa.chain_cnt = (const uint32_t*)b->chain_cnt.p;
-  xa.pool = (Ent*)b->pool.p;
-  xa.pool_cap = b->pool_cap;
-  xa.work = nullptr;
-  xa.n_work = n;
-  xa.n_work_ptr = nullptr;
-  xa.wpool = (Ent*)b->wpool.p;
-  xa.work_out = (uint32_t*)b->work.p;
-  xa.fin = (sigax_block*)b->fin.p;
-  xa.fin_read = (uint32_t*)b->fin_read.p;
-  xa.fin_seq = (uint32_t*)b->fin_seq.p;
-  xa.fin_cap = b->fin_cap;
-  xa.fin_cnt = (uint32_t*)b->fin_cnt.p;
-  xa.substring = (uint8_t*)b->substring.p;
-  xa.dstat = dstat;
+  // Sub-batches: the finder is bound by the memory system's request rate, filter/extract by VALU issue; running
+  // sub-batch i's filter/extract while sub-batch i+1's finder runs overlaps the two.
+  static const char* env_sub = getenv("SIGAX_SUBBATCHES");
+  unsigned nsub = env_sub ? (unsigned)atoi(env_sub) : (n >= 4 * 131072u ? 4u : n >= 2 * 131072u ? 2u : 1u);
+  if (nsub < 1) nsub = 1;
+  if (nsub > SIGAX_MAX_SUB) nsub = SIGAX_MAX_SUB;
+  b->nsub = nsub;
   static const bool only_general = getenv("SIGAX_GENERAL_ONLY") != nullptr;  // debugging aid: skip the fast kernel
-  if (!only_general) {
-    launch_filter_extract_fast(xa, ix->wide, fast_grid, st);
-    xa.work = (const uint32_t*)b->work.p;  // the general kernel redoes what the fast one queued
-    xa.n_work = 0;
-    xa.n_work_ptr = dstat + DS_SLOW_READS;
-  }
-  HIP_TRY(hipEventRecord(b->ev[EV_FX_FAST], st));
-  launch_filter_extract(xa, ix->wide, b->fx_grid, st);
-  HIP_TRY(hipEventRecord(b->ev[EV_FX_GEN], st));
+  HIP_TRY(hipStreamWaitEvent(b->s_find, b->ev[EV_START], 0));
+  HIP_TRY(hipStreamWaitEvent(b->s_fx, b->ev[EV_START], 0));
+  for (unsigned i = 0; i < nsub; ++i) {
+    const uint32_t rb = (uint32_t)((u64)n * i / nsub), re = (uint32_t)((u64)n * (i + 1) / nsub);
+    FindArgs fa;
+    fa.fwd = ix->st[0];
+    fa.rev = ix->st[1];
+    fa.seqs = b->d_seqs;
+    fa.offs = b->d_offs;
+    fa.n_reads = n;
+    fa.minov = b->minov;
+    fa.rc = (b->flags & SIGAX_RC) ? 1u : 0u;
+    fa.cap = b->cap;
+    fa.read_begin = rb;
+    fa.read_end = re;
+    fa.arena = (sigax_block*)b->arena.p;
+    fa.chain_cnt = (uint32_t*)b->chain_cnt.p;
+    fa.dstat = dstat;
+    HIP_TRY(hipEventRecord(b->sev[i][SV_F0], b->s_find));
+    launch_find(fa, ix->wide, b->s_find);
+    HIP_TRY(hipEventRecord(b->sev[i][SV_F1], b->s_find));
+    HIP_TRY(hipStreamWaitEvent(b->s_fx, b->sev[i][SV_F1], 0));
 
-  launch_scan((const uint32_t*)b->fin_cnt.p, n, (u64*)b->partial.p, (u64*)b->block_offs.p, dstat + DS_TOTAL_BLOCKS, st);
+    FxArgs xa;
+    xa.fwd = ix->st[0];
+    xa.rev = ix->st[1];
+    xa.offs = b->d_offs;
+    xa.n_reads = n;
+    xa.cap = b->cap;
+    xa.irreducible = (b->flags & SIGAX_IRREDUCIBLE) ? 1u : 0u;
+    xa.arena = (const sigax_block*)b->arena.p;
+    xa.chain_cnt = (const uint32_t*)b->chain_cnt.p;
+    xa.pool = (Ent*)b->pool.p;
+    xa.pool_cap = b->pool_cap;
+    xa.wpool = (Ent*)b->wpool.p;
+    xa.work_out = (uint32_t*)b->work.p + rb;
+    xa.slow_counter = dstat + DS_SLOW_BASE + i;
+    xa.read_begin = rb;
+    xa.read_end = re;
+    xa.item_base = (u64*)b->item_base.p;
+    xa.fin = (sigax_block*)b->fin.p;
+    xa.fin_cap = b->fin_cap;
+    xa.fin_cnt = (uint32_t*)b->fin_cnt.p;
+    xa.occ_side = (uint32_t*)b->occ_side.p;
+    xa.slow_flag = (uint32_t*)b->slow_flag.p;
+    xa.substring = (uint8_t*)b->substring.p;
+    xa.dstat = dstat;
+    HIP_TRY(hipEventRecord(b->sev[i][SV_X0], b->s_fx));
+    if (!only_general) {
+      xa.work = nullptr;
+      xa.n_work = 0;
+      xa.n_work_ptr = nullptr;
+      launch_filter_extract_fast(xa, ix->wide, fast_grid, b->s_fx);
+      xa.work = (const uint32_t*)b->work.p + rb;  // the general kernel redoes what the fast one queued
+      xa.n_work = 0;
+      xa.n_work_ptr = dstat + DS_SLOW_BASE + i;
+    } else {
+      // every read of the sub-batch through the general kernel
+      std::vector<uint32_t> ids(re - rb);
+      for (uint32_t k = rb; k < re; ++k) ids[k - rb] = k;
+      HIP_TRY(hipMemcpyAsync((uint32_t*)b->work.p + rb, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, b->s_fx));
+      HIP_TRY(hipStreamSynchronize(b->s_fx));
+      xa.work = (const uint32_t*)b->work.p + rb;
+      xa.n_work = re - rb;
+      xa.n_work_ptr = nullptr;
+    }
+    HIP_TRY(hipEventRecord(b->sev[i][SV_X1], b->s_fx));
+    launch_filter_extract(xa, ix->wide, b->fx_grid, b->s_fx);
+    HIP_TRY(hipEventRecord(b->sev[i][SV_G1], b->s_fx));
+  }
+  HIP_TRY(hipEventRecord(b->ev[EV_FX_DONE], b->s_fx));
+  HIP_TRY(hipStreamWaitEvent(st, b->ev[EV_FX_DONE], 0));
+
+  launch_scan((const uint32_t*)b->fin_cnt.p, 2 * (u64)n, (u64*)b->partial.p, (u64*)b->offs2.p, dstat + DS_TOTAL_BLOCKS, st);
+  launch_pick_read_offsets((const u64*)b->offs2.p, n, (u64*)b->block_offs.p, st);
   OrderArgs oa;
   oa.fin = (const sigax_block*)b->fin.p;
-  oa.fin_read = (const uint32_t*)b->fin_read.p;
-  oa.fin_seq = (const uint32_t*)b->fin_seq.p;
+  oa.item_base = (const u64*)b->item_base.p;
+  oa.fin_cnt = (const uint32_t*)b->fin_cnt.p;
+  oa.n_items = 2 * (u64)n;
   oa.fin_cap = b->fin_cap;
-  oa.block_offs = (const u64*)b->block_offs.p;
+  oa.offs2 = (const u64*)b->offs2.p;
   oa.out = (sigax_block*)b->outb.p;
   oa.out_cap = b->fin_cap;
-  oa.dstat = dstat;
-  launch_order_scatter(oa, b->fin_cap, st);
+  launch_order_scatter(oa, st);
   HIP_TRY(hipEventRecord(b->ev[EV_ORDER], st));
 
   if (edges) {
@@ -633,6 +695,7 @@ extern "C" int sigax_batch_finish(sigax_batch* b, void* stream, sigax_stats* sta
     }
     if (ds[DS_FIN_TOP] > b->fin_cap) {
       b->fin_cap = ds[DS_FIN_TOP] + ds[DS_FIN_TOP] / 4 + 1024;
+      b->fin_grown = true;
       if (b->edge_cap) b->edge_cap = std::max<u64>(b->edge_cap, b->fin_cap * 2);
       again = true;
     }
@@ -653,7 +716,8 @@ extern "C" int sigax_batch_finish(sigax_batch* b, void* stream, sigax_stats* sta
     b->last.n_occ_find = ds[DS_OCC_FIND];
     b->last.n_occ_extract = ds[DS_OCC_EXTRACT];
     b->last.n_substring = ds[DS_SUBSTRING];
-    b->last.n_slow_reads = ds[DS_SLOW_READS];
+    b->last.n_slow_reads = 0;
+    for (int i = 0; i < SIGAX_MAX_SUB; ++i) b->last.n_slow_reads += ds[DS_SLOW_BASE + i];
     b->last.n_extract_errors = ds[DS_EXTRACT_ERRORS];
     b->last_total_blocks = ds[DS_TOTAL_BLOCKS];
     b->last_total_edges = b->last.n_edges;
@@ -712,10 +776,18 @@ extern "C" int sigax_batch_download(sigax_batch* b, sigax_result* out) {
 extern "C" int sigax_batch_kernel_ms(sigax_batch* b, float ms[5]) {
   if (!b || !ms) return fail(SIGAX_E_ARG, "NULL argument");
   if (!b->finished) return fail(SIGAX_E_STATE, "batch not finished");
-  for (int i = 0; i < 5; ++i) {
-    ms[i] = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms[i], b->ev[i], b->ev[i + 1]));
+  for (int i = 0; i < 5; ++i) ms[i] = 0.f;
+  for (unsigned i = 0; i < b->nsub; ++i) {  // sums over the sub-batch launches (which overlap across the two streams)
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, b->sev[i][SV_F0], b->sev[i][SV_F1]));
+    ms[0] += t;
+    HIP_TRY(hipEventElapsedTime(&t, b->sev[i][SV_X0], b->sev[i][SV_X1]));
+    ms[1] += t;
+    HIP_TRY(hipEventElapsedTime(&t, b->sev[i][SV_X1], b->sev[i][SV_G1]));
+    ms[2] += t;
   }
+  HIP_TRY(hipEventElapsedTime(&ms[3], b->ev[EV_FX_DONE], b->ev[EV_ORDER]));
+  HIP_TRY(hipEventElapsedTime(&ms[4], b->ev[EV_ORDER], b->ev[EV_EDGES]));
   return SIGAX_OK;
 }
 

@@ -23,9 +23,10 @@ enum {
   DS_FIN_TOP,      // bump allocator of the unordered final-block arena (may run past fin_cap: needed size)
   DS_TOTAL_BLOCKS, // written by the scan: sum of per-read block counts
   DS_TOTAL_EDGES,  // written by the edge scan
-  DS_SLOW_READS,
-  DS_COUNT = 16
+  DS_SLOW_BASE,    // [DS_SLOW_BASE + i]: reads sub-batch i queued for the general kernel (i < SIGAX_MAX_SUB)
+  DS_COUNT = 32
 };
+#define SIGAX_MAX_SUB 8
 
 struct Ent;  // defined in sigax_kernels.hip (48 bytes)
 #define SIGAX_ENT_BYTES 48
@@ -35,6 +36,7 @@ struct FindArgs {
   const unsigned char* seqs;
   const unsigned long long* offs;
   uint32_t n_reads, minov, rc, cap;  // cap = slots per chain; the last one holds the containment block
+  uint32_t read_begin, read_end;     // this launch's sub-batch
   sigax_block* arena;                // [n_reads][4][cap]
   uint32_t* chain_cnt;               // [n_reads][4]
   unsigned long long* dstat;
@@ -52,25 +54,28 @@ struct FxArgs {
   unsigned long long n_work;
   const unsigned long long* n_work_ptr;  // if set, the list length is read from device memory
   Ent* wpool;         // fast kernel: [waves][fast_pool_entries_per_wave()]
-  uint32_t* work_out; // fast kernel: reads queued for the general kernel (count in dstat[DS_SLOW_READS])
-  sigax_block* fin;   // unordered final blocks
-  uint32_t* fin_read;
-  uint32_t* fin_seq;
+  uint32_t* work_out; // fast kernel: reads queued for the general kernel, counted in *slow_counter
+  unsigned long long* slow_counter;
+  uint32_t read_begin, read_end;  // fast kernel: this launch's sub-batch
+  sigax_block* fin;   // unordered final blocks, allocated in per-wave / per-lane chunks
+  unsigned long long* item_base;  // [n_reads][2]: where a (read, side) item's blocks start in `fin`
   unsigned long long fin_cap;
-  uint32_t* fin_cnt;  // [n_reads]
+  uint32_t* fin_cnt;  // [n_reads][2]: blocks of the suffix side (+ containments) and of the prefix side
+  uint32_t* occ_side; // [n_reads][2]: what a completed fast side added to the statistics (taken back on redo)
+  uint32_t* slow_flag;// [n_reads]: read queued for the general kernel
   uint8_t* substring; // [n_reads]
   unsigned long long* dstat;
 };
 
 struct OrderArgs {
   const sigax_block* fin;
-  const uint32_t* fin_read;
-  const uint32_t* fin_seq;
+  const unsigned long long* item_base;  // [n_items]
+  const uint32_t* fin_cnt;              // [n_items]
+  unsigned long long n_items;           // 2 * n_reads
   unsigned long long fin_cap;
-  const unsigned long long* block_offs;
+  const unsigned long long* offs2;      // [n_items+1] per-(read, side) offsets in the ordered output
   sigax_block* out;
   unsigned long long out_cap;
-  const unsigned long long* dstat;
 };
 
 struct EdgeArgs {
@@ -100,7 +105,10 @@ unsigned long long fast_pool_entries_per_wave();
 void launch_scan(const uint32_t* cnt, unsigned long long n, unsigned long long* partial, unsigned long long* offs,
                  unsigned long long* total_out, hipStream_t st);
 unsigned long long scan_partials_needed(unsigned long long n);
-void launch_order_scatter(const OrderArgs& a, unsigned long long max_items, hipStream_t st);
+void launch_order_scatter(const OrderArgs& a, hipStream_t st);
+unsigned long long fast_fin_chunk();
+void launch_pick_read_offsets(const unsigned long long* offs2, unsigned long long n_reads, unsigned long long* block_offs,
+                              hipStream_t st);
 void launch_edges(const EdgeArgs& a, bool fill, unsigned long long max_blocks, hipStream_t st);
 
 #endif

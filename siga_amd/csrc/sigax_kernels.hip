@@ -13,6 +13,8 @@
 // Integer / index work only: HBM- and latency-bound gathers of 64-byte rank granules (fm_layout.h); no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "sigax_kernels.h"
 
 typedef unsigned long long u64;
@@ -178,10 +180,10 @@ __global__ __launch_bounds__(256) void k_find(FindArgs A) {
   fm_tables_load(tb, A.fwd, A.rev);
 
   u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
-  u32 read = (u32)(gid >> 2), o = (u32)gid & 3u;
+  u32 read = A.read_begin + (u32)(gid >> 2), o = (u32)gid & 3u;
   u64 nocc = 0;
   u32 nb = 0, flagbits = 0;
-  bool live = read < A.n_reads && ((o & 1u) == 0 || A.rc);  // chains 1 and 3 are the opposite-strand finds
+  bool live = read < A.read_end && ((o & 1u) == 0 || A.rc);  // chains 1 and 3 are the opposite-strand finds
   u64 b0 = 0, L = 0;
   if (live) {
     b0 = A.offs[read];
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256) void k_find(FindArgs A) {
       }
     }
   }
-  if (read < A.n_reads) {
+  if (read < A.read_end) {
     u32 word = (nb & SIGAX_CC_COUNT_MASK) | (flagbits & (SIGAX_CC_SUBSTRING | SIGAX_CC_CONTAIN));
     A.chain_cnt[(u64)read * 4 + o] = word;
   }
@@ -309,7 +311,7 @@ struct Fx {
   __device__ FmRef ext_index(u32 src) const { return fm_pick((src / A.cap) < 2, R, F); }
 
   __device__ bool need(u32 upto) {
-    if (upto > A.pool_cap) { overflow = true; return false; }
+    if (upto + nout > A.pool_cap) { overflow = true; return false; }
     return true;
   }
 
@@ -319,16 +321,28 @@ struct Fx {
     e.src = src; e.len = b.length; e.pad0 = e.pad1 = 0;
   }
 
-  // outblocks->push_back (order tag = position in the read's hit)
+  // outblocks->push_back: emitted entries wait at the tail of the pool (growing downwards) until the read is done
   __device__ void emit(const Ent& e) {
-    u64 slot = atomicAdd(&A.dstat[DS_FIN_TOP], 1ull);
-    if (slot < A.fin_cap) {
+    if (top + nout + 1 > A.pool_cap) { overflow = true; return; }
+    pool[A.pool_cap - 1 - nout] = e;
+    ++nout;
+  }
+  // one allocation per read out of this lane's chunk of the unordered arena
+  __device__ void flush(u64& fin_cur, u64& fin_end) {
+    if (fin_cur + nout > fin_end) {
+      u64 grab = nout > 64 ? nout : 64;
+      fin_cur = atomicAdd(&A.dstat[DS_FIN_TOP], grab);
+      fin_end = fin_cur + grab;
+    }
+    A.item_base[2ull * read] = fin_cur;
+    for (u32 i = 0; i < nout; ++i) {
+      u64 slot = fin_cur + i;
+      if (slot >= A.fin_cap) break;
+      const Ent& e = pool[A.pool_cap - 1 - i];
       const sigax_block& b = slots[e.src];
       store_block(A.fin + slot, e.c0lo, e.c0hi, e.c1lo, e.c1hi, b.raw0_lo, b.raw0_hi, b.raw1_lo, b.raw1_hi, b.length, b.af);
-      A.fin_read[slot] = read;
-      A.fin_seq[slot] = nout;
     }
-    ++nout;
+    fin_cur += nout;
   }
 
   // IntervalPair::updateR(c, index) on the capped pair (overlap_builder.cpp:101-106,123-133)
@@ -665,15 +679,28 @@ __global__ __launch_bounds__(256) void k_filter_extract(FxArgs A) {
   u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
   u64 nlanes = (u64)gridDim.x * 256;
   Fx<WIDE> fx(A, tb, A.pool + gid * A.pool_cap);
-  u64 nocc = 0, nerr = 0, nover = 0, nsub = 0;
+  u64 nocc = 0, nerr = 0, nover = 0, nsub = 0, nocc_back = 0, nerr_back = 0, nsub_back = 0;
+  u64 fin_cur = 0, fin_end = 0;
   const u64 n_work = A.n_work_ptr ? *A.n_work_ptr : A.n_work;
   for (u64 w = gid; w < n_work; w += nlanes) {
     u32 r = A.work ? A.work[w] : (u32)w;
+    // a side of this read that completed in the fast kernel already added its share: take it back
+    for (int sd = 0; sd < 2; ++sd) {
+      u32 w0 = A.occ_side[2ull * r + sd];
+      nocc_back += w0 & 0x3FFFFFFFu;
+      if (w0 & 0x80000000u) ++nerr_back;
+      if (w0 & 0x40000000u) ++nsub_back;
+      A.occ_side[2ull * r + sd] = 0;
+    }
     fx.nocc = 0;
     fx.run(r);
     nocc += fx.nocc;
-    if (fx.overflow) { ++nover; A.fin_cnt[r] = 0; }
-    else A.fin_cnt[r] = fx.nout;
+    if (fx.overflow) fx.nout = 0;
+    fx.flush(fin_cur, fin_end);
+    A.fin_cnt[2ull * r] = fx.nout;
+    A.fin_cnt[2ull * r + 1] = 0;
+    A.item_base[2ull * r + 1] = 0;
+    if (fx.overflow) ++nover;
     if (fx.xerror) ++nerr;
     u32 sub = 0;
     for (int o = 0; o < 4; ++o) sub |= A.chain_cnt[(u64)r * 4 + o] & SIGAX_CC_SUBSTRING;
@@ -681,34 +708,52 @@ __global__ __launch_bounds__(256) void k_filter_extract(FxArgs A) {
     if (sub) ++nsub;
   }
   nocc = wave_sum(nocc); nerr = wave_sum(nerr); nover = wave_sum(nover); nsub = wave_sum(nsub);
+  nocc_back = wave_sum(nocc_back); nerr_back = wave_sum(nerr_back); nsub_back = wave_sum(nsub_back);
   if ((threadIdx.x & 63) == 0) {
-    if (nocc) atomicAdd(&A.dstat[DS_OCC_EXTRACT], nocc);
-    if (nerr) atomicAdd(&A.dstat[DS_EXTRACT_ERRORS], nerr);
+    if (nocc != nocc_back) atomicAdd(&A.dstat[DS_OCC_EXTRACT], nocc - nocc_back);  // wraps correctly when negative
+    if (nerr != nerr_back) atomicAdd(&A.dstat[DS_EXTRACT_ERRORS], nerr - nerr_back);
     if (nover) atomicAdd(&A.dstat[DS_POOL_OVERFLOW], nover);
-    if (nsub) atomicAdd(&A.dstat[DS_SUBSTRING], nsub);
+    if (nsub != nsub_back) atomicAdd(&A.dstat[DS_SUBSTRING], nsub - nsub_back);
   }
 }
 
 // -------------------------------------------------------------------------------------------------------
-// k_filter_extract_fast: one wave per read, one lane per overlap block.
+// k_filter_extract_fast: one wave per (read, side), one lane per overlap block.
 //
-// Same algorithm as Fx above, parallelised over the blocks of a list.  A group of the extractor
-// (overlap_builder.cpp:720-722) is a 64-bit alive mask over fixed lane slots: block order inside a group is lane
-// order, so "top-level blocks" are the alive lanes whose length equals the first alive lane's, erasing an invalid
-// block clears its bit, and a branch copies the lanes' entries to a fresh 64-entry slot of the wave's pool.  The
-// group being worked on lives in registers; with a single group (the common case: every overlapping read agrees on
-// the next base) a whole extraction runs without touching the pool.  Symbol tests ("exts[k] > 0") are wave ballots.
-// Reads that need SubMaximalBlockFilter::resolve, have more than 64 blocks on a side, or outgrow the wave's pool
-// are queued for the general kernel; nothing global is written for a read before it has completed here.
+// Side 0 = the suffix lists (finds 0 and 3), side 1 = the prefix lists (finds 1 and 2): the two halves of
+// OverlapBuilder::overlap (overlap_builder.cpp:1135-1173) are independent until the final push order, which
+// the ordered scatter restores (containments, suffix side, prefix side).  Same algorithm as Fx above,
+// parallelised over the blocks of a list.  A group of the extractor (overlap_builder.cpp:720-722) is a 64-bit
+// alive mask over fixed lane slots: block order inside a group is lane order, so "top-level blocks" are the
+// alive lanes whose length equals the first alive lane's, erasing an invalid block clears its bit, and a
+// branch copies the lanes' entries to a fresh 64-entry slot of the wave's pool.  The group being worked on
+// lives in registers; with a single group (the common case: every overlapping read agrees on the next base) a
+// whole extraction never touches the pool.  Symbol tests ("exts[k] > 0") are wave ballots; the sorted order is
+// produced by a rank + LDS permutation; emitted blocks wait in LDS until the side is complete.
+// Positions are u32 when the index has < 2^32 symbols (P), halving register use.
+// A side that needs SubMaximalBlockFilter::resolve, has more than 64 blocks, or outgrows the wave's pool queues
+// its read for the general kernel; nothing that the scatter will use is written before a side has completed.
 // -------------------------------------------------------------------------------------------------------
 #define FX_NSLOT 24
-#define FX_OUTCAP 192
-#define FX_WPOOL (FX_NSLOT * 64 + FX_OUTCAP)
+#define FX_OUTCAP 64
+#define FX_WPOOL (FX_NSLOT * 64)
 
-struct WaveSh {
+#define FX_FIN_CHUNK 512
+#define OCC_SIDE_ERR 0x80000000u
+#define OCC_SIDE_SUB 0x40000000u
+#define OCC_SIDE_MASK 0x3FFFFFFFu
+
+template <bool WIDE> struct PosOf { typedef u32 type; };
+template <> struct PosOf<true> { typedef u64 type; };
+
+template <bool WIDE>
+struct SideSh {
+  typedef typename PosOf<WIDE>::type P;
+  P e0[64], e1[64], e2[64], e3[64];  // permutation buffer / adjacency scratch
+  u32 esrc[64], elen[64];
+  P o0[FX_OUTCAP], o1[FX_OUTCAP], o2[FX_OUTCAP], o3[FX_OUTCAP];  // emitted blocks of this side
+  u32 osrc[FX_OUTCAP];
   u64 alive[FX_NSLOT];
-  u64 ivlo[64], ivhi[64];
-  unsigned short perm[64];
   unsigned char D[FX_NSLOT], I[FX_NSLOT];
 };
 
@@ -716,31 +761,70 @@ __device__ __forceinline__ u64 readlane64(u64 v, u32 l) {
   u32 lo = __builtin_amdgcn_readlane((u32)v, l), hi = __builtin_amdgcn_readlane((u32)(v >> 32), l);
   return ((u64)hi << 32) | lo;
 }
+// Tell the compiler a value is the same in every lane (it cannot see that for values derived from the wave index or
+// loaded through vector memory / LDS): keeps loop counters, masks and branch conditions in SGPRs.
+__device__ __forceinline__ u32 uni(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ u64 uni64(u64 v) {
+  return ((u64)__builtin_amdgcn_readfirstlane((u32)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)v);
+}
+
+__device__ __forceinline__ u32 readlaneP(u32 v, u32 l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ u64 readlaneP(u64 v, u32 l) { return readlane64(v, l); }
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ u64 sel5(const u64 v[5], u32 k) {
-  return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : k == 3 ? v[3] : v[4];
+__device__ __forceinline__ u64 widen(u32 v) { return v == 0xFFFFFFFFu ? ~0ull : (u64)v; }  // keep "-1" a -1
+__device__ __forceinline__ u64 widen(u64 v) { return v; }
+
+// rank vector at position p in the position type of the index ($ first)
+template <bool WIDE>
+__device__ __forceinline__ void fm_rank5p(const FmRef& s, typename PosOf<WIDE>::type p, typename PosOf<WIDE>::type v[5]) {
+  typedef typename PosOf<WIDE>::type P;
+  u64 pc = (u64)p > s.n ? s.n : (u64)p;
+  u64 gi = pc >> 7;
+  int r = (int)(pc & 127u);
+  const uint4* q = s.g + gi * 4;
+  uint4 k0 = q[0], k1 = q[1], k2 = q[2], k3 = q[3];
+  u32 a = k0.x, c = k1.x, g = k2.x, t = k3.x;
+  chunk_count(k0, r, a, c, g, t);
+  chunk_count(k1, r - 32, a, c, g, t);
+  chunk_count(k2, r - 64, a, c, g, t);
+  chunk_count(k3, r - 96, a, c, g, t);
+  P A = a, C = c, G = g, T = t;
+  if (WIDE) {
+    const u64* sb = s.super + (pc >> SIGAX_SUPER_SHIFT) * 4;
+    A += (P)sb[0]; C += (P)sb[1]; G += (P)sb[2]; T += (P)sb[3];
+  }
+  v[1] = A; v[2] = C; v[3] = G; v[4] = T;
+  v[0] = (P)pc - (A + C + G + T);
 }
 
 template <bool WIDE>
-struct FastFx {
+struct SideFx {
+  typedef typename PosOf<WIDE>::type P;
+  struct E {  // a block's capped pair in registers
+    P c0lo, c0hi, c1lo, c1hi;
+    u32 src, len;
+  };
   const FxArgs& A;
   const FmTables& tb;
-  WaveSh& sh;
+  SideSh<WIDE>& sh;
   FmRef F, R;
-  Ent* wpool;  // FX_NSLOT group slots of 64 entries, then FX_OUTCAP emitted entries
+  Ent* wpool;  // FX_NSLOT group slots of 64 entries (branch copies only)
   u32 lane;
-  u64 lt;      // lanes below this one
+  u64 lt;
   const sigax_block* slots;
   u32 nout;
   u64 nocc;
   bool xerror;
+  u64 fin_cur, fin_end;  // this wave's chunk of the unordered final-block arena
 
-  __device__ FastFx(const FxArgs& a, const FmTables& t, WaveSh& s, Ent* wp)
+  __device__ SideFx(const FxArgs& a, const FmTables& t, SideSh<WIDE>& s, Ent* wp)
       : A(a), tb(t), sh(s), F(fm_ref(a.fwd, 0)), R(fm_ref(a.rev, 1)), wpool(wp), lane(threadIdx.x & 63u),
-        lt((1ull << (threadIdx.x & 63u)) - 1ull), slots(nullptr), nout(0), nocc(0), xerror(false) {}
+        lt((1ull << (threadIdx.x & 63u)) - 1ull), slots(nullptr), nout(0), nocc(0), xerror(false), fin_cur(0), fin_end(0) {}
+
+  static __device__ bool valid(P lo, P hi) { return hi != (P)~(P)0 && hi >= lo; }  // fmindex.h:87-89
 
   __device__ u32 af_of(u32 src) const {
     u32 ch = src / A.cap;
@@ -748,53 +832,62 @@ struct FastFx {
   }
   __device__ FmRef ext_index(u32 src) const { return fm_pick((src / A.cap) < 2, R, F); }
 
-  __device__ void load_ent(Ent& e, u32 src) const {
+  __device__ void load_block(E& e, u32 src) const {
     const ulonglong2* b = reinterpret_cast<const ulonglong2*>(slots + src);
     ulonglong2 c0 = b[0], c1 = b[1], t = b[4];
-    e.c0lo = c0.x; e.c0hi = c0.y; e.c1lo = c1.x; e.c1hi = c1.y;
-    e.src = src; e.len = (u32)t.x; e.pad0 = e.pad1 = 0;
+    e.c0lo = (P)c0.x; e.c0hi = (P)c0.y; e.c1lo = (P)c1.x; e.c1hi = (P)c1.y;
+    e.src = src; e.len = (u32)t.x;
   }
-  __device__ void put(Ent* dst, const Ent& e) const {
+  __device__ void pool_put(Ent* dst, const E& e) const {
     ulonglong2* d = reinterpret_cast<ulonglong2*>(dst);
-    d[0] = make_ulonglong2(e.c0lo, e.c0hi);
-    d[1] = make_ulonglong2(e.c1lo, e.c1hi);
+    d[0] = make_ulonglong2(widen(e.c0lo), widen(e.c0hi));
+    d[1] = make_ulonglong2(widen(e.c1lo), widen(e.c1hi));
     d[2] = make_ulonglong2((u64)e.src | ((u64)e.len << 32), 0ull);
   }
-  __device__ void get(Ent& e, const Ent* src) const {
+  __device__ void pool_get(E& e, const Ent* src) const {
     const ulonglong2* d = reinterpret_cast<const ulonglong2*>(src);
     ulonglong2 a = d[0], b = d[1], c = d[2];
-    e.c0lo = a.x; e.c0hi = a.y; e.c1lo = b.x; e.c1hi = b.y;
-    e.src = (u32)c.x; e.len = (u32)(c.x >> 32); e.pad0 = e.pad1 = 0;
+    e.c0lo = (P)a.x; e.c0hi = (P)a.y; e.c1lo = (P)b.x; e.c1hi = (P)b.y;
+    e.src = (u32)c.x; e.len = (u32)(c.x >> 32);
+  }
+  __device__ void out_put(u32 i, const E& e) {
+    sh.o0[i] = e.c0lo; sh.o1[i] = e.c0hi; sh.o2[i] = e.c1lo; sh.o3[i] = e.c1hi; sh.osrc[i] = e.src;
   }
 
-  // IntervalPair::updateR(b, index) from the two rank vectors already in registers
-  __device__ void apply_updateR(Ent& e, u32 b, u32 which, const u64 l[5], const u64 u[5]) const {
-    u64 d0 = u[0] - l[0], d1 = u[1] - l[1], d2 = u[2] - l[2], d3 = u[3] - l[3];
-    u64 acc = b == 0 ? 0 : b == 1 ? d0 : b == 2 ? d0 + d1 : b == 3 ? d0 + d1 + d2 : d0 + d1 + d2 + d3;
-    u64 lb = sel5(l, b), ub = sel5(u, b);
-    u64 pb = tb.C[which][b];
+  static __device__ P sel5(const P v[5], u32 k) { return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : k == 3 ? v[3] : v[4]; }
+
+  // IntervalPair::updateR(b, index) (overlap_builder.cpp:101-106,123-133) from the two rank vectors in registers
+  __device__ void apply_updateR(E& e, u32 b, u32 which, const P l[5], const P u[5]) const {
+    P d0 = u[0] - l[0], d1 = u[1] - l[1], d2 = u[2] - l[2], d3 = u[3] - l[3];
+    P acc = b == 0 ? (P)0 : b == 1 ? d0 : b == 2 ? d0 + d1 : b == 3 ? d0 + d1 + d2 : d0 + d1 + d2 + d3;
+    P lb = sel5(l, b), ub = sel5(u, b);
+    P pb = (P)tb.C[which][b];
     e.c0lo += acc;
     e.c0hi = e.c0lo + (ub - lb) - 1;
     e.c1lo = pb + lb;
     e.c1hi = pb + ub - 1;
   }
 
-  // IrreducibleBlockListExtractor::extract over the n entries held one per lane (already sorted by length desc).
-  // Returns false when the read has to go to the general kernel.
-  __device__ bool extract(Ent e, u32 n) {
+  // IrreducibleBlockListExtractor::extract (overlap_builder.cpp:711-809) over the n entries held one per lane,
+  // already sorted by length descending.  Returns false when the read has to go to the general kernel.
+  // The group table lives in VGPR lanes: lane s holds slot s's alive mask, lane i holds the i-th group of the
+  // list (gD) / of this pass's incomings (gI); reads are v_readlane with a scalar index, so every value that steers
+  // control flow is in SGPRs.
+  __device__ bool extract(E e, u32 n) {
     if (n == 0) return true;
     u32 cur = 0, ng = 1, nslot = 1;
-    sh.alive[0] = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-    sh.D[0] = 0;
+    u64 gAlive = lane == 0 ? (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) : 0ull;
+    u32 gD = 0, gI = 0;
     u32 guard = 0;
     while (ng > 0) {
       u32 ni = 0, p = 0;
       while (p != ng) {
-        u32 slot = sh.D[p];
-        u64 alive = sh.alive[slot];
+        const u32 slot = __builtin_amdgcn_readlane(gD, p);
+        const u64 alive = readlane64(gAlive, slot);
         if (slot != cur) {
-          if ((sh.alive[cur] >> lane) & 1ull) put(wpool + cur * 64 + lane, e);
-          if ((alive >> lane) & 1ull) get(e, wpool + slot * 64 + lane);
+          const u64 was = readlane64(gAlive, cur);
+          if ((was >> lane) & 1ull) pool_put(wpool + cur * 64 + lane, e);
+          if ((alive >> lane) & 1ull) pool_get(e, wpool + slot * 64 + lane);
           cur = slot;
         }
         bool eraseGroup = true;
@@ -805,17 +898,17 @@ struct FastFx {
           const bool isTop = mine && e.len == topLen;
           const FmRef ix = ext_index(e.src);
           const bool qcomp = (af_of(e.src) & 4u) != 0;
-          u64 l[5] = {0, 0, 0, 0, 0}, u[5] = {0, 0, 0, 0, 0};
+          P l[5] = {0, 0, 0, 0, 0}, u[5] = {0, 0, 0, 0, 0};
           if (mine) {
-            fm_rank5<WIDE>(ix, e.c1lo, l);
-            fm_rank5<WIDE>(ix, e.c1hi + 1, u);
+            fm_rank5p<WIDE>(ix, e.c1lo, l);
+            fm_rank5p<WIDE>(ix, (P)(e.c1hi + 1), u);
           }
-          // OverlapBlock::ext, complemented for QUERYCOMP blocks: x[k] > 0 in the query's frame
-          const bool x0 = mine && (u[0] - l[0]) > 0;
-          const bool xa = mine && (qcomp ? (u[4] - l[4]) : (u[1] - l[1])) > 0;
-          const bool xc = mine && (qcomp ? (u[3] - l[3]) : (u[2] - l[2])) > 0;
-          const bool xg = mine && (qcomp ? (u[2] - l[2]) : (u[3] - l[3])) > 0;
-          const bool xt = mine && (qcomp ? (u[1] - l[1]) : (u[4] - l[4])) > 0;
+          // OverlapBlock::ext (overlap_builder.cpp:181-187), complemented for QUERYCOMP blocks
+          const bool x0 = mine && (u[0] != l[0]);
+          const bool xa = mine && (qcomp ? (u[4] != l[4]) : (u[1] != l[1]));
+          const bool xc = mine && (qcomp ? (u[3] != l[3]) : (u[2] != l[2]));
+          const bool xg = mine && (qcomp ? (u[2] != l[2]) : (u[3] != l[3]));
+          const bool xt = mine && (qcomp ? (u[1] != l[1]) : (u[4] != l[4]));
           const u64 topMask = __ballot(isTop);
           if (__ballot(isTop && x0)) {
             // the top-level block has ended: emit the top-level blocks in list order (:747-766)
@@ -826,9 +919,9 @@ struct FastFx {
             u32 ne = (u32)__popcll(emitMask);
             if (nout + ne > FX_OUTCAP) return false;
             if ((emitMask >> lane) & 1ull) {
-              Ent br = e;
+              E br = e;
               apply_updateR(br, 0, ix.which, l, u);
-              put(wpool + FX_NSLOT * 64 + nout + (u32)__popcll(emitMask & lt), br);
+              out_put(nout + (u32)__popcll(emitMask & lt), br);
             }
             nout += ne;
             if (bad) {
@@ -843,157 +936,187 @@ struct FastFx {
               u32 c = any0 ? 0u : any1 ? 1u : any2 ? 2u : any3 ? 3u : 4u;
               u32 b = qcomp ? comp_rank(c) : c;
               if (mine) apply_updateR(e, b, ix.which, l, u);
-              bool ok = mine && iv_valid(e.c0lo, e.c0hi) && iv_valid(e.c1lo, e.c1hi);
-              sh.alive[slot] = __ballot(ok);
+              bool ok = mine && valid(e.c0lo, e.c0hi) && valid(e.c1lo, e.c1hi);
+              u64 m = __ballot(ok);
+              if (lane == slot) gAlive = m;
               eraseGroup = false;
             } else {
-              const u64 anyk[5] = {any0, any1, any2, any3, any4};
               for (u32 c = 0; c < 5; ++c) {
-                u64 ak = c == 0 ? anyk[0] : c == 1 ? anyk[1] : c == 2 ? anyk[2] : c == 3 ? anyk[3] : anyk[4];
+                u64 ak = c == 0 ? any0 : c == 1 ? any1 : c == 2 ? any2 : c == 3 ? any3 : any4;
                 if (!ak) continue;
                 if (nslot >= FX_NSLOT || ni >= FX_NSLOT) return false;
                 u32 ns = nslot++;
-                Ent br = e;
+                E br = e;
                 u32 b = qcomp ? comp_rank(c) : c;
                 if (mine) apply_updateR(br, b, ix.which, l, u);
-                bool ok = mine && iv_valid(br.c0lo, br.c0hi) && iv_valid(br.c1lo, br.c1hi);
-                if (ok) put(wpool + ns * 64 + lane, br);
-                sh.alive[ns] = __ballot(ok);
-                sh.I[ni++] = (unsigned char)ns;
+                bool ok = mine && valid(br.c0lo, br.c0hi) && valid(br.c1lo, br.c1hi);
+                if (ok) pool_put(wpool + ns * 64 + lane, br);
+                u64 m = __ballot(ok);
+                if (lane == ns) gAlive = m;
+                if (lane == ni) gI = ns;
+                ++ni;
               }
             }
           }
         }
         // body `i = erase(i)` / `++i`, then the loop header's `++i` on the ring [g0..g(k-1), end]
         if (eraseGroup) {
-          for (u32 i = p; i + 1 < ng; ++i) sh.D[i] = sh.D[i + 1];
+          u32 nxt = __shfl_down(gD, 1, 64);
+          if (lane >= p) gD = nxt;
           --ng;
         } else {
-          p = (p + 1) % (ng + 1);
+          p = p + 1 > ng ? 0 : p + 1;
         }
-        p = (p + 1) % (ng + 1);
+        p = p + 1 > ng ? 0 : p + 1;
         if (++guard > (1u << 20)) return false;
       }
       if (ng + ni > FX_NSLOT) return false;
-      for (u32 i = 0; i < ni; ++i) sh.D[ng++] = sh.I[i];
-    }
-    return true;
-  }
-
-  // One side of OverlapBuilder::overlap: side 0 = suffix lists (chains 0 and 3), side 1 = prefix lists (1 and 2).
-  __device__ bool side(u32 sd, const u32 cc[4], u64 L) {
-    const u32 chA = sd == 0 ? 0u : 1u, chB = sd == 0 ? 3u : 2u;
-    const u32 nA = cc[chA] & SIGAX_CC_COUNT_MASK, nB = cc[chB] & SIGAX_CC_COUNT_MASK;
-    const u32 c0 = (cc[0] & SIGAX_CC_CONTAIN) ? 1u : 0u, c1 = (cc[1] & SIGAX_CC_CONTAIN) ? 1u : 0u;
-    const u32 c2 = (cc[2] & SIGAX_CC_CONTAIN) ? 1u : 0u, c3 = (cc[3] & SIGAX_CC_CONTAIN) ? 1u : 0u;
-    // list X = chain A's blocks + containfwd {0,1}; list Y = chain B's blocks + containrev {2,3} (:1137-1140)
-    const u32 nX = nA + c0 + c1, nY = nB + c2 + c3, T = nX + nY;
-    if (T > 64) return false;
-    if (T == 0) return true;
-    const bool active = lane < T;
-    const u32 list = lane >= nX ? 1u : 0u;
-    const u32 k = list ? lane - nX : lane;
-    u32 src = 0;
-    if (active) {
-      if (!list) src = k < nA ? chA * A.cap + k : ((k == nA && c0) ? 0u : 1u) * A.cap + (A.cap - 1);
-      else src = k < nB ? chB * A.cap + k : ((k == nB && c2) ? 2u : 3u) * A.cap + (A.cap - 1);
-    }
-    Ent e;
-    e.c0lo = e.c0hi = e.c1lo = e.c1hi = 0; e.src = 0; e.len = 0; e.pad0 = e.pad1 = 0;
-    if (active) load_ent(e, src);
-    // stable rank by capped[0].lower inside the own list (SubMaximalBlockFilter::filter's sort, :930-931)
-    u32 rank = 0;
-    for (u32 j = 0; j < T; ++j) {
-      u64 loj = readlane64(e.c0lo, j);
-      u32 lj = j >= nX ? 1u : 0u, kj = lj ? j - nX : j;
-      if (active && lj == list && (loj < e.c0lo || (loj == e.c0lo && kj < k))) ++rank;
-    }
-    // adjacent blocks in that order must not intersect (:936-937), else resolve() is needed: general kernel
-    const u32 lbase = list ? nX : 0u, nlist = list ? nY : nX;
-    if (active) {
-      sh.ivlo[lbase + rank] = e.c0lo;
-      sh.ivhi[lbase + rank] = e.c0hi;
-    }
-    wave_lds_sync();
-    bool inter = false;
-    if (active && rank + 1 < nlist) {
-      u64 nlo = sh.ivlo[lbase + rank + 1], nhi = sh.ivhi[lbase + rank + 1];
-      inter = intersecting(e.c0lo, e.c0hi, nlo, nhi);
-    }
-    wave_lds_sync();
-    if (__ballot(inter)) return false;
-    const bool member = active && e.len != L;  // ContainmentBlockRemover (:1094-1111)
-    const u32 nm = (u32)__popcll(__ballot(member));
-    u32 pos = 0;
-    if (A.irreducible) {
-      // suffixfwd += suffixrev; stable sort by length descending (:715-716,1169): ties keep list X first
-      for (u32 j = 0; j < T; ++j) {
-        u32 lenj = __builtin_amdgcn_readlane(e.len, j);
-        u32 lj = j >= nX ? 1u : 0u;
-        bool mj = lenj != L;
-        if (mj && (lenj > e.len || (lenj == e.len && lj < list))) ++pos;
+      for (u32 i = 0; i < ni; ++i) {
+        u32 v = __builtin_amdgcn_readlane(gI, i);
+        if (lane == ng) gD = v;
+        ++ng;
       }
-      if (member) sh.perm[pos] = (unsigned short)src;
-      wave_lds_sync();
-      Ent g;
-      g.c0lo = g.c0hi = g.c1lo = g.c1hi = 0; g.src = 0; g.len = 0; g.pad0 = g.pad1 = 0;
-      if (lane < nm) load_ent(g, sh.perm[lane]);
-      wave_lds_sync();
-      return extract(g, nm);
     }
-    // exhaustive: the filtered lists go out as they are, X then Y, each in capped[0].lower order (:1175-1178)
-    for (u32 j = 0; j < T; ++j) {
-      u32 lenj = __builtin_amdgcn_readlane(e.len, j);
-      u32 rj = __builtin_amdgcn_readlane(rank, j);
-      u32 lj = j >= nX ? 1u : 0u;
-      if (lenj != L && (lj < list || (lj == list && rj < rank))) ++pos;
-    }
-    if (nout + nm > FX_OUTCAP) return false;
-    if (member) put(wpool + FX_NSLOT * 64 + nout + pos, e);
-    nout += nm;
     return true;
   }
 
   // returns false when the read must be redone by the general kernel
-  __device__ bool run(u32 r) {
+  __device__ bool run(u32 r, u32 sd) {
     nout = 0;
     xerror = false;
     slots = A.arena + (u64)r * 4 * A.cap;
-    u64 L = A.offs[r + 1] - A.offs[r];
+    const u32 L = uni((u32)(A.offs[r + 1] - A.offs[r]));
     u32 cc[4];
-    for (int o = 0; o < 4; ++o) cc[o] = A.chain_cnt[(u64)r * 4 + o];
-    // containfwd, containrev first (:1161-1162)
     {
+      uint4 c4 = reinterpret_cast<const uint4*>(A.chain_cnt)[r];
+      cc[0] = uni(c4.x); cc[1] = uni(c4.y); cc[2] = uni(c4.z); cc[3] = uni(c4.w);
+    }
+    if (sd == 0) {  // containfwd, containrev first (:1161-1162)
       bool has = lane < 4 && (cc[lane & 3] & SIGAX_CC_CONTAIN);
       u64 m = __ballot(has);
       if (has) {
-        Ent e;
-        load_ent(e, lane * A.cap + (A.cap - 1));
-        put(wpool + FX_NSLOT * 64 + (u32)__popcll(m & lt), e);
+        E e;
+        load_block(e, lane * A.cap + (A.cap - 1));
+        out_put((u32)__popcll(m & lt), e);
       }
       nout = (u32)__popcll(m);
     }
-    if (A.irreducible) {
-      if (!side(0, cc, L)) return false;  // extract(&suffixfwd, blocks) first, then the prefix lists (:1169-1173)
-      if (!side(1, cc, L)) return false;
-    } else {
-      if (!side(0, cc, L)) return false;
-      if (!side(1, cc, L)) return false;
-    }
-    // flush: one allocation per read, blocks tagged (read, position in hit)
-    u64 base = 0;
-    if (lane == 0) base = atomicAdd(&A.dstat[DS_FIN_TOP], (u64)nout);
-    base = readlane64(base, 0);
-    for (u32 i = lane; i < nout; i += 64) {
-      u64 slot = base + i;
-      if (slot < A.fin_cap) {
-        Ent e;
-        get(e, wpool + FX_NSLOT * 64 + i);
-        const sigax_block& b = slots[e.src];
-        store_block(A.fin + slot, e.c0lo, e.c0hi, e.c1lo, e.c1hi, b.raw0_lo, b.raw0_hi, b.raw1_lo, b.raw1_hi, b.length, b.af);
-        A.fin_read[slot] = r;
-        A.fin_seq[slot] = i;
+    const u32 chA = sd == 0 ? 0u : 1u, chB = sd == 0 ? 3u : 2u;
+    const u32 nA = cc[chA] & SIGAX_CC_COUNT_MASK, nB = cc[chB] & SIGAX_CC_COUNT_MASK;
+    const u32 c0 = (cc[0] & SIGAX_CC_CONTAIN) ? 1u : 0u, c1 = (cc[1] & SIGAX_CC_CONTAIN) ? 1u : 0u;
+    const u32 c2 = (cc[2] & SIGAX_CC_CONTAIN) ? 1u : 0u, c3 = (cc[3] & SIGAX_CC_CONTAIN) ? 1u : 0u;
+    // list X = find A's blocks + containfwd {0,1}; list Y = find B's blocks + containrev {2,3} (:1137-1140)
+    const u32 nX = nA + c0 + c1, nY = nB + c2 + c3, T = nX + nY;
+    if (T > 64) return false;
+    if (T > 0) {
+      const bool active = lane < T;
+      const u32 list = lane >= nX ? 1u : 0u;
+      const u32 k = list ? lane - nX : lane;
+      u32 src = 0;
+      if (active) {
+        if (!list) src = k < nA ? chA * A.cap + k : ((k == nA && c0) ? 0u : 1u) * A.cap + (A.cap - 1);
+        else src = k < nB ? chB * A.cap + k : ((k == nB && c2) ? 2u : 3u) * A.cap + (A.cap - 1);
       }
+      E e;
+      e.c0lo = e.c0hi = e.c1lo = e.c1hi = 0; e.src = 0; e.len = 0;
+      if (active) load_block(e, src);
+      const bool member = active && e.len != L;  // ContainmentBlockRemover (:1094-1111)
+      const u32 nm = (u32)__popcll(__ballot(member));
+      if (A.irreducible) {
+        // SubMaximalBlockFilter::filter (:930-953) sorts by capped[0].lower and resolves adjacent intersecting
+        // blocks.  With the blocks sorted by lower bound, SOME pair intersects iff some ADJACENT pair does (if i
+        // precedes j and lower_j <= upper_i, the successor k of i has lower_k <= lower_j <= upper_i), so an
+        // any-pair test inside each list decides exactly whether resolve() is needed: general kernel then.
+        bool inter = false;
+        for (u32 j = 0; j < T; ++j) {
+          P loj = readlaneP(e.c0lo, j), hij = readlaneP(e.c0hi, j);
+          u32 lj = j >= nX ? 1u : 0u;
+          inter |= (lj == list) & (j != lane) & !(e.c0lo > hij || loj > e.c0hi);  // coord.h:37-40
+        }
+        if (__ballot(active && inter)) return false;
+        // X += Y; stable sort by length descending (:715-716,1169), ties keep list X first.  Both finds pushed their
+        // blocks in increasing length, so the position is a merge rank: blocks after me in my own list, plus the
+        // other list's blocks that are longer (or, seen from Y, as long).
+        const u32 nAm = nA, nBm = nB;  // list members without the containment copies
+        u32 other = 0;
+        {
+          // binary search in the other list's lengths (ascending in lane order)
+          const u32 obase = list ? 0u : nX, on = list ? nAm : nBm;
+          u32 lo = 0, hi = on;  // first index whose length is > mine (list X) / >= mine (list Y)
+          for (u32 step = 0; step < 7; ++step) {
+            u32 mid = (lo + hi) >> 1;
+            u32 lenm = __shfl(e.len, (int)(obase + (mid < on ? mid : 0)), 64);
+            bool right = list ? (lenm < e.len) : (lenm <= e.len);
+            if (lo < hi) {
+              if (right) lo = mid + 1; else hi = mid;
+            }
+          }
+          other = on - lo;
+        }
+        const u32 mine_after = (list ? nBm : nAm) - 1u - k;
+        const u32 pos = mine_after + other;
+        if (member) {
+          sh.e0[pos] = e.c0lo; sh.e1[pos] = e.c0hi; sh.e2[pos] = e.c1lo; sh.e3[pos] = e.c1hi;
+          sh.esrc[pos] = e.src; sh.elen[pos] = e.len;
+        }
+        wave_lds_sync();
+        E g;
+        g.c0lo = g.c0hi = g.c1lo = g.c1hi = 0; g.src = 0; g.len = 0;
+        if (lane < nm) {
+          g.c0lo = sh.e0[lane]; g.c0hi = sh.e1[lane]; g.c1lo = sh.e2[lane]; g.c1hi = sh.e3[lane];
+          g.src = sh.esrc[lane]; g.len = sh.elen[lane];
+        }
+        wave_lds_sync();
+        if (!extract(g, nm)) return false;
+      } else {
+        // exhaustive: the filtered lists go out as they are, X then Y, each in capped[0].lower order (:1175-1178):
+        // stable rank by capped[0].lower inside the own list (SubMaximalBlockFilter::filter's sort, :930-931)
+        u32 rank = 0;
+        bool inter = false;
+        for (u32 j = 0; j < T; ++j) {
+          P loj = readlaneP(e.c0lo, j), hij = readlaneP(e.c0hi, j);
+          u32 lj = j >= nX ? 1u : 0u, kj = lj ? j - nX : j;
+          bool same = active && lj == list;
+          if (same && (loj < e.c0lo || (loj == e.c0lo && kj < k))) ++rank;
+          inter |= same & (j != lane) & !(e.c0lo > hij || loj > e.c0hi);
+        }
+        if (__ballot(active && inter)) return false;
+        u32 pos = 0;
+        for (u32 j = 0; j < T; ++j) {
+          u32 lenj = __builtin_amdgcn_readlane(e.len, j);
+          u32 rj = __builtin_amdgcn_readlane(rank, j);
+          u32 lj = j >= nX ? 1u : 0u;
+          if (lenj != L && (lj < list || (lj == list && rj < rank))) ++pos;
+        }
+        if (nout + nm > FX_OUTCAP) return false;
+        if (member) out_put(nout + pos, e);
+        nout += nm;
+      }
+    }
+    // flush this side into the wave's chunk of the unordered arena (one atomic per FX_FIN_CHUNK blocks)
+    wave_lds_sync();
+    if (fin_cur + nout > fin_end) {
+      u64 b0 = 0;
+      if (lane == 0) b0 = atomicAdd(&A.dstat[DS_FIN_TOP], (u64)FX_FIN_CHUNK);
+      fin_cur = readlane64(b0, 0);
+      fin_end = fin_cur + FX_FIN_CHUNK;
+    }
+    const u64 base = fin_cur;
+    fin_cur += nout;
+    if (lane == 0) A.item_base[2ull * r + sd] = base;
+    ulonglong2 r0, r1, t4;
+    u32 src = 0;
+    if (lane < nout) {
+      src = sh.osrc[lane];
+      const ulonglong2* b = reinterpret_cast<const ulonglong2*>(slots + src);
+      r0 = b[2]; r1 = b[3]; t4 = b[4];
+    }
+    if (lane < nout && base + lane < A.fin_cap) {
+      u64 slot = base + lane;
+      ulonglong2* d = reinterpret_cast<ulonglong2*>(A.fin + slot);
+      d[0] = make_ulonglong2(widen(sh.o0[lane]), widen(sh.o1[lane]));
+      d[1] = make_ulonglong2(widen(sh.o2[lane]), widen(sh.o3[lane]));
+      d[2] = r0; d[3] = r1; d[4] = t4;
     }
     return true;
   }
@@ -1002,34 +1125,38 @@ struct FastFx {
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_filter_extract_fast(FxArgs A) {
   __shared__ FmTables tb;
-  __shared__ WaveSh shm[4];
+  __shared__ SideSh<WIDE> shm[4];
   fm_tables_load(tb, A.fwd, A.rev);
-  const u32 wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const u32 wid = uni(threadIdx.x >> 6), lane = threadIdx.x & 63u;
   const u64 wave = (u64)blockIdx.x * 4 + wid, nwaves = (u64)gridDim.x * 4;
-  FastFx<WIDE> fx(A, tb, shm[wid], A.wpool + wave * FX_WPOOL);
-  u64 nerr = 0, nsub = 0;
-  for (u64 r = wave; r < A.n_reads; r += nwaves) {
-    u64 occ_before = fx.nocc;
-    bool done = fx.run((u32)r);
-    if (!done) {
-      fx.nocc = occ_before;  // the general kernel recounts this read
-      if (lane == 0) {
-        u64 w = atomicAdd(&A.dstat[DS_SLOW_READS], 1ull);
-        A.work_out[w] = (u32)r;
-      }
-      continue;
-    }
-    if (fx.xerror) ++nerr;
+  SideFx<WIDE> fx(A, tb, shm[wid], A.wpool + wave * FX_WPOOL);
+  u64 nocc_total = 0, nerr = 0, nsub = 0;
+  for (u64 w = 2ull * A.read_begin + wave; w < 2ull * A.read_end; w += nwaves) {
+    const u32 r = (u32)(w >> 1), sd = (u32)(w & 1);
+    fx.nocc = 0;
+    bool done = fx.run(r, sd);
     if (lane == 0) {
-      u32 sub = 0;
-      for (int o = 0; o < 4; ++o) sub |= A.chain_cnt[r * 4 + o] & SIGAX_CC_SUBSTRING;
-      A.fin_cnt[r] = fx.nout;
-      A.substring[r] = sub ? 1 : 0;
-      if (sub) ++nsub;
+      if (!done) {
+        A.fin_cnt[w] = 0;
+        A.occ_side[w] = 0;
+        if (atomicExch(&A.slow_flag[r], 1u) == 0u) A.work_out[atomicAdd(A.slow_counter, 1ull)] = r;
+      } else {
+        u32 word = (u32)fx.nocc & OCC_SIDE_MASK;
+        nocc_total += fx.nocc;
+        if (fx.xerror) { word |= OCC_SIDE_ERR; ++nerr; }
+        if (sd == 0) {
+          u32 sub = 0;
+          for (int o = 0; o < 4; ++o) sub |= A.chain_cnt[(u64)r * 4 + o] & SIGAX_CC_SUBSTRING;
+          A.substring[r] = sub ? 1 : 0;
+          if (sub) { word |= OCC_SIDE_SUB; ++nsub; }
+        }
+        A.fin_cnt[w] = fx.nout;
+        A.occ_side[w] = word;
+      }
     }
   }
   if (lane == 0) {
-    if (fx.nocc) atomicAdd(&A.dstat[DS_OCC_EXTRACT], fx.nocc);
+    if (nocc_total) atomicAdd(&A.dstat[DS_OCC_EXTRACT], nocc_total);
     if (nerr) atomicAdd(&A.dstat[DS_EXTRACT_ERRORS], nerr);
     if (nsub) atomicAdd(&A.dstat[DS_SUBSTRING], nsub);
   }
@@ -1097,16 +1224,26 @@ __global__ __launch_bounds__(256) void k_scan_apply(const u32* cnt, u64 n, const
   if (base <= n && n < base + 8) offs[n] = ex;  // the thread owning position n writes the grand total
 }
 
-__global__ __launch_bounds__(256) void k_order_scatter(OrderArgs A) {
+// block_offs[r] = offs2[2r]: per-read offsets from the per-(read, side) scan
+__global__ __launch_bounds__(256) void k_pick_read_offsets(const u64* offs2, u64 n_reads, u64* block_offs) {
   u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-  u64 n = A.dstat[DS_FIN_TOP];
-  if (n > A.fin_cap) n = A.fin_cap;
-  if (i >= n) return;
-  u64 dst = A.block_offs[A.fin_read[i]] + A.fin_seq[i];
-  if (dst >= A.out_cap) return;  // only after an overflow, whose results the host discards
-  const ulonglong2* s = reinterpret_cast<const ulonglong2*>(A.fin + i);
-  ulonglong2* d = reinterpret_cast<ulonglong2*>(A.out + dst);
-  d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3]; d[4] = s[4];
+  if (i <= n_reads) block_offs[i] = offs2[2 * i];
+}
+
+// one lane per (read, side) item: copy its blocks from the unordered arena to their place in the ordered output
+__global__ __launch_bounds__(256) void k_order_scatter(OrderArgs A) {
+  u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (w >= A.n_items) return;
+  u32 cnt = A.fin_cnt[w];
+  if (!cnt) return;
+  u64 srcb = A.item_base[w], dstb = A.offs2[w];
+  for (u32 i = 0; i < cnt; ++i) {
+    if (srcb + i >= A.fin_cap || dstb + i >= A.out_cap) return;  // only after an overflow, whose results the host discards
+    const ulonglong2* s = reinterpret_cast<const ulonglong2*>(A.fin + srcb + i);
+    ulonglong2* d = reinterpret_cast<ulonglong2*>(A.out + dstb + i);
+    ulonglong2 v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3], v4 = s[4];
+    d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3; d[4] = v4;
+  }
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -1174,19 +1311,25 @@ void launch_kmer_count(const FmStrand& s, bool wide, const unsigned char* kmers,
 }
 
 void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
-  if (a.n_reads == 0) return;
-  unsigned g = nblk((u64)a.n_reads * 4, 256);
-  if (wide) hipLaunchKernelGGL(k_find<true>, dim3(g), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k_find<false>, dim3(g), dim3(256), 0, st, a);
+  if (a.read_end <= a.read_begin) return;
+  unsigned g = nblk((u64)(a.read_end - a.read_begin) * 4, 256);
+  // Unused dynamic LDS caps the finder's residency (it saturates the memory request rate with few waves), leaving
+  // wave slots and registers for the filter/extract kernel that runs beside it on the other stream.
+  // Measured on MI355X at C2: 28 resident waves/CU 15.7 ms, 12 waves 14.5 ms, 8 waves 13.4 ms, 4 waves 14.9 ms.
+  static const char* env = getenv("SIGAX_FIND_LDS");
+  unsigned lds = env ? (unsigned)atoi(env) : 80000u;  // two 256-thread workgroups per CU
+  if (wide) hipLaunchKernelGGL(k_find<true>, dim3(g), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(k_find<false>, dim3(g), dim3(256), lds, st, a);
 }
 
 void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid, hipStream_t st) {
-  if (a.n_reads == 0) return;
+  if (a.read_end <= a.read_begin) return;
   if (wide) hipLaunchKernelGGL(k_filter_extract_fast<true>, dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_filter_extract_fast<false>, dim3(grid), dim3(256), 0, st, a);
 }
 
 unsigned long long fast_pool_entries_per_wave() { return FX_WPOOL; }
+unsigned long long fast_fin_chunk() { return FX_FIN_CHUNK; }
 
 void launch_filter_extract(const FxArgs& a, bool wide, unsigned grid, hipStream_t st) {
   if (a.n_work == 0 && !a.n_work_ptr) return;
@@ -1204,9 +1347,13 @@ void launch_scan(const u32* cnt, u64 n, u64* partial, u64* offs, u64* total_out,
 
 u64 scan_partials_needed(u64 n) { return (n + 1 + SCAN_ITEMS - 1) / SCAN_ITEMS + 1; }
 
-void launch_order_scatter(const OrderArgs& a, u64 max_items, hipStream_t st) {
-  if (max_items == 0) return;
-  hipLaunchKernelGGL(k_order_scatter, dim3(nblk(max_items, 256)), dim3(256), 0, st, a);
+void launch_pick_read_offsets(const u64* offs2, u64 n_reads, u64* block_offs, hipStream_t st) {
+  hipLaunchKernelGGL(k_pick_read_offsets, dim3(nblk(n_reads + 1, 256)), dim3(256), 0, st, offs2, n_reads, block_offs);
+}
+
+void launch_order_scatter(const OrderArgs& a, hipStream_t st) {
+  if (a.n_items == 0) return;
+  hipLaunchKernelGGL(k_order_scatter, dim3(nblk(a.n_items, 256)), dim3(256), 0, st, a);
 }
 
 void launch_edges(const EdgeArgs& a, bool fill, u64 max_blocks, hipStream_t st) {
