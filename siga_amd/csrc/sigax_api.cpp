@@ -199,7 +199,8 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
   ix->device = device;
   ix->n_symbols = n_symbols;
   ix->n_strings = n_strings;
-  ix->wide = n_symbols >= 0xFFFFFFF0ull;
+  // 64-bit positions when the BWT does not fit 32 bits (SIGAX_FORCE_WIDE=1 exercises that path on small inputs)
+  ix->wide = n_symbols >= 0xFFFFFFF0ull || getenv("SIGAX_FORCE_WIDE") != nullptr;
   const uint8_t* rr[2] = {runs, rruns};
   u64 nr[2] = {n_runs, n_rruns};
   for (int s = 0; s < 2; ++s) {
@@ -365,7 +366,7 @@ struct sigax_batch {
   uint32_t read_base, minov, flags;
   bool ran;
   // arenas
-  DevBuf arena, chain_cnt, pool, wpool, work, occ_side, slow_flag, offs2, item_base, fin, fin_cnt, substring, block_offs, outb, edge_cnt,
+  DevBuf arena, chain_cnt, pool, wpool, work, work64, occ_side, slow_flag, offs2, item_base, fin, fin_cnt, substring, block_offs, outb, edge_cnt,
       edge_offs, edges, partial, dstat;
   uint32_t cap;
   uint32_t pool_cap;
@@ -384,7 +385,7 @@ struct sigax_batch {
 extern "C" void sigax_batch_destroy(sigax_batch* b) {
   if (!b) return;
   hipSetDevice(b->ix->device);
-  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin,
+  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin,
                    &b->fin_cnt, &b->substring, &b->block_offs, &b->outb, &b->edge_cnt, &b->edge_offs, &b->edges,
                    &b->partial, &b->dstat};
   for (DevBuf* d : all)
@@ -511,10 +512,11 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   if ((rc = ensure(&b->substring, (size_t)n + 16)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->block_offs, ((size_t)n + 2) * 8)) != SIGAX_OK) return rc;
   // fast filter/extract kernel: persistent waves (one read at a time per wave) with a private pool each
-  unsigned fast_grid = (unsigned)std::min<u64>(2048, (2 * (u64)n + 3) / 4);
+  unsigned fast_grid = (unsigned)std::min<u64>(2048, ((u64)n + 3) / 4);  // two items per wave
   if (fast_grid == 0) fast_grid = 1;
   if ((rc = ensure(&b->wpool, (size_t)fast_grid * 4 * fast_pool_entries_per_wave() * SIGAX_ENT_BYTES)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->work, ((size_t)n + 1) * 4)) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->work64, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
   // general filter/extract kernel (reads the fast kernel queued): persistent lanes with a private pool each
   unsigned want_grid = (unsigned)std::min<u64>(128, ((u64)n + 255) / 256);
   if (want_grid == 0) want_grid = 1;
@@ -588,6 +590,8 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     xa.wpool = (Ent*)b->wpool.p;
     xa.work_out = (uint32_t*)b->work.p + rb;
     xa.slow_counter = dstat + DS_SLOW_BASE + i;
+    xa.work64 = (uint32_t*)b->work64.p + 2 * (size_t)rb;
+    xa.w64_counter = dstat + DS_W64_BASE + i;
     xa.read_begin = rb;
     xa.read_end = re;
     xa.item_base = (u64*)b->item_base.p;
@@ -603,7 +607,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
       xa.work = nullptr;
       xa.n_work = 0;
       xa.n_work_ptr = nullptr;
-      launch_filter_extract_fast(xa, ix->wide, fast_grid, b->s_fx);
+      launch_filter_extract_fast(xa, ix->wide, fast_grid, std::min(fast_grid, 512u), b->s_fx);
       xa.work = (const uint32_t*)b->work.p + rb;  // the general kernel redoes what the fast one queued
       xa.n_work = 0;
       xa.n_work_ptr = dstat + DS_SLOW_BASE + i;

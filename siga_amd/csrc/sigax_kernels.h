@@ -24,7 +24,8 @@ enum {
   DS_TOTAL_BLOCKS, // written by the scan: sum of per-read block counts
   DS_TOTAL_EDGES,  // written by the edge scan
   DS_SLOW_BASE,    // [DS_SLOW_BASE + i]: reads sub-batch i queued for the general kernel (i < SIGAX_MAX_SUB)
-  DS_COUNT = 32
+  DS_W64_BASE = DS_SLOW_BASE + 8,  // [DS_W64_BASE + i]: (read, side) items sub-batch i queued for the 64-lane launch
+  DS_COUNT = 48
 };
 #define SIGAX_MAX_SUB 8
 
@@ -56,6 +57,8 @@ struct FxArgs {
   Ent* wpool;         // fast kernel: [waves][fast_pool_entries_per_wave()]
   uint32_t* work_out; // fast kernel: reads queued for the general kernel, counted in *slow_counter
   unsigned long long* slow_counter;
+  uint32_t* work64;   // 32-lane launch: (read, side) items queued for the 64-lane launch, counted in *w64_counter
+  unsigned long long* w64_counter;
   uint32_t read_begin, read_end;  // fast kernel: this launch's sub-batch
   sigax_block* fin;   // unordered final blocks, allocated in per-wave / per-lane chunks
   unsigned long long* item_base;  // [n_reads][2]: where a (read, side) item's blocks start in `fin`
@@ -100,7 +103,7 @@ void launch_kmer_count(const FmStrand& s, bool wide, const unsigned char* kmers,
                        unsigned long long* out, hipStream_t st);
 void launch_find(const FindArgs& a, bool wide, hipStream_t st);
 void launch_filter_extract(const FxArgs& a, bool wide, unsigned grid, hipStream_t st);
-void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid, hipStream_t st);
+void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid32, unsigned grid64, hipStream_t st);
 unsigned long long fast_pool_entries_per_wave();
 void launch_scan(const uint32_t* cnt, unsigned long long n, unsigned long long* partial, unsigned long long* offs,
                  unsigned long long* total_out, hipStream_t st);

@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256) void k_filter_extract(FxArgs A) {
 }
 
 // -------------------------------------------------------------------------------------------------------
-// k_filter_extract_fast: one wave per (read, side), one lane per overlap block.
+// k_filter_extract_fast: one lane group (32 or 64 lanes) per (read, side), one lane per overlap block.
 //
 // Side 0 = the suffix lists (finds 0 and 3), side 1 = the prefix lists (finds 1 and 2): the two halves of
 // OverlapBuilder::overlap (overlap_builder.cpp:1135-1173) are independent until the final push order, which
@@ -800,8 +800,8 @@ __device__ __forceinline__ void fm_rank5p(const FmRef& s, typename PosOf<WIDE>::
   v[0] = (P)pc - (A + C + G + T);
 }
 
-template <bool WIDE>
-struct SideFx {
+template <bool WIDE, int W>
+struct GFx {
   typedef typename PosOf<WIDE>::type P;
   struct E {  // a block's capped pair in registers
     P c0lo, c0hi, c1lo, c1hi;
@@ -811,18 +811,35 @@ struct SideFx {
   const FmTables& tb;
   SideSh<WIDE>& sh;
   FmRef F, R;
-  Ent* wpool;  // FX_NSLOT group slots of 64 entries (branch copies only)
-  u32 lane;
-  u64 lt;
+  Ent* wpool;  // FX_NSLOT group slots of 64 entries (branch copies only), shared by the wave's lane groups
+  u32 lane;    // lane in the wave
+  u32 gb;      // first lane of this lane's group (0, or 32 for the second group when W == 32)
+  u32 gl;      // lane inside the group
+  u64 glt;     // group lanes below this one, as a mask over group lanes
   const sigax_block* slots;
   u32 nout;
-  u64 nocc;
+  u32 nocc;
   bool xerror;
-  u64 fin_cur, fin_end;  // this wave's chunk of the unordered final-block arena
+  u64 fin_cur, fin_end;  // this wave's chunk of the unordered final-block arena (wave-uniform)
 
-  __device__ SideFx(const FxArgs& a, const FmTables& t, SideSh<WIDE>& s, Ent* wp)
+  __device__ GFx(const FxArgs& a, const FmTables& t, SideSh<WIDE>& s, Ent* wp)
       : A(a), tb(t), sh(s), F(fm_ref(a.fwd, 0)), R(fm_ref(a.rev, 1)), wpool(wp), lane(threadIdx.x & 63u),
-        lt((1ull << (threadIdx.x & 63u)) - 1ull), slots(nullptr), nout(0), nocc(0), xerror(false), fin_cur(0), fin_end(0) {}
+        gb(W == 64 ? 0u : (threadIdx.x & 32u)), gl(W == 64 ? (threadIdx.x & 63u) : (threadIdx.x & 31u)),
+        glt((1ull << (W == 64 ? (threadIdx.x & 63u) : (threadIdx.x & 31u))) - 1ull), slots(nullptr), nout(0), nocc(0),
+        xerror(false), fin_cur(0), fin_end(0) {}
+
+  // ---- lane-group primitives: a group is the whole wave (W == 64) or one half of it (W == 32) ----
+  __device__ u64 gballot(bool p) const {
+    u64 b = __ballot(p);
+    return W == 64 ? b : (gb ? (b >> 32) : (b & 0xFFFFFFFFull));
+  }
+  __device__ u32 gshfl(u32 v, u32 idx) const { return (u32)__shfl((int)v, (int)(gb + idx), 64); }
+  __device__ u64 gshfl(u64 v, u32 idx) const {
+    u32 lo = gshfl((u32)v, idx), hi = gshfl((u32)(v >> 32), idx);
+    return ((u64)hi << 32) | lo;
+  }
+  static __device__ u32 pop(u64 m) { return (u32)__popcll(m); }
+  static __device__ u32 ffs0(u64 m) { return (u32)__ffsll((long long)m) - 1u; }
 
   static __device__ bool valid(P lo, P hi) { return hi != (P)~(P)0 && hi >= lo; }  // fmindex.h:87-89
 
@@ -850,8 +867,8 @@ struct SideFx {
     e.c0lo = (P)a.x; e.c0hi = (P)a.y; e.c1lo = (P)b.x; e.c1hi = (P)b.y;
     e.src = (u32)c.x; e.len = (u32)(c.x >> 32);
   }
-  __device__ void out_put(u32 i, const E& e) {
-    sh.o0[i] = e.c0lo; sh.o1[i] = e.c0hi; sh.o2[i] = e.c1lo; sh.o3[i] = e.c1hi; sh.osrc[i] = e.src;
+  __device__ void out_put(u32 i, const E& e) {  // i = position in this group's output
+    sh.o0[gb + i] = e.c0lo; sh.o1[gb + i] = e.c0hi; sh.o2[gb + i] = e.c1lo; sh.o3[gb + i] = e.c1hi; sh.osrc[gb + i] = e.src;
   }
 
   static __device__ P sel5(const P v[5], u32 k) { return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : k == 3 ? v[3] : v[4]; }
@@ -868,33 +885,35 @@ struct SideFx {
     e.c1hi = pb + ub - 1;
   }
 
-  // IrreducibleBlockListExtractor::extract (overlap_builder.cpp:711-809) over the n entries held one per lane,
-  // already sorted by length descending.  Returns false when the read has to go to the general kernel.
-  // The group table lives in VGPR lanes: lane s holds slot s's alive mask, lane i holds the i-th group of the
-  // list (gD) / of this pass's incomings (gI); reads are v_readlane with a scalar index, so every value that steers
-  // control flow is in SGPRs.
+  // IrreducibleBlockListExtractor::extract (overlap_builder.cpp:711-809) over the n entries held one per group lane,
+  // already sorted by length descending.  Returns false when the item has to be redone by a wider kernel.
+  // The group table lives in VGPR lanes of the group: lane s holds slot s's alive mask, lane i holds the i-th group
+  // of the list (gD) / of this pass's incomings (gI).  Every scalar of the algorithm (ng, p, slot, masks) is a
+  // per-lane value that is equal across the lane group, so two groups of one wave can be at different points.
   __device__ bool extract(E e, u32 n) {
     if (n == 0) return true;
+    const u32 OUTCAP = W == 64 ? FX_OUTCAP : FX_OUTCAP / 2;
+    const u32 NSLOT = W == 64 ? FX_NSLOT : 32 < FX_NSLOT ? 32 : FX_NSLOT;
     u32 cur = 0, ng = 1, nslot = 1;
-    u64 gAlive = lane == 0 ? (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) : 0ull;
+    u64 gAlive = gl == 0 ? (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) : 0ull;
     u32 gD = 0, gI = 0;
     u32 guard = 0;
     while (ng > 0) {
       u32 ni = 0, p = 0;
       while (p != ng) {
-        const u32 slot = __builtin_amdgcn_readlane(gD, p);
-        const u64 alive = readlane64(gAlive, slot);
+        const u32 slot = gshfl(gD, p);
+        const u64 alive = gshfl(gAlive, slot);
         if (slot != cur) {
-          const u64 was = readlane64(gAlive, cur);
-          if ((was >> lane) & 1ull) pool_put(wpool + cur * 64 + lane, e);
-          if ((alive >> lane) & 1ull) pool_get(e, wpool + slot * 64 + lane);
+          const u64 was = gshfl(gAlive, cur);
+          if ((was >> gl) & 1ull) pool_put(wpool + cur * 64 + lane, e);
+          if ((alive >> gl) & 1ull) pool_get(e, wpool + slot * 64 + lane);
           cur = slot;
         }
         bool eraseGroup = true;
         if (alive) {
-          const bool mine = (alive >> lane) & 1ull;
-          const u32 first = (u32)__ffsll((long long)alive) - 1u;
-          const u32 topLen = __builtin_amdgcn_readlane(e.len, first);
+          const bool mine = (alive >> gl) & 1ull;
+          const u32 first = ffs0(alive);
+          const u32 topLen = gshfl(e.len, first);
           const bool isTop = mine && e.len == topLen;
           const FmRef ix = ext_index(e.src);
           const bool qcomp = (af_of(e.src) & 4u) != 0;
@@ -909,19 +928,19 @@ struct SideFx {
           const bool xc = mine && (qcomp ? (u[3] != l[3]) : (u[2] != l[2]));
           const bool xg = mine && (qcomp ? (u[2] != l[2]) : (u[3] != l[3]));
           const bool xt = mine && (qcomp ? (u[1] != l[1]) : (u[4] != l[4]));
-          const u64 topMask = __ballot(isTop);
-          if (__ballot(isTop && x0)) {
+          const u64 topMask = gballot(isTop);
+          if (gballot(isTop && x0)) {
             // the top-level block has ended: emit the top-level blocks in list order (:747-766)
-            u64 bad = __ballot(isTop && !x0);
+            u64 bad = gballot(isTop && !x0);
             u64 emitMask = topMask;
-            if (bad) emitMask &= (1ull << ((u32)__ffsll((long long)bad) - 1u)) - 1ull;
-            nocc += 2ull * (u64)__popcll(topMask);
-            u32 ne = (u32)__popcll(emitMask);
-            if (nout + ne > FX_OUTCAP) return false;
-            if ((emitMask >> lane) & 1ull) {
+            if (bad) emitMask &= (1ull << ffs0(bad)) - 1ull;
+            nocc += 2u * pop(topMask);
+            u32 ne = pop(emitMask);
+            if (nout + ne > OUTCAP) return false;
+            if ((emitMask >> gl) & 1ull) {
               E br = e;
               apply_updateR(br, 0, ix.which, l, u);
-              out_put(nout + (u32)__popcll(emitMask & lt), br);
+              out_put(nout + pop(emitMask & glt), br);
             }
             nout += ne;
             if (bad) {
@@ -929,31 +948,31 @@ struct SideFx {
               return true;
             }
           } else {
-            nocc += 2ull * (u64)__popcll(alive);
-            u64 any0 = __ballot(x0), any1 = __ballot(xa), any2 = __ballot(xc), any3 = __ballot(xg), any4 = __ballot(xt);
+            nocc += 2u * pop(alive);
+            u64 any0 = gballot(x0), any1 = gballot(xa), any2 = gballot(xc), any3 = gballot(xg), any4 = gballot(xt);
             u32 nz = (any0 != 0) + (any1 != 0) + (any2 != 0) + (any3 != 0) + (any4 != 0);
             if (nz == 1) {
               u32 c = any0 ? 0u : any1 ? 1u : any2 ? 2u : any3 ? 3u : 4u;
               u32 b = qcomp ? comp_rank(c) : c;
               if (mine) apply_updateR(e, b, ix.which, l, u);
               bool ok = mine && valid(e.c0lo, e.c0hi) && valid(e.c1lo, e.c1hi);
-              u64 m = __ballot(ok);
-              if (lane == slot) gAlive = m;
+              u64 m = gballot(ok);
+              if (gl == slot) gAlive = m;
               eraseGroup = false;
             } else {
               for (u32 c = 0; c < 5; ++c) {
                 u64 ak = c == 0 ? any0 : c == 1 ? any1 : c == 2 ? any2 : c == 3 ? any3 : any4;
                 if (!ak) continue;
-                if (nslot >= FX_NSLOT || ni >= FX_NSLOT) return false;
+                if (nslot >= NSLOT || ni >= NSLOT) return false;
                 u32 ns = nslot++;
                 E br = e;
                 u32 b = qcomp ? comp_rank(c) : c;
                 if (mine) apply_updateR(br, b, ix.which, l, u);
                 bool ok = mine && valid(br.c0lo, br.c0hi) && valid(br.c1lo, br.c1hi);
                 if (ok) pool_put(wpool + ns * 64 + lane, br);
-                u64 m = __ballot(ok);
-                if (lane == ns) gAlive = m;
-                if (lane == ni) gI = ns;
+                u64 m = gballot(ok);
+                if (gl == ns) gAlive = m;
+                if (gl == ni) gI = ns;
                 ++ni;
               }
             }
@@ -961,8 +980,8 @@ struct SideFx {
         }
         // body `i = erase(i)` / `++i`, then the loop header's `++i` on the ring [g0..g(k-1), end]
         if (eraseGroup) {
-          u32 nxt = __shfl_down(gD, 1, 64);
-          if (lane >= p) gD = nxt;
+          u32 nxt = gshfl(gD, gl + 1 < (u32)W ? gl + 1 : gl);
+          if (gl >= p) gD = nxt;
           --ng;
         } else {
           p = p + 1 > ng ? 0 : p + 1;
@@ -970,191 +989,208 @@ struct SideFx {
         p = p + 1 > ng ? 0 : p + 1;
         if (++guard > (1u << 20)) return false;
       }
-      if (ng + ni > FX_NSLOT) return false;
+      if (ng + ni > NSLOT) return false;
       for (u32 i = 0; i < ni; ++i) {
-        u32 v = __builtin_amdgcn_readlane(gI, i);
-        if (lane == ng) gD = v;
+        u32 v = gshfl(gI, i);
+        if (gl == ng) gD = v;
         ++ng;
       }
     }
     return true;
   }
 
-  // returns false when the read must be redone by the general kernel
-  __device__ bool run(u32 r, u32 sd) {
+  // one (read, side) item on this lane group; returns false when it must be redone by a wider kernel
+  __device__ bool body(u32 r, u32 sd) {
+    const u32 OUTCAP = W == 64 ? FX_OUTCAP : FX_OUTCAP / 2;
     nout = 0;
+    nocc = 0;
     xerror = false;
     slots = A.arena + (u64)r * 4 * A.cap;
-    const u32 L = uni((u32)(A.offs[r + 1] - A.offs[r]));
+    const u32 L = (u32)(A.offs[r + 1] - A.offs[r]);
     u32 cc[4];
     {
       uint4 c4 = reinterpret_cast<const uint4*>(A.chain_cnt)[r];
-      cc[0] = uni(c4.x); cc[1] = uni(c4.y); cc[2] = uni(c4.z); cc[3] = uni(c4.w);
+      cc[0] = c4.x; cc[1] = c4.y; cc[2] = c4.z; cc[3] = c4.w;
     }
     if (sd == 0) {  // containfwd, containrev first (:1161-1162)
-      bool has = lane < 4 && (cc[lane & 3] & SIGAX_CC_CONTAIN);
-      u64 m = __ballot(has);
+      u32 ccl = gl == 0 ? cc[0] : gl == 1 ? cc[1] : gl == 2 ? cc[2] : cc[3];
+      bool has = gl < 4 && (ccl & SIGAX_CC_CONTAIN);
+      u64 m = gballot(has);
       if (has) {
         E e;
-        load_block(e, lane * A.cap + (A.cap - 1));
-        out_put((u32)__popcll(m & lt), e);
+        load_block(e, gl * A.cap + (A.cap - 1));
+        out_put(pop(m & glt), e);
       }
-      nout = (u32)__popcll(m);
+      nout = pop(m);
     }
     const u32 chA = sd == 0 ? 0u : 1u, chB = sd == 0 ? 3u : 2u;
-    const u32 nA = cc[chA] & SIGAX_CC_COUNT_MASK, nB = cc[chB] & SIGAX_CC_COUNT_MASK;
+    const u32 nA = (sd == 0 ? cc[0] : cc[1]) & SIGAX_CC_COUNT_MASK, nB = (sd == 0 ? cc[3] : cc[2]) & SIGAX_CC_COUNT_MASK;
     const u32 c0 = (cc[0] & SIGAX_CC_CONTAIN) ? 1u : 0u, c1 = (cc[1] & SIGAX_CC_CONTAIN) ? 1u : 0u;
     const u32 c2 = (cc[2] & SIGAX_CC_CONTAIN) ? 1u : 0u, c3 = (cc[3] & SIGAX_CC_CONTAIN) ? 1u : 0u;
     // list X = find A's blocks + containfwd {0,1}; list Y = find B's blocks + containrev {2,3} (:1137-1140)
     const u32 nX = nA + c0 + c1, nY = nB + c2 + c3, T = nX + nY;
-    if (T > 64) return false;
-    if (T > 0) {
-      const bool active = lane < T;
-      const u32 list = lane >= nX ? 1u : 0u;
-      const u32 k = list ? lane - nX : lane;
-      u32 src = 0;
-      if (active) {
-        if (!list) src = k < nA ? chA * A.cap + k : ((k == nA && c0) ? 0u : 1u) * A.cap + (A.cap - 1);
-        else src = k < nB ? chB * A.cap + k : ((k == nB && c2) ? 2u : 3u) * A.cap + (A.cap - 1);
-      }
-      E e;
-      e.c0lo = e.c0hi = e.c1lo = e.c1hi = 0; e.src = 0; e.len = 0;
-      if (active) load_block(e, src);
-      const bool member = active && e.len != L;  // ContainmentBlockRemover (:1094-1111)
-      const u32 nm = (u32)__popcll(__ballot(member));
-      if (A.irreducible) {
-        // SubMaximalBlockFilter::filter (:930-953) sorts by capped[0].lower and resolves adjacent intersecting
-        // blocks.  With the blocks sorted by lower bound, SOME pair intersects iff some ADJACENT pair does (if i
-        // precedes j and lower_j <= upper_i, the successor k of i has lower_k <= lower_j <= upper_i), so an
-        // any-pair test inside each list decides exactly whether resolve() is needed: general kernel then.
-        bool inter = false;
-        for (u32 j = 0; j < T; ++j) {
-          P loj = readlaneP(e.c0lo, j), hij = readlaneP(e.c0hi, j);
-          u32 lj = j >= nX ? 1u : 0u;
-          inter |= (lj == list) & (j != lane) & !(e.c0lo > hij || loj > e.c0hi);  // coord.h:37-40
-        }
-        if (__ballot(active && inter)) return false;
-        // X += Y; stable sort by length descending (:715-716,1169), ties keep list X first.  Both finds pushed their
-        // blocks in increasing length, so the position is a merge rank: blocks after me in my own list, plus the
-        // other list's blocks that are longer (or, seen from Y, as long).
-        const u32 nAm = nA, nBm = nB;  // list members without the containment copies
-        u32 other = 0;
-        {
-          // binary search in the other list's lengths (ascending in lane order)
-          const u32 obase = list ? 0u : nX, on = list ? nAm : nBm;
-          u32 lo = 0, hi = on;  // first index whose length is > mine (list X) / >= mine (list Y)
-          for (u32 step = 0; step < 7; ++step) {
-            u32 mid = (lo + hi) >> 1;
-            u32 lenm = __shfl(e.len, (int)(obase + (mid < on ? mid : 0)), 64);
-            bool right = list ? (lenm < e.len) : (lenm <= e.len);
-            if (lo < hi) {
-              if (right) lo = mid + 1; else hi = mid;
-            }
-          }
-          other = on - lo;
-        }
-        const u32 mine_after = (list ? nBm : nAm) - 1u - k;
-        const u32 pos = mine_after + other;
-        if (member) {
-          sh.e0[pos] = e.c0lo; sh.e1[pos] = e.c0hi; sh.e2[pos] = e.c1lo; sh.e3[pos] = e.c1hi;
-          sh.esrc[pos] = e.src; sh.elen[pos] = e.len;
-        }
-        wave_lds_sync();
-        E g;
-        g.c0lo = g.c0hi = g.c1lo = g.c1hi = 0; g.src = 0; g.len = 0;
-        if (lane < nm) {
-          g.c0lo = sh.e0[lane]; g.c0hi = sh.e1[lane]; g.c1lo = sh.e2[lane]; g.c1hi = sh.e3[lane];
-          g.src = sh.esrc[lane]; g.len = sh.elen[lane];
-        }
-        wave_lds_sync();
-        if (!extract(g, nm)) return false;
-      } else {
-        // exhaustive: the filtered lists go out as they are, X then Y, each in capped[0].lower order (:1175-1178):
-        // stable rank by capped[0].lower inside the own list (SubMaximalBlockFilter::filter's sort, :930-931)
-        u32 rank = 0;
-        bool inter = false;
-        for (u32 j = 0; j < T; ++j) {
-          P loj = readlaneP(e.c0lo, j), hij = readlaneP(e.c0hi, j);
-          u32 lj = j >= nX ? 1u : 0u, kj = lj ? j - nX : j;
-          bool same = active && lj == list;
-          if (same && (loj < e.c0lo || (loj == e.c0lo && kj < k))) ++rank;
-          inter |= same & (j != lane) & !(e.c0lo > hij || loj > e.c0hi);
-        }
-        if (__ballot(active && inter)) return false;
-        u32 pos = 0;
-        for (u32 j = 0; j < T; ++j) {
-          u32 lenj = __builtin_amdgcn_readlane(e.len, j);
-          u32 rj = __builtin_amdgcn_readlane(rank, j);
-          u32 lj = j >= nX ? 1u : 0u;
-          if (lenj != L && (lj < list || (lj == list && rj < rank))) ++pos;
-        }
-        if (nout + nm > FX_OUTCAP) return false;
-        if (member) out_put(nout + pos, e);
-        nout += nm;
-      }
+    if (T > (u32)W) return false;
+    if (T == 0) return true;
+    const bool active = gl < T;
+    const u32 list = gl >= nX ? 1u : 0u;
+    const u32 k = list ? gl - nX : gl;
+    u32 src = 0;
+    if (active) {
+      if (!list) src = k < nA ? chA * A.cap + k : ((k == nA && c0) ? 0u : 1u) * A.cap + (A.cap - 1);
+      else src = k < nB ? chB * A.cap + k : ((k == nB && c2) ? 2u : 3u) * A.cap + (A.cap - 1);
     }
-    // flush this side into the wave's chunk of the unordered arena (one atomic per FX_FIN_CHUNK blocks)
+    E e;
+    e.c0lo = e.c0hi = e.c1lo = e.c1hi = 0; e.src = 0; e.len = 0;
+    if (active) load_block(e, src);
+    const bool member = active && e.len != L;  // ContainmentBlockRemover (:1094-1111)
+    const u32 nm = pop(gballot(member));
+    // SubMaximalBlockFilter::filter (:930-953) sorts by capped[0].lower and resolves adjacent intersecting blocks.
+    // With the blocks sorted by lower bound, SOME pair intersects iff some ADJACENT pair does (if i precedes j and
+    // lower_j <= upper_i, the successor k of i has lower_k <= lower_j <= upper_i), so an any-pair test inside each
+    // list decides exactly whether resolve() is needed; if so the item goes to the general kernel.
+    u32 rank = 0;  // stable rank by capped[0].lower inside the own list (only the exhaustive output order needs it)
+    bool inter = false;
+    for (u32 j = 0; j < T; ++j) {
+      P loj = gshfl(e.c0lo, j), hij = gshfl(e.c0hi, j);
+      u32 lj = j >= nX ? 1u : 0u, kj = lj ? j - nX : j;
+      bool same = active && lj == list;
+      if (!A.irreducible && same && (loj < e.c0lo || (loj == e.c0lo && kj < k))) ++rank;
+      inter |= same & (j != gl) & !(e.c0lo > hij || loj > e.c0hi);  // coord.h:37-40
+    }
+    if (gballot(inter)) return false;
+    if (A.irreducible) {
+      // X += Y; stable sort by length descending (:715-716,1169), ties keep list X first.  Both finds pushed their
+      // blocks in increasing length, so the position is a merge rank: blocks after me in my own list, plus the other
+      // list's blocks that are longer (or, seen from Y, as long): a binary search over the other list's lanes.
+      const u32 obase = list ? 0u : nX, on = list ? nA : nB;
+      u32 lo = 0, hi = on;
+      for (u32 step = 0; step < 7; ++step) {
+        u32 mid = (lo + hi) >> 1;
+        u32 lenm = gshfl(e.len, obase + (mid < on ? mid : 0));
+        bool right = list ? (lenm < e.len) : (lenm <= e.len);
+        if (lo < hi) {
+          if (right) lo = mid + 1; else hi = mid;
+        }
+      }
+      const u32 pos = ((list ? nB : nA) - 1u - k) + (on - lo);
+      if (member) {
+        sh.e0[gb + pos] = e.c0lo; sh.e1[gb + pos] = e.c0hi; sh.e2[gb + pos] = e.c1lo; sh.e3[gb + pos] = e.c1hi;
+        sh.esrc[gb + pos] = e.src; sh.elen[gb + pos] = e.len;
+      }
+      wave_lds_sync();
+      E g;
+      g.c0lo = g.c0hi = g.c1lo = g.c1hi = 0; g.src = 0; g.len = 0;
+      if (gl < nm) {
+        g.c0lo = sh.e0[lane]; g.c0hi = sh.e1[lane]; g.c1lo = sh.e2[lane]; g.c1hi = sh.e3[lane];
+        g.src = sh.esrc[lane]; g.len = sh.elen[lane];
+      }
+      wave_lds_sync();
+      return extract(g, nm);
+    }
+    // exhaustive: the filtered lists go out as they are, X then Y, each in capped[0].lower order (:1175-1178)
+    u32 pos = 0;
+    for (u32 j = 0; j < T; ++j) {
+      u32 lenj = gshfl(e.len, j), rj = gshfl(rank, j);
+      u32 lj = j >= nX ? 1u : 0u;
+      if (lenj != L && (lj < list || (lj == list && rj < rank))) ++pos;
+    }
+    if (nout + nm > OUTCAP) return false;
+    if (member) out_put(nout + pos, e);
+    nout += nm;
+    return true;
+  }
+
+  // Both lane groups of the wave together: run the items, then flush their blocks into the wave's chunk of the
+  // unordered arena (one atomic per FX_FIN_CHUNK blocks).  `has` = this group has an item; returns done.
+  __device__ bool run(bool has, u32 r, u32 sd) {
+    bool done = false;
+    if (has) done = body(r, sd);
     wave_lds_sync();
-    if (fin_cur + nout > fin_end) {
+    const u32 mine_n = (has && done) ? nout : 0u;
+    const u32 n0 = __builtin_amdgcn_readlane(mine_n, 0);
+    const u32 n1 = W == 64 ? 0u : __builtin_amdgcn_readlane(mine_n, 32);
+    if (n0 + n1 == 0) return done;
+    if (fin_cur + n0 + n1 > fin_end) {
       u64 b0 = 0;
       if (lane == 0) b0 = atomicAdd(&A.dstat[DS_FIN_TOP], (u64)FX_FIN_CHUNK);
       fin_cur = readlane64(b0, 0);
       fin_end = fin_cur + FX_FIN_CHUNK;
     }
-    const u64 base = fin_cur;
-    fin_cur += nout;
-    if (lane == 0) A.item_base[2ull * r + sd] = base;
-    ulonglong2 r0, r1, t4;
-    u32 src = 0;
-    if (lane < nout) {
-      src = sh.osrc[lane];
-      const ulonglong2* b = reinterpret_cast<const ulonglong2*>(slots + src);
-      r0 = b[2]; r1 = b[3]; t4 = b[4];
+    const u64 base = fin_cur + (gb ? n0 : 0u);
+    fin_cur += n0 + n1;
+    if (has && done) {
+      if (gl == 0) A.item_base[2ull * r + sd] = base;
+      if (gl < nout && base + gl < A.fin_cap) {
+        const u32 src = sh.osrc[lane];
+        const ulonglong2* b = reinterpret_cast<const ulonglong2*>(slots + src);
+        ulonglong2 r0 = b[2], r1 = b[3], t4 = b[4];
+        ulonglong2* d = reinterpret_cast<ulonglong2*>(A.fin + base + gl);
+        d[0] = make_ulonglong2(widen(sh.o0[lane]), widen(sh.o1[lane]));
+        d[1] = make_ulonglong2(widen(sh.o2[lane]), widen(sh.o3[lane]));
+        d[2] = r0; d[3] = r1; d[4] = t4;
+      }
     }
-    if (lane < nout && base + lane < A.fin_cap) {
-      u64 slot = base + lane;
-      ulonglong2* d = reinterpret_cast<ulonglong2*>(A.fin + slot);
-      d[0] = make_ulonglong2(widen(sh.o0[lane]), widen(sh.o1[lane]));
-      d[1] = make_ulonglong2(widen(sh.o2[lane]), widen(sh.o3[lane]));
-      d[2] = r0; d[3] = r1; d[4] = t4;
+    return done;
+  }
+
+  // per-item bookkeeping by the group's first lane
+  __device__ void account(bool has, bool done, u64 item, u64& nocc_total, u64& nerr, u64& nsub) {
+    if (!has || gl != 0 || !done) return;
+    const u32 r = (u32)(item >> 1), sd = (u32)(item & 1);
+    u32 word = nocc & OCC_SIDE_MASK;
+    nocc_total += nocc;
+    if (xerror) { word |= OCC_SIDE_ERR; ++nerr; }
+    if (sd == 0) {
+      uint4 c4 = reinterpret_cast<const uint4*>(A.chain_cnt)[r];
+      u32 sub = (c4.x | c4.y | c4.z | c4.w) & SIGAX_CC_SUBSTRING;
+      A.substring[r] = sub ? 1 : 0;
+      if (sub) { word |= OCC_SIDE_SUB; ++nsub; }
     }
-    return true;
+    A.fin_cnt[item] = nout;
+    A.occ_side[item] = word;
   }
 };
 
-template <bool WIDE>
+// W == 32: two (read, side) items per wave, one per half; items that do not fit (more than 32 blocks, branching beyond
+// the half's slots, output beyond its share) are queued for the W == 64 launch, which in turn queues what it cannot
+// finish for the general kernel.
+template <bool WIDE, int W>
 __global__ __launch_bounds__(256) void k_filter_extract_fast(FxArgs A) {
   __shared__ FmTables tb;
   __shared__ SideSh<WIDE> shm[4];
   fm_tables_load(tb, A.fwd, A.rev);
-  const u32 wid = uni(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  const u32 wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const u64 wave = (u64)blockIdx.x * 4 + wid, nwaves = (u64)gridDim.x * 4;
-  SideFx<WIDE> fx(A, tb, shm[wid], A.wpool + wave * FX_WPOOL);
+  GFx<WIDE, W> fx(A, tb, shm[wid], A.wpool + wave * FX_WPOOL);
   u64 nocc_total = 0, nerr = 0, nsub = 0;
-  for (u64 w = 2ull * A.read_begin + wave; w < 2ull * A.read_end; w += nwaves) {
-    const u32 r = (u32)(w >> 1), sd = (u32)(w & 1);
-    fx.nocc = 0;
-    bool done = fx.run(r, sd);
-    if (lane == 0) {
-      if (!done) {
-        A.fin_cnt[w] = 0;
-        A.occ_side[w] = 0;
-        if (atomicExch(&A.slow_flag[r], 1u) == 0u) A.work_out[atomicAdd(A.slow_counter, 1ull)] = r;
-      } else {
-        u32 word = (u32)fx.nocc & OCC_SIDE_MASK;
-        nocc_total += fx.nocc;
-        if (fx.xerror) { word |= OCC_SIDE_ERR; ++nerr; }
-        if (sd == 0) {
-          u32 sub = 0;
-          for (int o = 0; o < 4; ++o) sub |= A.chain_cnt[(u64)r * 4 + o] & SIGAX_CC_SUBSTRING;
-          A.substring[r] = sub ? 1 : 0;
-          if (sub) { word |= OCC_SIDE_SUB; ++nsub; }
-        }
-        A.fin_cnt[w] = fx.nout;
-        A.occ_side[w] = word;
+  if (W == 32) {
+    const u64 first = 2ull * A.read_begin, last = 2ull * A.read_end;
+    for (u64 w0 = first + wave * 2; w0 < last; w0 += nwaves * 2) {
+      const u64 item = w0 + (lane >> 5);
+      const bool has = item < last;
+      bool done = fx.run(has, (u32)(item >> 1), (u32)(item & 1));
+      if (has && !done && fx.gl == 0) {
+        A.fin_cnt[item] = 0;
+        A.occ_side[item] = 0;
+        A.work64[atomicAdd(A.w64_counter, 1ull)] = (u32)item;
       }
+      fx.account(has, done, item, nocc_total, nerr, nsub);
+    }
+  } else {
+    const u64 n = *A.w64_counter;
+    for (u64 i = wave; i < n; i += nwaves) {
+      const u64 item = A.work64[i];
+      bool done = fx.run(true, (u32)(item >> 1), (u32)(item & 1));
+      if (!done && lane == 0) {
+        const u32 r = (u32)(item >> 1);
+        A.fin_cnt[item] = 0;
+        A.occ_side[item] = 0;
+        if (atomicExch(&A.slow_flag[r], 1u) == 0u) A.work_out[atomicAdd(A.slow_counter, 1ull)] = r;
+      }
+      fx.account(true, done, item, nocc_total, nerr, nsub);
     }
   }
+  nocc_total = wave_sum(nocc_total); nerr = wave_sum(nerr); nsub = wave_sum(nsub);
   if (lane == 0) {
     if (nocc_total) atomicAdd(&A.dstat[DS_OCC_EXTRACT], nocc_total);
     if (nerr) atomicAdd(&A.dstat[DS_EXTRACT_ERRORS], nerr);
@@ -1316,16 +1352,22 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
   // Unused dynamic LDS caps the finder's residency (it saturates the memory request rate with few waves), leaving
   // wave slots and registers for the filter/extract kernel that runs beside it on the other stream.
   // Measured on MI355X at C2: 28 resident waves/CU 15.7 ms, 12 waves 14.5 ms, 8 waves 13.4 ms, 4 waves 14.9 ms.
+  // 60 KB per workgroup = two workgroups (8 waves) per CU and 40 KB of LDS left for filter/extract workgroups.
   static const char* env = getenv("SIGAX_FIND_LDS");
-  unsigned lds = env ? (unsigned)atoi(env) : 80000u;  // two 256-thread workgroups per CU
+  unsigned lds = env ? (unsigned)atoi(env) : 60000u;
   if (wide) hipLaunchKernelGGL(k_find<true>, dim3(g), dim3(256), lds, st, a);
   else hipLaunchKernelGGL(k_find<false>, dim3(g), dim3(256), lds, st, a);
 }
 
-void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid, hipStream_t st) {
+void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid32, unsigned grid64, hipStream_t st) {
   if (a.read_end <= a.read_begin) return;
-  if (wide) hipLaunchKernelGGL(k_filter_extract_fast<true>, dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k_filter_extract_fast<false>, dim3(grid), dim3(256), 0, st, a);
+  if (wide) {
+    hipLaunchKernelGGL((k_filter_extract_fast<true, 32>), dim3(grid32), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_filter_extract_fast<true, 64>), dim3(grid64), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((k_filter_extract_fast<false, 32>), dim3(grid32), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_filter_extract_fast<false, 64>), dim3(grid64), dim3(256), 0, st, a);
+  }
 }
 
 unsigned long long fast_pool_entries_per_wave() { return FX_WPOOL; }
