@@ -19,18 +19,20 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_libsigax(force=False, verbose=False):
+def build_libsigax(force=False, verbose=False, out=None, defines=()):
+    """out/defines: build a variant (tests use -DSIGAX_SUPER_SHIFT=12 to exercise the multi-superblock path)."""
+    lib = out or LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    if not force and not _stale(LIB, deps):
-        return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    if not force and not _stale(lib, deps):
+        return lib
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "-Wno-unused-value",
-           "-I" + os.path.join(ROOT, "include"), "-o", LIB] + srcs
+           "-I" + os.path.join(ROOT, "include"), "-o", lib] + ["-D" + d for d in defines] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 HOST = os.path.join(HERE, "host")

@@ -23,7 +23,9 @@
 
 #define SIGAX_GRANULE_SYMS 128
 #define SIGAX_GRANULE_BYTES 64
-#define SIGAX_SUPER_SHIFT 32  /* wide mode: u64 counters every 2^32 symbols */
+#ifndef SIGAX_SUPER_SHIFT
+#define SIGAX_SUPER_SHIFT 32  /* wide mode: u64 counters every 2^32 symbols (tests build a variant with a small shift) */
+#endif
 
 /* AlignFlags of the four finds of OverlapBuilder::overlap (src/overlap_builder.cpp:52-55,1124-1132), by chain:
  * 0 seq on fmi (SuffixPrefix 000), 1 revcomp(seq) on fmi (PrefixPrefix qr,qc = 101b),

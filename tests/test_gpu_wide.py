@@ -1,0 +1,30 @@
+"""64-bit position path (indexes with >= 2^32 symbols: BASELINE configs[4]) on small inputs: SIGAX_FORCE_WIDE=1 selects
+the WIDE kernels, and a library variant built with superblocks every 2^12 symbols exercises the superblock counters.
+Runs the parity suite in a subprocess because the library is chosen at load time."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.fixtures import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_parity(env_extra, select):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-k", select],
+                       cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_wide_kernels_bit_exact():
+    _run_parity({"SIGAX_FORCE_WIDE": "1"}, "occ or toy or rep or dup or corner or kmer")
+
+
+def test_wide_kernels_with_many_superblocks():
+    from siga_amd import build as sbuild
+    lib = sbuild.build_libsigax(out=os.path.join(ROOT, "build", "libsigax_super12.so"), defines=("SIGAX_SUPER_SHIFT=12",))
+    _run_parity({"SIGAX_FORCE_WIDE": "1", "SIGAX_LIB": lib}, "occ or toy or rep or dup or tiny or kmer")
