@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU restatement (0 = skip)")
     ap.add_argument("--workdir", default=None)
+    ap.add_argument("--subbatches", type=int, default=0,
+                    help="sub-batches per step (0 = library default: 4 at this size; their find and filter/extract kernels overlap)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow on fewer GPUs than ranks (edge records gathered via host)")
     args = ap.parse_args()
@@ -126,6 +128,8 @@ def main():
 
     stats = _lib.Stats()
     kms = (C.c_float * 5)()
+    nsub = C.c_uint32(1)
+    assert lib.sigax_batch_set_subbatches(batch, args.subbatches) == 0, _lib.last_error()
 
     def step():
         rc = lib.sigax_batch_run(batch, lo, args.min_overlap, flags, sptr)
@@ -154,7 +158,7 @@ def main():
     total_edges = 0
     for _ in range(args.steps):
         total_edges = step()
-        lib.sigax_batch_kernel_ms(batch, C.byref(kms))  # HIP events recorded on the run's stream
+        lib.sigax_batch_kernel_ms(batch, C.byref(kms), C.byref(nsub))  # HIP events on the streams the kernels run on
         ksum += np.array(list(kms))
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -164,8 +168,20 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kavg = ksum / max(args.steps, 1)
+    kavg = ksum / max(args.steps, 1)  # per step, summed over the step's sub-batch launches
     st = stats.as_dict()
+    launches = int(nsub.value)
+
+    # the same kernels with sub-batching off (no overlap between find and filter/extract): untimed extra steps
+    iso = None
+    if launches > 1:
+        assert lib.sigax_batch_set_subbatches(batch, 1) == 0
+        isum = np.zeros(5)
+        for _ in range(2):
+            step()
+            lib.sigax_batch_kernel_ms(batch, C.byref(kms), C.byref(nsub))
+            isum += np.array(list(kms))
+        iso = isum / 2
 
     out = None
     if rank == 0:
@@ -174,8 +190,9 @@ def main():
         n_occ = st["n_occ_find"] + st["n_occ_extract"]
         bytes_find = 64 * st["n_occ_find"] + n_local * L + 64 * st["n_candidate_blocks"]
         bytes_read = (64 * n_occ + n_local * L + 64 * st["n_blocks"]) / max(n_local, 1)
-        find_ms = float(kavg[0])
-        achieved = bytes_find / (find_ms * 1e-3) / 1e9 if find_ms > 0 else 0.0
+        find_ms = float(kavg[0]) / launches          # average duration of one k_find launch in the timed region
+        bytes_launch = bytes_find / launches
+        achieved = bytes_launch / (find_ms * 1e-3) / 1e9 if find_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -195,12 +212,21 @@ def main():
                        "reads_per_gpu": n_local, "edges": total_edges, "blocks_per_read": st["n_blocks"] / max(n_local, 1),
                        "n_occ_min_per_read": n_occ / max(n_local, 1), "algorithmic_bytes_per_read": bytes_read,
                        "slow_path_reads": st["n_slow_reads"]},
-            "kernel_ms": {k: float(v) for k, v in zip(KERNELS, kavg)},
+            "kernel_ms_per_step": {k: float(v) for k, v in zip(KERNELS, kavg)},
+            "launches_per_step": launches,
             "roofline": {"bound": "hbm", "kernel": "k_find", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_find, "avg_launch_ms": find_ms,
-                         "whole_path_achieved": bytes_read * n_local / (float(kavg.sum()) * 1e-3) / 1e9 if kavg.sum() > 0 else 0.0},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic / launches if traffic else None,
+                         "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": find_ms,
+                         "note": "launch durations in the timed region, where sub-batch i+1's k_find runs beside "
+                                 "sub-batch i's filter/extract kernels" if launches > 1 else "kernels run back to back",
+                         "whole_path_achieved": bytes_read * n_local / (elapsed / args.steps) / 1e9},
         }
+        if iso is not None:
+            ims = float(iso[0])
+            out["roofline"]["isolated"] = {
+                "what": "same kernels, sub-batching off (one launch per step, nothing beside it), 2 untimed steps",
+                "k_find_ms": ims, "achieved": bytes_find / (ims * 1e-3) / 1e9, "frac": bytes_find / (ims * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "kernel_ms_per_step": {k: float(v) for k, v in zip(KERNELS, iso)}}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(prefix, reads, min(args.cpu_sample, n_total), args.min_overlap, st, lib, batch)
 

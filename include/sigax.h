@@ -127,6 +127,9 @@ int  sigax_batch_upload(sigax_batch*, const char* seqs, const uint64_t* offs, ui
 /* Use reads that already sit in device memory (d_seqs bytes, d_offs u64[n_reads+1]); max_len = longest read. */
 int  sigax_batch_set_device_reads(sigax_batch*, const void* d_seqs, const void* d_offs, uint32_t n_reads,
                                   uint64_t n_bases, uint32_t max_len);
+/* How many sub-batches a run is cut into (0 = automatic).  With more than one, sub-batch i's filter/extract kernels run on
+ * an internal stream beside sub-batch i+1's block finder (the first is VALU-bound, the second memory-request-bound). */
+int  sigax_batch_set_subbatches(sigax_batch*, uint32_t n);
 /* Enqueue the whole path on `stream`: find -> filter/extract -> order -> edges.  Asynchronous. */
 int  sigax_batch_run(sigax_batch*, uint32_t read_base, uint32_t min_overlap, uint32_t flags, void* stream);
 /* Wait for the stream, check arena overflow flags (growing arenas and re-running if needed), fill stats. */
@@ -135,9 +138,10 @@ int  sigax_batch_finish(sigax_batch*, void* stream, sigax_stats* stats);
 int  sigax_batch_device_outputs(sigax_batch*, const sigax_block** d_blocks, const uint64_t** d_block_offs,
                                 const uint8_t** d_substring, const sigax_edge** d_edges);
 int  sigax_batch_download(sigax_batch*, sigax_result* out);
-/* Device time of each kernel of the last finished run, measured with HIP events on the run's stream:
- * ms[0] find, ms[1] filter/extract (fast), ms[2] filter/extract (general), ms[3] order, ms[4] edges. */
-int  sigax_batch_kernel_ms(sigax_batch*, float ms[5]);
+/* Device time of the kernels of the last finished run, measured with HIP events on the streams they were launched on,
+ * summed over the run's sub-batch launches: ms[0] find, ms[1] filter/extract (32- and 64-lane launches),
+ * ms[2] filter/extract (general), ms[3] order, ms[4] edges.  *n_sub = launches per kernel (sub-batches). */
+int  sigax_batch_kernel_ms(sigax_batch*, float ms[5], uint32_t* n_sub);
 
 #ifdef __cplusplus
 }

@@ -43,7 +43,7 @@ SYMBOLS = [
     "sigax_last_error", "sigax_device_count", "sigax_index_open", "sigax_index_open_mem", "sigax_index_close",
     "sigax_index_info_get", "sigax_index_set_reads", "sigax_occ_batch", "sigax_kmer_count_batch",
     "sigax_overlap_batch", "sigax_result_free", "sigax_batch_create", "sigax_batch_destroy", "sigax_batch_upload",
-    "sigax_batch_set_device_reads", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
+    "sigax_batch_set_device_reads", "sigax_batch_set_subbatches", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
     "sigax_batch_download", "sigax_batch_kernel_ms",
 ]
 
@@ -84,7 +84,8 @@ def lib():
     L.sigax_batch_finish.argtypes = [vp, vp, C.POINTER(Stats)]
     L.sigax_batch_device_outputs.argtypes = [vp, pvp, pvp, pvp, pvp]
     L.sigax_batch_download.argtypes = [vp, C.POINTER(Result)]
-    L.sigax_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 5)]
+    L.sigax_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 5), C.POINTER(C.c_uint32)]
+    L.sigax_batch_set_subbatches.argtypes = [vp, u32]
     _lib = L
     return L
 

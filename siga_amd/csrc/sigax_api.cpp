@@ -377,6 +377,7 @@ struct sigax_batch {
   hipEvent_t sev[SIGAX_MAX_SUB][SV_COUNT];
   hipStream_t s_find, s_fx;  // internal pipeline: sub-batch i's filter/extract overlaps sub-batch i+1's find
   unsigned nsub;
+  unsigned nsub_req;  // 0 = automatic
   sigax_stats last;
   u64 last_total_blocks, last_total_edges;
   bool finished;
@@ -429,6 +430,7 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
     for (int j = 0; j < SV_COUNT; ++j) b->sev[i][j] = nullptr;
   b->s_find = b->s_fx = nullptr;
   b->nsub = 1;
+  b->nsub_req = 0;
   {
     hipError_t e = hipSuccess;
     for (int i = 0; i < EV_COUNT && e == hipSuccess; ++i) e = hipEventCreate(&b->ev[i]);
@@ -548,7 +550,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   // Sub-batches: the finder is bound by the memory system's request rate, filter/extract by VALU issue; running
   // sub-batch i's filter/extract while sub-batch i+1's finder runs overlaps the two.
   static const char* env_sub = getenv("SIGAX_SUBBATCHES");
-  unsigned nsub = env_sub ? (unsigned)atoi(env_sub) : (n >= 4 * 131072u ? 4u : n >= 2 * 131072u ? 2u : 1u);
+  unsigned nsub = b->nsub_req ? b->nsub_req : env_sub ? (unsigned)atoi(env_sub) : (n >= 4 * 131072u ? 4u : n >= 2 * 131072u ? 2u : 1u);
   if (nsub < 1) nsub = 1;
   if (nsub > SIGAX_MAX_SUB) nsub = SIGAX_MAX_SUB;
   b->nsub = nsub;
@@ -777,9 +779,17 @@ extern "C" int sigax_batch_download(sigax_batch* b, sigax_result* out) {
   return SIGAX_OK;
 }
 
-extern "C" int sigax_batch_kernel_ms(sigax_batch* b, float ms[5]) {
+extern "C" int sigax_batch_set_subbatches(sigax_batch* b, uint32_t n) {
+  if (!b) return fail(SIGAX_E_ARG, "NULL batch");
+  if (n > SIGAX_MAX_SUB) return fail(SIGAX_E_ARG, "at most %d sub-batches", SIGAX_MAX_SUB);
+  b->nsub_req = n;
+  return SIGAX_OK;
+}
+
+extern "C" int sigax_batch_kernel_ms(sigax_batch* b, float ms[5], uint32_t* n_sub) {
   if (!b || !ms) return fail(SIGAX_E_ARG, "NULL argument");
   if (!b->finished) return fail(SIGAX_E_STATE, "batch not finished");
+  if (n_sub) *n_sub = b->nsub;
   for (int i = 0; i < 5; ++i) ms[i] = 0.f;
   for (unsigned i = 0; i < b->nsub; ++i) {  // sums over the sub-batch launches (which overlap across the two streams)
     float t = 0.f;
