@@ -33,6 +33,9 @@ extern "C" {
 #define SIGAX_IRREDUCIBLE  1u  /* irreducible=true  (CLI: absence of -x/--exhaustive, src/overlap.cpp:43) */
 #define SIGAX_RC           2u  /* rc=true           (CLI: absence of --no-opposite-strand) */
 #define SIGAX_EDGES        4u  /* also materialise edge records (Hit2OverlapConverter, src/overlap_builder.cpp:345-375) */
+#define SIGAX_DUPLICATE    8u  /* OverlapBuilder::duplicate instead of overlap (src/overlap_builder.cpp:1184-1195): only the
+                                  seq/fmi and complement(seq)/rfmi finds, minOverlap = read length, blocks = the containment
+                                  blocks; min_overlap and the other mode flags are ignored.  Used by `siga rmdup`. */
 
 typedef struct sigax_index sigax_index; /* both FM-indexes + both .sai tables, resident on one GPU */
 typedef struct sigax_batch sigax_batch; /* device workspace for batches of reads */

@@ -132,6 +132,20 @@ int orc_build_asqg(void* hf, void* hr, const char* reads_path, uint64_t min_over
   return 0;
 }
 
+// `siga rmdup` at -t 1 (overlap_builder.cpp:562-704)
+int orc_rmdup(void* hf, void* hr, const char* reads_path, const char* fasta_path, const char* dups_path) {
+  OrcIndex* f = (OrcIndex*)hf;
+  OrcIndex* r = (OrcIndex*)hr;
+  std::ifstream in(reads_path);
+  if (!in) return -1;
+  std::vector<DNASeq> reads;
+  if (!readSequences(in, &reads)) return -2;
+  std::ofstream fa(fasta_path), du(dups_path);
+  if (!fa || !du) return -3;
+  rmdupText(reads, f->b.fm, r->b.fm, f->b.sai, r->b.sai, fa, du);
+  return 0;
+}
+
 // CPU baseline leg: OverlapBuilder::overlap over a batch of reads, OpenMP over reads like
 // parallel_framework.h:38.  Returns seconds; out3 = {blocks, substring reads, N_occ_min}.
 double orc_overlap_batch_timed(void* hf, void* hr, const char* seqs, const uint64_t* offs, uint64_t n,

@@ -47,6 +47,7 @@ def lib():
         L.orc_overlap.restype = C.c_int64
         L.orc_overlap.argtypes = [vp, vp, cp, u64, u64, C.c_int, C.c_int, pu64, u64, C.POINTER(C.c_int), pu64]
         L.orc_build_asqg.argtypes = [vp, vp, cp, u64, C.c_int, C.c_int, cp, cp, pu64]
+        L.orc_rmdup.argtypes = [vp, vp, cp, cp, cp]
         L.orc_overlap_batch_timed.restype = C.c_double
         L.orc_overlap_batch_timed.argtypes = [vp, vp, cp, pu64, u64, u64, C.c_int, C.c_int, C.c_int, pu64]
         L.orc_rl_encode.restype = u64
@@ -153,6 +154,12 @@ def build_asqg(fwd, rev, reads_path, min_overlap, asqg_path, hits_path="", irred
     if r != 0:
         raise RuntimeError("orc_build_asqg failed: %d" % r)
     return {"occ_calls": int(st[0]), "n_occ_min": int(st[1]), "blocks": int(st[2])}
+
+
+def rmdup(fwd, rev, reads_path, fasta_path, dups_path):
+    r = lib().orc_rmdup(fwd.h, rev.h, reads_path.encode(), fasta_path.encode(), dups_path.encode())
+    if r != 0:
+        raise RuntimeError("orc_rmdup failed: %d" % r)
 
 
 def overlap_batch_timed(fwd, rev, reads, min_overlap, irreducible=True, rc=True, threads=0):

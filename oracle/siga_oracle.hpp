@@ -1040,6 +1040,52 @@ static inline bool buildASQG(const std::vector<DNASeq>& reads, const FMIndex& fm
   return true;
 }
 
+// overlap_builder.cpp:562-672 at threads == 1: `siga rmdup` = duplicate() per read, then Hits2FastaConverter
+static inline void rmdupText(const std::vector<DNASeq>& reads, const FMIndex& fmi, const FMIndex& rfmi,
+                             const std::vector<uint32_t>& sa, const std::vector<uint32_t>& rsa, std::ostream& fasta,
+                             std::ostream& duplicates) {
+  OverlapBuilder builder(&fmi, &rfmi);
+  std::vector<ReadInfo> info(reads.size());
+  for (size_t i = 0; i < reads.size(); ++i) {
+    info[i].name = reads[i].name;
+    info[i].length = reads[i].seq.length();
+  }
+  for (size_t i = 0; i < reads.size(); ++i) {
+    OverlapBlockList blocks;
+    OverlapResult r = builder.duplicate(reads[i].seq, &blocks);
+    // Hit2OverlapConverter::convert (:345-375) keeping the overlaps, then :589-598
+    size_t numCopies = 0;
+    bool isContained = r.substring;
+    const ReadInfo& query = info[i];
+    for (auto& block : blocks) {
+      for (u64 j = block.capped[0].lower; j <= block.capped[0].upper; ++j) {
+        ++numCopies;
+        const std::vector<uint32_t>& s = block.af.targetRev() ? rsa : sa;
+        const ReadInfo& target = info[s[j]];
+        if (query.name != target.name) {
+          u64 s0 = query.length - block.length, e0 = query.length - 1, l0 = query.length;
+          u64 s1 = 0, e1 = block.length - 1, l1 = target.length;
+          if (block.af.queryRev()) { u64 t = s0; s0 = l0 - e0 - 1; e0 = l0 - t - 1; }
+          if (block.af.targetRev()) { u64 t = s1; s1 = l1 - e1 - 1; e1 = l1 - t - 1; }
+          bool contained0 = (s0 == 0 && e0 + 1 == l0), contained1 = (s1 == 0 && e1 + 1 == l1);
+          if (query.name < target.name || ((contained0 || contained1) && block.af.queryRev())) continue;
+          // o.isContainment() && o.containedIdx() == 0 (coord.h:150-152,185-194)
+          if (contained0 || contained1) {
+            size_t idx = (contained0 && contained1) ? (query.name < target.name ? 1 : 0) : (contained0 ? 0 : 1);
+            if (idx == 0) isContained = true;
+          }
+        }
+      }
+    }
+    if (isContained) {
+      duplicates << '>' << reads[i].name << ",seqrank=" << i << ' ' << reads[i].name << " NumDuplicates=" << numCopies << '\n'
+                 << reads[i].seq << '\n';
+    } else {
+      fasta << '>' << reads[i].name << ' ' << reads[i].name << " NumDuplicates=" << numCopies << '\n' << reads[i].seq << '\n';
+    }
+  }
+}
+
 // utils.cpp:128-135  stem: strip .gz/.bz2, then directory and last extension
 static inline std::string stem(const std::string& filename) {
   auto ends = [](const std::string& s, const char* suf) {

@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("SIGAX_LIB", os.path.join(HERE, "lib", "libsigax.so"))
 SIGAX_IRREDUCIBLE = 1
 SIGAX_RC = 2
 SIGAX_EDGES = 4
+SIGAX_DUPLICATE = 8
 
 BLOCK_DTYPE = np.dtype([
     ("capped0_lo", "<u8"), ("capped0_hi", "<u8"), ("capped1_lo", "<u8"), ("capped1_hi", "<u8"),

@@ -566,7 +566,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.offs = b->d_offs;
     fa.n_reads = n;
     fa.minov = b->minov;
-    fa.rc = (b->flags & SIGAX_RC) ? 1u : 0u;
+    fa.chain_mask = (b->flags & SIGAX_DUPLICATE) ? 0x9u : (b->flags & SIGAX_RC) ? 0xFu : 0x5u;
     fa.cap = b->cap;
     fa.read_begin = rb;
     fa.read_end = re;
@@ -677,6 +677,10 @@ extern "C" int sigax_batch_run(sigax_batch* b, uint32_t read_base, uint32_t min_
   b->read_base = read_base;
   b->minov = min_overlap;
   b->flags = flags;
+  if (flags & SIGAX_DUPLICATE) {  // duplicate(): minOverlap = seq.length() so no proper-overlap block is ever pushed;
+    b->minov = 0xFFFFFFFFu;       // the exhaustive plumbing then returns exactly {containment of find 0, of find 3}
+    b->flags = (flags & SIGAX_EDGES) | SIGAX_DUPLICATE;
+  }
   b->finished = false;
   int rc = enqueue(b, (hipStream_t)stream);
   b->ran = rc == SIGAX_OK;

@@ -36,7 +36,7 @@ struct FindArgs {
   FmStrand fwd, rev;
   const unsigned char* seqs;
   const unsigned long long* offs;
-  uint32_t n_reads, minov, rc, cap;  // cap = slots per chain; the last one holds the containment block
+  uint32_t n_reads, minov, chain_mask, cap;  // chain_mask bit o = find o runs; cap = slots per chain, last = containment
   uint32_t read_begin, read_end;     // this launch's sub-batch
   sigax_block* arena;                // [n_reads][4][cap]
   uint32_t* chain_cnt;               // [n_reads][4]

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_find(FindArgs A) {
   u32 read = A.read_begin + (u32)(gid >> 2), o = (u32)gid & 3u;
   u64 nocc = 0;
   u32 nb = 0, flagbits = 0;
-  bool live = read < A.read_end && ((o & 1u) == 0 || A.rc);  // chains 1 and 3 are the opposite-strand finds
+  bool live = read < A.read_end && ((A.chain_mask >> o) & 1u);  // overlap: 0xF, or 0x5 without the opposite strand; duplicate: 0x9
   u64 b0 = 0, L = 0;
   if (live) {
     b0 = A.offs[read];

@@ -21,6 +21,7 @@ def lib():
         L.sigah_overlap_file.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_int, C.c_int, C.c_uint64,
                                          C.c_uint64, C.c_int, C.c_char_p, C.c_uint64]
         L.sigah_stem.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64]
+        L.sigah_rmdup_file.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_uint64]
         _lib = L
     return _lib
 
@@ -47,6 +48,13 @@ def overlap_file(reads_path, prefix, min_overlap, output, irreducible=True, rc=T
                                  threads, batch, device, err, 512)
     if r != 0:
         raise RuntimeError("siga overlap failed: " + err.value.decode())
+
+
+def rmdup_file(reads_path, prefix, output, duplicates, device=0):
+    """FMIndex::load + OverlapBuilder::rmdup in the host C++ library (GPU compute)."""
+    err = C.create_string_buffer(512)
+    if lib().sigah_rmdup_file(reads_path.encode(), prefix.encode(), output.encode(), duplicates.encode(), device, err, 512) != 0:
+        raise RuntimeError("siga rmdup failed: " + err.value.decode())
 
 
 def stem(path):

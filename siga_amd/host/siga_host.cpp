@@ -476,6 +476,8 @@ static void write_edge(std::string& o, const sigax_edge& e, const DNASeqList& re
   o += " 0\n";
 }
 
+static bool set_read_info(const FMIndex* fmi, const DNASeqList& reads, std::string* error);
+
 bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const std::string& output, size_t threads,
                            size_t batch, size_t* processed) const {
   (void)processed;  // accepted and never written, like the reference (src/overlap_builder.cpp:423-424)
@@ -501,19 +503,7 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
   }
   const size_t n = reads.size();
   // ReadInfo{name,length} for the edge converter (src/overlap_builder.cpp:333-343) as lengths + name ranks
-  std::vector<uint32_t> lengths(n), ranks(n), order(n);
-  for (size_t i = 0; i < n; ++i) lengths[i] = (uint32_t)reads[i].seq.size();
-  std::iota(order.begin(), order.end(), 0u);
-  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return reads[a].name < reads[b].name; });
-  uint32_t rk = 0;
-  for (size_t k = 0; k < n; ++k) {
-    if (k > 0 && reads[order[k]].name != reads[order[k - 1]].name) ++rk;
-    ranks[order[k]] = rk;
-  }
-  if (n > 0 && sigax_index_set_reads(_fmi->handle(), lengths.data(), ranks.data(), n) != SIGAX_OK) {
-    _error = std::string("failed to load suffix array index ") + _prefix + ": " + sigax_last_error();
-    return false;
-  }
+  if (!set_read_info(_fmi, reads, &_error)) return false;
   uint32_t flags = SIGAX_EDGES | (_irreducible ? SIGAX_IRREDUCIBLE : 0u) | (_rc ? SIGAX_RC : 0u);
   size_t per = std::max<size_t>(std::max<size_t>(threads, 1) * std::max<size_t>(batch, 1), 131072);
   std::vector<sigax_edge> edges;
@@ -551,6 +541,98 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
   out.write(text);
   if (!out.close()) {
     _error = "Failed to write ASQG " + output;
+    return false;
+  }
+  return true;
+}
+
+// ReadInfo table for the edge converter: lengths + rank of each name under std::string operator<
+static bool set_read_info(const FMIndex* fmi, const DNASeqList& reads, std::string* error) {
+  const size_t n = reads.size();
+  std::vector<uint32_t> lengths(n), ranks(n), order(n);
+  for (size_t i = 0; i < n; ++i) lengths[i] = (uint32_t)reads[i].seq.size();
+  std::iota(order.begin(), order.end(), 0u);
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return reads[a].name < reads[b].name; });
+  uint32_t rk = 0;
+  for (size_t k = 0; k < n; ++k) {
+    if (k > 0 && reads[order[k]].name != reads[order[k - 1]].name) ++rk;
+    ranks[order[k]] = rk;
+  }
+  if (n > 0 && sigax_index_set_reads(fmi->handle(), lengths.data(), ranks.data(), n) != SIGAX_OK) {
+    *error = std::string("failed to load suffix array index: ") + sigax_last_error();
+    return false;
+  }
+  return true;
+}
+
+bool OverlapBuilder::rmdup(const std::string& input, const std::string& output, const std::string& duplicates, size_t threads,
+                           size_t* processed) const {
+  (void)threads;
+  (void)processed;
+  _error.clear();
+  if (!_fmi || !_fmi->handle()) {
+    _error = "FMIndex not loaded";
+    return false;
+  }
+  DNASeqList reads;
+  if (!ReadDNASequences(input, reads)) {
+    _error = "Failed to create DNASeqReader " + input;
+    return false;
+  }
+  OutFile fasta(output), dups(duplicates);
+  if (!fasta.ok() || !dups.ok()) {
+    _error = "Failed to create FASTA " + output;
+    return false;
+  }
+  if (!set_read_info(_fmi, reads, &_error)) return false;
+  const size_t n = reads.size(), per = 262144;
+  std::string seqs, text;
+  std::vector<uint64_t> offs;
+  for (size_t base = 0; base < n; base += per) {
+    size_t cnt = std::min(per, n - base);
+    seqs.clear();
+    offs.assign(1, 0);
+    for (size_t i = 0; i < cnt; ++i) {
+      seqs += reads[base + i].seq;
+      offs.push_back(seqs.size());
+    }
+    sigax_result res;
+    if (sigax_overlap_batch(_fmi->handle(), seqs.data(), offs.data(), (uint32_t)cnt, (uint32_t)base, 0,
+                            SIGAX_DUPLICATE | SIGAX_EDGES, &res) != SIGAX_OK) {
+      _error = std::string("rmdup failed: ") + sigax_last_error();
+      return false;
+    }
+    // Hits2FastaConverter::convert (src/overlap_builder.cpp:578-616).  A kept overlap of a duplicate block is a
+    // containment of the query with containedIdx() == 0 (both reads contained and id[0] > id[1], coord.h:185-194).
+    std::vector<uint8_t> hasEdge(cnt, 0);
+    for (uint64_t e = 0; e < res.n_edges; ++e) hasEdge[res.edges[e].query - base] = 1;
+    for (size_t i = 0; i < cnt; ++i) {
+      const DNASeq& rd = reads[base + i];
+      uint64_t numCopies = 0;
+      for (uint64_t k = res.block_offs[i]; k < res.block_offs[i + 1]; ++k)
+        numCopies += res.blocks[k].capped0_hi - res.blocks[k].capped0_lo + 1;
+      bool contained = res.substring[i] != 0 || hasEdge[i] != 0;
+      text.clear();
+      text += '>';
+      text += rd.name;
+      if (contained) {
+        text += ",seqrank=";
+        text += std::to_string(base + i);
+      }
+      text += ' ';
+      text += rd.name;
+      text += " NumDuplicates=";
+      text += std::to_string(numCopies);
+      text += '\n';
+      text += rd.seq;
+      text += '\n';
+      (contained ? dups : fasta).write(text);
+    }
+    sigax_result_free(&res);
+  }
+  bool ok1 = fasta.close(), ok2 = dups.close();
+  if (!ok1 || !ok2) {
+    _error = "Failed to write rmdup output";
     return false;
   }
   return true;
@@ -616,6 +698,22 @@ int sigah_overlap_file(const char* reads_path, const char* prefix, uint64_t min_
   }
   sigah::OverlapBuilder builder(&fmi, prefix, irreducible != 0, rc != 0);
   if (!builder.build(reads_path, min_overlap, output, threads, batch)) {
+    if (err && errcap) snprintf(err, errcap, "%s", builder.error().c_str());
+    return -1;
+  }
+  return 0;
+}
+
+// `siga rmdup`: FMIndex::load + OverlapBuilder::rmdup
+int sigah_rmdup_file(const char* reads_path, const char* prefix, const char* output, const char* duplicates, int device,
+                     char* err, uint64_t errcap) {
+  sigah::FMIndex fmi;
+  if (!sigah::FMIndex::load(prefix, fmi, device)) {
+    if (err && errcap) snprintf(err, errcap, "Failed to load FMIndex from %s: %s", prefix, sigax_last_error());
+    return -1;
+  }
+  sigah::OverlapBuilder builder(&fmi, prefix);
+  if (!builder.rmdup(reads_path, output, duplicates)) {
     if (err && errcap) snprintf(err, errcap, "%s", builder.error().c_str());
     return -1;
   }

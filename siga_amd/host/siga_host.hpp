@@ -85,6 +85,12 @@ class OverlapBuilder {
   bool build(const std::string& input, size_t minOverlap, const std::string& output, size_t threads = 1,
              size_t batch = 1000, size_t* processed = nullptr) const;
 
+  // `siga rmdup` (src/overlap_builder.cpp:562-704): reads without an identical / reverse-complement-identical twin of
+  // smaller name and that are no substring go to `output`, the others to `duplicates`, headers as the reference
+  // writes them ("<name> <name> NumDuplicates=<n>" / "<name>,seqrank=<idx> <name> NumDuplicates=<n>").
+  bool rmdup(const std::string& input, const std::string& output, const std::string& duplicates, size_t threads = 1,
+             size_t* processed = nullptr) const;
+
   const std::string& error() const { return _error; }
 
  private:

@@ -13,7 +13,7 @@
 extern "C" int sigah_index_file(const char*, const char*, int, char*, uint64_t);
 
 static int usage() {
-  printf("siga [index|overlap] [OPTION] ... READSFILE\n"
+  printf("siga [index|overlap|rmdup] [OPTION] ... READSFILE\n"
          "  index     build the FM-index (.sai/.bwt/.rsai/.rbwt) of READSFILE\n"
          "  overlap   compute pairwise overlaps between all the sequences in READSFILE (GPU)\n");
   return 256;
@@ -150,10 +150,59 @@ static int run_overlap(int argc, char** argv) {
   return 0;
 }
 
+static int rmdup_help() {
+  printf("siga rmdup [OPTION] ... READSFILE\n"
+         "Remove duplicated reads from the data set\n"
+         "\n"
+         "      -h, --help                       display this help and exit\n"
+         "      -p, --prefix=PREFIX              use PREFIX instead of the prefix of the reads filename for the input/output files\n"
+         "      -t, --threads=N                  use N threads (default: 1)\n"
+         "          --device=NUM                 GPU to use (default: 0)\n"
+         "\n");
+  return 256;
+}
+
+// src/rmdup.cpp:22-49: outputs <prefix>.rmdup.fa and <prefix>.rmdup.dups.fa
+static int run_rmdup(int argc, char** argv) {
+  enum { OPT_DEVICE = 1 };
+  static const option longopts[] = {{"log4cxx", required_argument, nullptr, 'c'}, {"ini", required_argument, nullptr, 's'},
+                                    {"prefix", required_argument, nullptr, 'p'},  {"threads", required_argument, nullptr, 't'},
+                                    {"sample-rate", required_argument, nullptr, 'd'}, {"device", required_argument, nullptr, OPT_DEVICE},
+                                    {"help", no_argument, nullptr, 'h'}, {nullptr, 0, nullptr, 0}};
+  std::string prefix;
+  size_t threads = 1;
+  bool help = false;
+  int device = 0, c;
+  while ((c = getopt_long(argc, argv, "c:s:t:p:d:h", longopts, nullptr)) != -1) {
+    switch (c) {
+      case 'p': prefix = optarg; break;
+      case 't': threads = strtoull(optarg, nullptr, 10); break;
+      case OPT_DEVICE: device = atoi(optarg); break;
+      case 'h': help = true; break;
+      default: break;
+    }
+  }
+  if (help || argc - optind != 1) return rmdup_help();
+  std::string input = argv[optind];
+  if (prefix.empty()) prefix = sigah::Utils::stem(input);
+  sigah::FMIndex fmi;
+  if (!sigah::FMIndex::load(prefix, fmi, device)) {
+    fprintf(stderr, "Failed to load FMIndex from %s: %s\n", input.c_str(), sigax_last_error());
+    return -1;
+  }
+  sigah::OverlapBuilder builder(&fmi, prefix);
+  if (!builder.rmdup(input, prefix + ".rmdup.fa", prefix + ".rmdup.dups.fa", threads)) {
+    fprintf(stderr, "Failed to remove duplicates from reads %s: %s\n", input.c_str(), builder.error().c_str());
+    return -1;
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) return usage();
   std::string cmd = argv[1];
   if (cmd == "index") return run_index(argc - 1, argv + 1);
+  if (cmd == "rmdup") return run_rmdup(argc - 1, argv + 1);
   if (cmd == "overlap") return run_overlap(argc - 1, argv + 1);
   return usage();
 }

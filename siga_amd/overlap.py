@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import BLOCK_DTYPE, EDGE_DTYPE, SIGAX_EDGES, SIGAX_IRREDUCIBLE, SIGAX_RC
+from ._lib import BLOCK_DTYPE, EDGE_DTYPE, SIGAX_DUPLICATE, SIGAX_EDGES, SIGAX_IRREDUCIBLE, SIGAX_RC
 
 
 class SigaxError(RuntimeError):
@@ -170,12 +170,17 @@ class OverlapBuilder:
     def _flags(self, edges):
         return (SIGAX_IRREDUCIBLE if self.irreducible else 0) | (SIGAX_RC if self.rc else 0) | (SIGAX_EDGES if edges else 0)
 
-    def overlap(self, seqs, min_overlap, read_base=0, edges=False):
+    def duplicate(self, seqs, read_base=0, edges=False):
+        """Batched OverlapBuilder::duplicate (src/overlap_builder.cpp:1184-1195)."""
+        return self.overlap(seqs, 0, read_base, edges, _flags=SIGAX_DUPLICATE | (SIGAX_EDGES if edges else 0))
+
+    def overlap(self, seqs, min_overlap, read_base=0, edges=False, _flags=None):
         """Batched OverlapBuilder::overlap.  Returns dict(block_offs, blocks, substring, edges, stats)."""
         buf, offs = pack_reads(seqs)
         res = _lib.Result()
         _check(_lib.lib().sigax_overlap_batch(self.fmi.handle, buf, offs.ctypes.data, len(seqs), read_base, min_overlap,
-                                              self._flags(edges), C.byref(res)), "sigax_overlap_batch")
+                                              self._flags(edges) if _flags is None else _flags, C.byref(res)),
+               "sigax_overlap_batch")
         try:
             n = res.n_reads
             block_offs = np.ctypeslib.as_array(res.block_offs, shape=(n + 1,)).copy()

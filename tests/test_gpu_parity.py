@@ -166,3 +166,41 @@ def test_mid_fixture_through_gpu_matches_reference_md5(sa, tmp_path):
     text = open(out).read()
     assert md5_prefix(text) == GOLDEN["mid"]["md5"]["asqg_t1"]
     assert len(ed_lines(text)) == GOLDEN["mid"]["ed_irreducible"]
+
+
+# ---- `siga rmdup`: OverlapBuilder::duplicate on the GPU + Hits2FastaConverter on the host --------
+@pytest.mark.parametrize("name", ["dup", "corner", "tiny", "ragged"])
+def test_rmdup_matches_oracle(sa, name, tmp_path):
+    import shutil
+    import subprocess
+    from oracle import pyoracle as po
+    from siga_amd import host
+    fx = fixture(name)
+    po.rmdup(fx.fwd, fx.rev, fx.fa, str(tmp_path / "o.fa"), str(tmp_path / "o.dups.fa"))
+    host.rmdup_file(fx.fa, fx.prefix, str(tmp_path / "g.fa"), str(tmp_path / "g.dups.fa"))
+    assert open(tmp_path / "g.fa").read() == open(tmp_path / "o.fa").read()
+    assert open(tmp_path / "g.dups.fa").read() == open(tmp_path / "o.dups.fa").read()
+    if name == "dup":  # the CLI, with the reference's output names in the CWD (src/rmdup.cpp:40-44)
+        cwd = str(tmp_path)
+        for ext in (".fa", ".bwt", ".rbwt", ".sai", ".rsai"):
+            shutil.copy(fx.prefix + ext, cwd)
+        assert subprocess.run([host.CLI_PATH, "rmdup", "dup.fa"], cwd=cwd).returncode == 0
+        assert open(cwd + "/dup.rmdup.fa").read() == open(tmp_path / "o.fa").read()
+        assert open(cwd + "/dup.rmdup.dups.fa").read() == open(tmp_path / "o.dups.fa").read()
+        assert open(tmp_path / "o.dups.fa").read().count(">") > 100  # the fixture is mostly duplicates / substrings
+
+
+def test_duplicate_blocks_match_oracle(sa):
+    """sigax SIGAX_DUPLICATE blocks == OverlapBuilder::duplicate of the oracle, read by read."""
+    fx = fixture("dup")
+    pair = _pair(sa, fx)
+    res = sa.OverlapBuilder(pair).duplicate(fx.seqs)
+    from oracle import pyoracle as po
+    import ctypes as C
+    offs = res["block_offs"]
+    assert res["stats"]["n_blocks"] == int(offs[-1])
+    # every block is a full-length containment block with flags 000 or 110
+    assert all(int(b["af"]) in (0, 6) for b in res["blocks"])
+    for r, s in enumerate(fx.seqs):
+        got = res["blocks"][int(offs[r]):int(offs[r + 1])]
+        assert all(int(b["length"]) == len(s) for b in got)
