@@ -115,6 +115,15 @@ int  sigax_occ_batch(sigax_index*, int which, const uint64_t* positions, uint64_
 /* FMIndex::Interval::occurrences (src/fmindex.h:80-86) for n k-mers of length k on the forward index. */
 int  sigax_kmer_count_batch(sigax_index*, const char* kmers, uint32_t k, uint64_t n, uint64_t* counts);
 
+/* KmerCorrector::process for a batch of reads (src/correct_processor.cpp:72-229, `siga correct -a kmer`).  quals may be
+ * NULL (FASTA input: every base scores 15).  out_seqs has the layout of seqs and receives the corrected sequence of
+ * reads that became all-solid and the unchanged sequence otherwise; valid[r] = CorrectResult::validQC (only those
+ * reads are written by PostCorrector, :242-265).  Parameters as the CLI's -k/-x/-i/-O (defaults 31/3/10/1,
+ * src/correct_processor.h:15-20).  Forward index only, as the reference. */
+int  sigax_correct_batch(sigax_index*, const char* seqs, const char* quals, const uint64_t* offs, uint32_t n_reads,
+                         uint32_t kmer_size, int32_t kmer_threshold, uint32_t kmer_rounds, uint32_t count_offset,
+                         char* out_seqs, uint8_t* valid);
+
 /* OverlapBuilder::overlap for a batch (host buffers in, host buffers out).  seqs = concatenated read bytes,
  * offs[n_reads+1]; read r of the batch is read `read_base + r` of the indexed set (only used for edges).
  * The result is filled with malloc'd arrays; release with sigax_result_free. */

@@ -146,6 +146,34 @@ int orc_rmdup(void* hf, void* hr, const char* reads_path, const char* fasta_path
   return 0;
 }
 
+// `siga correct` (k-mer algorithm) at -t 1: correct_processor.cpp:270-317.  stats2 = {reads written, reads changed}
+int orc_correct(void* hf, const char* reads_path, const char* out_path, uint64_t k, int threshold, uint64_t rounds,
+                uint64_t offset, uint64_t* stats2) {
+  OrcIndex* f = (OrcIndex*)hf;
+  std::ifstream in(reads_path);
+  if (!in) return -1;
+  SeqReader reader(in);
+  if (!reader.ok()) return -2;
+  std::ofstream out(out_path);
+  if (!out) return -3;
+  CorrectParams P;
+  P.kmerSize = k; P.minSupport = threshold; P.maxAttempts = rounds; P.countOffset = offset;
+  DNASeq rd;  // one object reused across reads, as DNASeqWorkItemGenerator does (kseq.h:176-183)
+  uint64_t written = 0, changed = 0;
+  while (reader.read(rd)) {
+    std::string seq;
+    if (correctRead(f->b.fm, P, rd, &seq)) {
+      if (seq != rd.seq) ++changed;
+      DNASeq w = rd;
+      w.seq = seq;
+      writeSeq(out, w);
+      ++written;
+    }
+  }
+  if (stats2) { stats2[0] = written; stats2[1] = changed; }
+  return 0;
+}
+
 // CPU baseline leg: OverlapBuilder::overlap over a batch of reads, OpenMP over reads like
 // parallel_framework.h:38.  Returns seconds; out3 = {blocks, substring reads, N_occ_min}.
 double orc_overlap_batch_timed(void* hf, void* hr, const char* seqs, const uint64_t* offs, uint64_t n,

@@ -48,6 +48,7 @@ def lib():
         L.orc_overlap.argtypes = [vp, vp, cp, u64, u64, C.c_int, C.c_int, pu64, u64, C.POINTER(C.c_int), pu64]
         L.orc_build_asqg.argtypes = [vp, vp, cp, u64, C.c_int, C.c_int, cp, cp, pu64]
         L.orc_rmdup.argtypes = [vp, vp, cp, cp, cp]
+        L.orc_correct.argtypes = [vp, cp, cp, u64, C.c_int, u64, u64, pu64]
         L.orc_overlap_batch_timed.restype = C.c_double
         L.orc_overlap_batch_timed.argtypes = [vp, vp, cp, pu64, u64, u64, C.c_int, C.c_int, C.c_int, pu64]
         L.orc_rl_encode.restype = u64
@@ -160,6 +161,14 @@ def rmdup(fwd, rev, reads_path, fasta_path, dups_path):
     r = lib().orc_rmdup(fwd.h, rev.h, reads_path.encode(), fasta_path.encode(), dups_path.encode())
     if r != 0:
         raise RuntimeError("orc_rmdup failed: %d" % r)
+
+
+def correct(fwd, reads_path, out_path, k=31, threshold=3, rounds=10, offset=1):
+    st = np.zeros(2, dtype=np.uint64)
+    r = lib().orc_correct(fwd.h, reads_path.encode(), out_path.encode(), k, threshold, rounds, offset, _p64(st))
+    if r != 0:
+        raise RuntimeError("orc_correct failed: %d" % r)
+    return {"written": int(st[0]), "changed": int(st[1])}
 
 
 def overlap_batch_timed(fwd, rev, reads, min_overlap, irreducible=True, rc=True, threads=0):

@@ -1086,6 +1086,104 @@ static inline void rmdupText(const std::vector<DNASeq>& reads, const FMIndex& fm
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// `siga correct`, k-mer algorithm: correct_processor.cpp:20-46 (CorrectThreshold), :72-229 (KmerCorrector),
+// :242-265 (PostCorrector: only reads that became all-solid are written, in the input's format).
+// ---------------------------------------------------------------------------------------------
+struct CorrectParams {
+  size_t kmerSize, maxAttempts, countOffset;
+  int minSupport;
+  CorrectParams() : kmerSize(31), maxAttempts(10), countOffset(1), minSupport(3) {}  // correct_processor.h:15-20
+  size_t requiredSupport(int phred) const { return phred >= 20 ? (size_t)(minSupport + 1) : (size_t)minSupport; }
+};
+
+static inline int phredScore(const DNASeq& r, size_t i) {  // kseq.h:34-40, quality.h:12,30-34
+  return r.quality.empty() ? 15 : (int)(uint8_t)r.quality[i] - 33;
+}
+
+static inline bool try2Correct(const FMIndex& index, const CorrectParams& P, size_t baseIdx, size_t kmerIdx, size_t minCount,
+                               std::string& read) {  // correct_processor.cpp:192-224
+  size_t deltaIdx = baseIdx - kmerIdx;
+  char currBase = read[baseIdx];
+  std::string kmer = read.substr(kmerIdx, P.kmerSize);
+  size_t bestCount = 0;
+  char bestBase = '$';
+  static const char DNA[4] = {'A', 'C', 'G', 'T'};
+  for (size_t i = 0; i < 4; ++i) {
+    char c = DNA[i];
+    if (c != currBase) {
+      kmer[deltaIdx] = c;
+      size_t count = Interval::occurrences(kmer, &index);
+      if (count >= minCount) {
+        if (bestBase != '$') return false;
+        bestBase = c;
+        bestCount = count;
+      }
+    }
+  }
+  if (bestCount >= minCount) {
+    read[baseIdx] = bestBase;
+    return true;
+  }
+  return false;
+}
+
+// KmerCorrector::process; returns validQC and the sequence to write
+static inline bool correctRead(const FMIndex& index, const CorrectParams& P, const DNASeq& read, std::string* out) {
+  if (read.seq.length() < P.kmerSize) {
+    *out = read.seq;
+    return false;
+  }
+  std::string seq = read.seq;
+  size_t k = P.kmerSize, n = seq.length();
+  std::vector<int> minPhred(n - k + 1);
+  for (size_t i = k; i <= n; ++i) {
+    int ps = 0x7FFFFFFF;
+    for (size_t j = i - k; j < i; ++j) ps = std::min(ps, phredScore(read, j));
+    minPhred[i - k] = ps;
+  }
+  bool allSolid = false, done = false;
+  size_t rounds = 0;
+  while (!done) {
+    std::vector<int> countVector(n - k + 1, 0);  // never filled by the reference (:113,162,167)
+    std::vector<int> solid(n, 0);
+    for (size_t i = k; i <= n; ++i) {
+      size_t count = Interval::occurrences(seq.substr(i - k, k), &index);
+      if (count >= P.requiredSupport(minPhred[i - k]))
+        for (size_t j = 0; j < k; ++j) solid[i - k + j] = 1;
+    }
+    allSolid = true;
+    for (size_t i = 0; i < n; ++i)
+      if (!solid[i]) allSolid = false;
+    if (allSolid || ++rounds > P.maxAttempts) break;
+    bool corrected = false;
+    for (size_t i = 0; i < n; ++i) {
+      if (!solid[i]) {
+        size_t threshold = P.requiredSupport(phredScore(read, i));
+        size_t leftIdx = (i + 1 >= k ? i + 1 - k : 0);
+        if ((corrected = try2Correct(index, P, i, leftIdx, std::max(countVector[leftIdx] + P.countOffset, threshold), seq))) break;
+        size_t rightIdx = std::min(i, n - k);
+        if ((corrected = try2Correct(index, P, i, rightIdx, std::max(countVector[rightIdx] + P.countOffset, threshold), seq))) break;
+      }
+    }
+    if (!corrected) done = true;
+  }
+  if (allSolid) {
+    *out = seq;
+    return true;
+  }
+  *out = read.seq;
+  return false;
+}
+
+// kseq.cpp:106-126 DNASeq operator<<
+static inline void writeSeq(std::ostream& os, const DNASeq& s) {
+  os << (s.quality.empty() ? '>' : '@') << s.name;
+  if (!s.comment.empty()) os << ' ' << s.comment;
+  os << '\n' << s.seq << '\n';
+  if (!s.quality.empty()) os << '+' << '\n' << s.quality << '\n';
+}
+
 // utils.cpp:128-135  stem: strip .gz/.bz2, then directory and last extension
 static inline std::string stem(const std::string& filename) {
   auto ends = [](const std::string& s, const char* suf) {

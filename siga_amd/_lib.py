@@ -43,7 +43,7 @@ class IndexInfo(C.Structure):
 SYMBOLS = [
     "sigax_last_error", "sigax_device_count", "sigax_index_open", "sigax_index_open_mem", "sigax_index_close",
     "sigax_index_info_get", "sigax_index_set_reads", "sigax_occ_batch", "sigax_kmer_count_batch",
-    "sigax_overlap_batch", "sigax_result_free", "sigax_batch_create", "sigax_batch_destroy", "sigax_batch_upload",
+    "sigax_correct_batch", "sigax_overlap_batch", "sigax_result_free", "sigax_batch_create", "sigax_batch_destroy", "sigax_batch_upload",
     "sigax_batch_set_device_reads", "sigax_batch_set_subbatches", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
     "sigax_batch_download", "sigax_batch_kernel_ms",
 ]
@@ -73,6 +73,7 @@ def lib():
     L.sigax_index_set_reads.argtypes = [vp, vp, vp, u64]
     L.sigax_occ_batch.argtypes = [vp, ci, vp, u64, vp]
     L.sigax_kmer_count_batch.argtypes = [vp, cp, u32, u64, vp]
+    L.sigax_correct_batch.argtypes = [vp, cp, cp, vp, u32, u32, C.c_int32, u32, u32, vp, vp]
     L.sigax_overlap_batch.argtypes = [vp, cp, vp, u32, u32, u32, u32, C.POINTER(Result)]
     L.sigax_result_free.argtypes = [C.POINTER(Result)]
     L.sigax_result_free.restype = None

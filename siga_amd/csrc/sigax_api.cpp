@@ -326,6 +326,55 @@ extern "C" int sigax_kmer_count_batch(sigax_index* ix, const char* kmers, uint32
   return SIGAX_OK;
 }
 
+extern "C" int sigax_correct_batch(sigax_index* ix, const char* seqs, const char* quals, const uint64_t* offs, uint32_t n_reads,
+                                   uint32_t kmer_size, int32_t kmer_threshold, uint32_t kmer_rounds, uint32_t count_offset,
+                                   char* out_seqs, uint8_t* valid) {
+  if (!ix || kmer_size == 0 || (n_reads && (!seqs || !offs || !out_seqs || !valid))) return fail(SIGAX_E_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(ix->device));
+  if (n_reads == 0) return SIGAX_OK;
+  const u64 nb = offs[n_reads];
+  unsigned char *d_seqs = nullptr, *d_quals = nullptr, *d_out = nullptr, *d_valid = nullptr;
+  u64 *d_offs = nullptr, *d_stat = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_seqs, nb + 16));
+  HIP_TRY(hipMalloc((void**)&d_out, nb + 16));
+  HIP_TRY(hipMalloc((void**)&d_offs, ((size_t)n_reads + 1) * 8));
+  HIP_TRY(hipMalloc((void**)&d_valid, (size_t)n_reads + 16));
+  HIP_TRY(hipMalloc((void**)&d_stat, 64));
+  HIP_TRY(hipMemset(d_stat, 0, 64));
+  HIP_TRY(hipMemcpy(d_seqs, seqs, nb, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_offs, offs, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
+  if (quals) {
+    HIP_TRY(hipMalloc((void**)&d_quals, nb + 16));
+    HIP_TRY(hipMemcpy(d_quals, quals, nb, hipMemcpyHostToDevice));
+  }
+  CorrectArgs ca;
+  ca.fwd = ix->st[0];
+  ca.seqs = d_seqs;
+  ca.quals = d_quals;
+  ca.offs = d_offs;
+  ca.n_reads = n_reads;
+  ca.k = kmer_size;
+  ca.low = (uint32_t)std::max(kmer_threshold, 0);       // CorrectThreshold::minSupport (src/correct_processor.cpp:28-31)
+  ca.high = (uint32_t)std::max(kmer_threshold + 1, 0);
+  ca.cutoff = 20;
+  ca.rounds = kmer_rounds;
+  ca.offset = count_offset;
+  ca.out = d_out;
+  ca.valid = d_valid;
+  ca.dstat = d_stat;
+  launch_correct(ca, ix->wide, 0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  u64 toolong = 0;
+  HIP_TRY(hipMemcpy(&toolong, d_stat, 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_seqs, d_out, nb, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(valid, d_valid, n_reads, hipMemcpyDeviceToHost));
+  hipFree(d_seqs); hipFree(d_out); hipFree(d_offs); hipFree(d_valid); hipFree(d_stat);
+  if (d_quals) hipFree(d_quals);
+  if (toolong) return fail(SIGAX_E_ARG, "%llu reads are longer than the 1024 bases the correction kernel supports", toolong);
+  return SIGAX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // batch workspace
 // ------------------------------------------------------------------------------------------------------

@@ -97,6 +97,19 @@ struct EdgeArgs {
   unsigned long long edge_cap;
 };
 
+struct CorrectArgs {
+  FmStrand fwd;
+  const unsigned char* seqs;
+  const unsigned char* quals;  // NULL: every base scores Quality::Phred::DEFAULT_SCORE (15)
+  const unsigned long long* offs;
+  unsigned long long n_reads;
+  uint32_t k, low, high, cutoff, rounds, offset;  // CorrectThreshold: required support low / high (phred >= cutoff)
+  unsigned char* out;    // corrected sequences, same layout as seqs
+  unsigned char* valid;  // CorrectResult::validQC; 2 = read longer than the kernel supports
+  unsigned long long* dstat;  // [0] reads too long
+};
+void launch_correct(const CorrectArgs& a, bool wide, hipStream_t st);
+
 void launch_occ_batch(const FmStrand& s, bool wide, const unsigned long long* pos, unsigned long long n,
                       unsigned long long* out, hipStream_t st);
 void launch_kmer_count(const FmStrand& s, bool wide, const unsigned char* kmers, uint32_t k, unsigned long long n,

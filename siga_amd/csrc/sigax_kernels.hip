@@ -1199,6 +1199,176 @@ __global__ __launch_bounds__(256) void k_filter_extract_fast(FxArgs A) {
 }
 
 // -------------------------------------------------------------------------------------------------------
+// k_correct: KmerCorrector::process (src/correct_processor.cpp:81-229), one wave per read.
+// Lanes are k-mer windows: every window's FMIndex::Interval::occurrences (src/fmindex.h:67-86) is an independent
+// chain of k-1 dependent rank pairs, so a round is the same memory-bound gather as the block finder.  Only windows
+// covering a corrected base are recounted (the reference's per-read kmerCache has the same effect).  Candidate
+// corrections of up to eight unsolid bases are evaluated at once (2 covering k-mers x 4 bases each); the one the
+// reference's left-to-right scan would take first is applied.
+// -------------------------------------------------------------------------------------------------------
+#define CORRECT_LMAX 1024
+
+struct CorrectSh {
+  unsigned char seq[CORRECT_LMAX];    // current sequence (bytes as read)
+  unsigned char score[CORRECT_LMAX];  // phred per base (DNASeq::score, src/kseq.h:34-40)
+  unsigned char minph[CORRECT_LMAX];  // min phred of the window starting here (src/correct_processor.cpp:95-103)
+  unsigned char redo[CORRECT_LMAX];   // window must be recounted
+  unsigned short pref[CORRECT_LMAX + 1];  // solid windows before this one
+  u32 cnt[CORRECT_LMAX];              // occurrences of the window's k-mer (saturated)
+};
+
+// Interval::occurrences of the k-mer starting at `s` in sh.seq, with base `ovpos` replaced by rank `ovrank`
+template <bool WIDE>
+__device__ __forceinline__ u32 kmer_occ(const FmRef& f, const FmTables& tb, const unsigned char* seq, u32 s, u32 k, u32 ovpos,
+                                        u32 ovrank) {
+  typedef typename PosOf<WIDE>::type P;
+  u32 j = k;
+  u32 r = (s + j - 1 == ovpos) ? ovrank : base_rank(seq[s + j - 1]);
+  P lo = (P)tb.C[f.which][r], hi = lo + (P)tb.T[f.which][r] - 1;  // Interval::init (src/fmindex.h:90-93)
+  while (--j > 0 && hi != (P)~(P)0 && hi >= lo) {
+    r = (s + j - 1 == ovpos) ? ovrank : base_rank(seq[s + j - 1]);
+    P l[5], u[5];
+    fm_rank5p<WIDE>(f, lo, l);            // getOcc(c, lower - 1)
+    fm_rank5p<WIDE>(f, (P)(hi + 1), u);   // getOcc(c, upper)
+    P lr = r == 0 ? l[0] : r == 1 ? l[1] : r == 2 ? l[2] : r == 3 ? l[3] : l[4];
+    P ur = r == 0 ? u[0] : r == 1 ? u[1] : r == 2 ? u[2] : r == 3 ? u[3] : u[4];
+    P pb = (P)tb.C[f.which][r];
+    lo = pb + lr;
+    hi = pb + ur - 1;
+  }
+  if (!(hi != (P)~(P)0 && hi >= lo)) return 0u;
+  u64 c = (u64)(hi - lo) + 1ull;
+  return c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)c;
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_correct(CorrectArgs A) {
+  __shared__ FmTables tb;
+  __shared__ CorrectSh shm[4];
+  fm_tables_load(tb, A.fwd, A.fwd);
+  const u32 wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const u64 lt = (1ull << lane) - 1ull;
+  CorrectSh& sh = shm[wid];
+  const FmRef F = fm_ref(A.fwd, 0);
+  const u64 wave = (u64)blockIdx.x * 4 + wid, nwaves = (u64)gridDim.x * 4;
+  const u32 k = A.k;
+  for (u64 rd = wave; rd < A.n_reads; rd += nwaves) {
+    const u64 b0 = A.offs[rd];
+    const u32 n = uni((u32)(A.offs[rd + 1] - b0));
+    u32 valid = 0;
+    if (n > CORRECT_LMAX) {
+      if (lane == 0) { A.valid[rd] = 2; atomicAdd(&A.dstat[0], 1ull); }
+      continue;
+    }
+    for (u32 i = lane; i < n; i += 64) {
+      unsigned char c = A.seqs[b0 + i];
+      sh.seq[i] = c;
+      A.out[b0 + i] = c;  // r.seq = item.read.seq unless the read becomes all-solid
+      sh.score[i] = A.quals ? (unsigned char)(A.quals[b0 + i] - 33) : (unsigned char)15;
+    }
+    wave_lds_sync();
+    if (n >= k) {  // src/correct_processor.cpp:85-89
+      const u32 nw = n - k + 1;
+      for (u32 s = lane; s < nw; s += 64) {
+        u32 m = 255;
+        for (u32 j = 0; j < k; ++j) m = min(m, (u32)sh.score[s + j]);
+        sh.minph[s] = (unsigned char)m;
+        sh.redo[s] = 1;
+      }
+      wave_lds_sync();
+      u32 rounds = 0;
+      while (true) {
+        // k-mer counts of the windows that changed, solid windows, prefix counts of solid windows
+        u32 base = 0;
+        for (u32 s0 = 0; s0 < nw; s0 += 64) {
+          const u32 s = s0 + lane;
+          bool good = false;
+          if (s < nw) {
+            if (sh.redo[s]) {
+              sh.cnt[s] = kmer_occ<WIDE>(F, tb, sh.seq, s, k, 0xFFFFFFFFu, 0u);
+              sh.redo[s] = 0;
+            }
+            good = sh.cnt[s] >= (sh.minph[s] >= A.cutoff ? A.high : A.low);  // CorrectThreshold::requiredSupport
+          }
+          u64 gm = __ballot(good);
+          if (s < nw) sh.pref[s] = (unsigned short)(base + (u32)__popcll(gm & lt));
+          base += (u32)__popcll(gm);
+        }
+        if (lane == 0) sh.pref[nw] = (unsigned short)base;
+        wave_lds_sync();
+        // a base is solid if some solid window covers it (:131-135)
+        bool allSolid = true;
+        for (u32 i0 = 0; i0 < n; i0 += 64) {
+          const u32 i = i0 + lane;
+          bool unsolid = false;
+          if (i < n) {
+            u32 lo = i + 1 >= k ? i + 1 - k : 0, hi = i < nw - 1 ? i : nw - 1;
+            unsolid = sh.pref[hi + 1] == sh.pref[lo];
+          }
+          if (__ballot(unsolid)) allSolid = false;
+        }
+        if (allSolid) { valid = 1; break; }
+        if (++rounds > A.rounds) break;
+        // leftmost base that can be corrected, trying its leftmost then rightmost covering k-mer (:154-173)
+        bool corrected = false;
+        for (u32 i0 = 0; i0 < n && !corrected; i0 += 64) {
+          const u32 i = i0 + lane;
+          bool unsolid = false;
+          if (i < n) {
+            u32 lo = i + 1 >= k ? i + 1 - k : 0, hi = i < nw - 1 ? i : nw - 1;
+            unsolid = sh.pref[hi + 1] == sh.pref[lo];
+          }
+          u64 m = __ballot(unsolid);
+          while (m && !corrected) {
+            // lane = (candidate q = lane / 8, side = (lane / 4) & 1, base rank = 1 + lane % 4)
+            const u32 q = lane >> 3, side = (lane >> 2) & 1u, brank = 1u + (lane & 3u);
+            u64 mm = m;
+            u32 pos = 0xFFFFFFFFu;
+            for (u32 t = 0; t < 8; ++t) {
+              u32 bit = mm ? (u32)__ffsll((long long)mm) - 1u : 0xFFFFFFFFu;
+              if (t == q && mm) pos = i0 + bit;
+              if (mm) mm &= mm - 1;
+            }
+            bool cand = false;
+            if (pos != 0xFFFFFFFFu) {
+              const u32 cur = base_rank(sh.seq[pos]);
+              if (brank != cur) {  // c != currBase (:204-206)
+                const u32 kidx = side ? (pos < n - k ? pos : n - k) : (pos + 1 >= k ? pos + 1 - k : 0u);
+                const u32 thr = sh.score[pos] >= A.cutoff ? A.high : A.low;
+                const u32 minCount = A.offset > thr ? A.offset : thr;  // max(countVector[..] (always 0) + offset, threshold)
+                cand = kmer_occ<WIDE>(F, tb, sh.seq, kidx, k, pos, brank) >= minCount;
+              }
+            }
+            // try2Correct succeeds iff exactly one alternative base reaches minCount (:207-223)
+            const u64 cm = __ballot(cand);
+            const u32 grp = (u32)((cm >> (lane & ~3u)) & 0xFull);
+            const bool win = cand && __popc(grp) == 1;
+            const u64 wm = __ballot(win);
+            if (wm) {
+              const u32 wl = (u32)__ffsll((long long)wm) - 1u;  // lowest lane = smallest position, left before right
+              const u32 wpos = __builtin_amdgcn_readlane(pos, wl);
+              const u32 wr = 1u + (wl & 3u);
+              if (lane == 0) sh.seq[wpos] = wr == 1 ? 'A' : wr == 2 ? 'C' : wr == 3 ? 'G' : 'T';
+              const u32 wlo = wpos + 1 >= k ? wpos + 1 - k : 0, whi = wpos < nw - 1 ? wpos : nw - 1;
+              for (u32 s = wlo + lane; s <= whi; s += 64) sh.redo[s] = 1;
+              corrected = true;
+            }
+            m = mm;  // the eight candidates just tried are done
+          }
+        }
+        wave_lds_sync();
+        if (!corrected) break;
+      }
+    }
+    if (valid) {
+      for (u32 i = lane; i < n; i += 64) A.out[b0 + i] = sh.seq[i];
+    }
+    if (lane == 0) A.valid[rd] = (unsigned char)valid;
+    wave_lds_sync();
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
 // exclusive scan of u32 counts into u64 offsets (three small kernels), ordered scatter of the final blocks
 // -------------------------------------------------------------------------------------------------------
 #define SCAN_ITEMS 2048  // per workgroup of 256 threads
@@ -1344,6 +1514,14 @@ void launch_kmer_count(const FmStrand& s, bool wide, const unsigned char* kmers,
   if (n == 0) return;
   if (wide) hipLaunchKernelGGL(k_kmer_count<true>, dim3(nblk(n, 256)), dim3(256), 0, st, s, kmers, k, n, out);
   else hipLaunchKernelGGL(k_kmer_count<false>, dim3(nblk(n, 256)), dim3(256), 0, st, s, kmers, k, n, out);
+}
+
+void launch_correct(const CorrectArgs& a, bool wide, hipStream_t st) {
+  if (a.n_reads == 0) return;
+  unsigned g = (unsigned)((a.n_reads + 3) / 4);
+  if (g > 4096) g = 4096;
+  if (wide) hipLaunchKernelGGL(k_correct<true>, dim3(g), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_correct<false>, dim3(g), dim3(256), 0, st, a);
 }
 
 void launch_find(const FindArgs& a, bool wide, hipStream_t st) {

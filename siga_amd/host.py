@@ -21,6 +21,8 @@ def lib():
         L.sigah_overlap_file.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_int, C.c_int, C.c_uint64,
                                          C.c_uint64, C.c_int, C.c_char_p, C.c_uint64]
         L.sigah_stem.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64]
+        L.sigah_correct_file.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                         C.c_int, C.c_char_p, C.c_uint64]
         L.sigah_rmdup_file.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_uint64]
         _lib = L
     return _lib
@@ -55,6 +57,14 @@ def rmdup_file(reads_path, prefix, output, duplicates, device=0):
     err = C.create_string_buffer(512)
     if lib().sigah_rmdup_file(reads_path.encode(), prefix.encode(), output.encode(), duplicates.encode(), device, err, 512) != 0:
         raise RuntimeError("siga rmdup failed: " + err.value.decode())
+
+
+def correct_file(reads_path, prefix, output, k=31, threshold=3, rounds=10, offset=1, device=0):
+    """FMIndex::load + CorrectProcessor::process (k-mer algorithm) in the host C++ library (GPU compute)."""
+    err = C.create_string_buffer(512)
+    if lib().sigah_correct_file(reads_path.encode(), prefix.encode(), output.encode(), k, threshold, rounds, offset, device,
+                                err, 512) != 0:
+        raise RuntimeError("siga correct failed: " + err.value.decode())
 
 
 def stem(path):

@@ -248,9 +248,10 @@ static bool build_strand(const char* seqs, const uint64_t* offs, uint64_t nReads
     uint64_t pos = (uint64_t)SA[k];
     uint32_t prevCode = pos == 0 ? 1u : T[pos - 1];
     push(prevCode - 1);
-    if (prevCode == 1) {  // suffix starts a read: SA row with j == 0 (src/suffix_array_builder.cpp:520-531)
-      uint64_t id = std::upper_bound(starts.begin(), starts.end(), pos) - starts.begin() - 1;
-      out->sai.push_back((uint32_t)id);
+    if (prevCode == 1) {  // maybe the start of a read: SA row with j == 0 (src/suffix_array_builder.cpp:520-531).
+      // Decided by position, not by the preceding symbol: a non-ACGT base ranks like the sentinel (alphabet.h:19-39).
+      auto it = std::lower_bound(starts.begin(), starts.end(), pos);
+      if (it != starts.end() && *it == pos) out->sai.push_back((uint32_t)(it - starts.begin()));
     }
   }
   if (run) out->runs.push_back(run);
@@ -638,6 +639,81 @@ bool OverlapBuilder::rmdup(const std::string& input, const std::string& output, 
   return true;
 }
 
+bool CorrectProcessor::process(const FMIndex& index, const std::string& input, const std::string& output, size_t threads,
+                               size_t* processed) const {
+  (void)threads;
+  (void)processed;
+  _error.clear();
+  if (!index.handle()) {
+    _error = "FMIndex not loaded";
+    return false;
+  }
+  DNASeqList reads;
+  if (!ReadDNASequences(input, reads)) {
+    _error = "Failed to create DNASeqReader " + input;
+    return false;
+  }
+  OutFile out(output);
+  if (!out.ok()) {
+    _error = "Failed to create DNASeqWriter " + output;
+    return false;
+  }
+  const size_t n = reads.size(), per = 262144;
+  std::string seqs, quals, corrected, text;
+  std::vector<uint64_t> offs;
+  std::vector<uint8_t> valid;
+  for (size_t base = 0; base < n; base += per) {
+    size_t cnt = std::min(per, n - base);
+    seqs.clear();
+    quals.clear();
+    offs.assign(1, 0);
+    bool anyQual = false;
+    for (size_t i = 0; i < cnt; ++i) anyQual = anyQual || !reads[base + i].quality.empty();
+    for (size_t i = 0; i < cnt; ++i) {
+      const DNASeq& rd = reads[base + i];
+      seqs += rd.seq;
+      if (anyQual) {  // a read without qualities scores 15 per base (src/kseq.h:34-40): '0' is phred 15
+        if (rd.quality.empty()) quals.append(rd.seq.size(), (char)(15 + 33));
+        else quals += rd.quality;
+      }
+      offs.push_back(seqs.size());
+    }
+    corrected.assign(seqs.size(), '\0');
+    valid.assign(cnt, 0);
+    if (sigax_correct_batch(index.handle(), seqs.data(), anyQual ? quals.data() : nullptr, offs.data(), (uint32_t)cnt,
+                            (uint32_t)_options.kmerSize, (int32_t)_options.kmerThreshold, (uint32_t)_options.kmerRounds,
+                            (uint32_t)_options.kmerCountOffset, &corrected[0], valid.data()) != SIGAX_OK) {
+      _error = std::string("correct failed: ") + sigax_last_error();
+      return false;
+    }
+    text.clear();
+    for (size_t i = 0; i < cnt; ++i) {  // PostCorrector (src/correct_processor.cpp:247-253) + DNASeq << (src/kseq.cpp:106-126)
+      if (valid[i] != 1) continue;
+      const DNASeq& rd = reads[base + i];
+      text += rd.quality.empty() ? '>' : '@';
+      text += rd.name;
+      if (!rd.comment.empty()) {
+        text += ' ';
+        text += rd.comment;
+      }
+      text += '\n';
+      text.append(corrected, offs[i], offs[i + 1] - offs[i]);
+      text += '\n';
+      if (!rd.quality.empty()) {
+        text += "+\n";
+        text += rd.quality;
+        text += '\n';
+      }
+    }
+    out.write(text);
+  }
+  if (!out.close()) {
+    _error = "Failed to write " + output;
+    return false;
+  }
+  return true;
+}
+
 }  // namespace sigah
 
 // ------------------------------------------------------------------------------------------------------
@@ -715,6 +791,24 @@ int sigah_rmdup_file(const char* reads_path, const char* prefix, const char* out
   sigah::OverlapBuilder builder(&fmi, prefix);
   if (!builder.rmdup(reads_path, output, duplicates)) {
     if (err && errcap) snprintf(err, errcap, "%s", builder.error().c_str());
+    return -1;
+  }
+  return 0;
+}
+
+// `siga correct`: FMIndex::load(prefix.bwt) + CorrectProcessor::process
+int sigah_correct_file(const char* reads_path, const char* prefix, const char* output, uint64_t k, uint64_t threshold,
+                       uint64_t rounds, uint64_t offset, int device, char* err, uint64_t errcap) {
+  sigah::FMIndex fmi;
+  if (!sigah::FMIndex::load(prefix, fmi, device)) {
+    if (err && errcap) snprintf(err, errcap, "Failed to load FMIndex from %s: %s", prefix, sigax_last_error());
+    return -1;
+  }
+  sigah::CorrectProcessor::Options o;
+  o.kmerSize = k; o.kmerThreshold = threshold; o.kmerRounds = rounds; o.kmerCountOffset = offset;
+  sigah::CorrectProcessor proc(o);
+  if (!proc.process(fmi, reads_path, output)) {
+    if (err && errcap) snprintf(err, errcap, "%s", proc.error().c_str());
     return -1;
   }
   return 0;

@@ -101,6 +101,24 @@ class OverlapBuilder {
   mutable std::string _error;
 };
 
+// src/correct_processor.h:25-42 (k-mer algorithm only; the reference's "overlap" algorithm is an empty stub)
+class CorrectProcessor {
+ public:
+  struct Options {
+    size_t kmerSize, kmerThreshold, kmerRounds, kmerCountOffset;  // -k -x -i -O, defaults src/correct_processor.h:15-20
+    Options() : kmerSize(31), kmerThreshold(3), kmerRounds(10), kmerCountOffset(1) {}
+  };
+  explicit CorrectProcessor(const Options& options) : _options(options) {}
+  // reads that became all-solid are written to `output` in the input's format (FASTA/FASTQ), the rest are dropped
+  bool process(const FMIndex& index, const std::string& input, const std::string& output, size_t threads = 1,
+               size_t* processed = nullptr) const;
+  const std::string& error() const { return _error; }
+
+ private:
+  Options _options;
+  mutable std::string _error;
+};
+
 }  // namespace sigah
 
 #endif

@@ -13,7 +13,7 @@
 extern "C" int sigah_index_file(const char*, const char*, int, char*, uint64_t);
 
 static int usage() {
-  printf("siga [index|overlap|rmdup] [OPTION] ... READSFILE\n"
+  printf("siga [index|correct|overlap|rmdup] [OPTION] ... READSFILE\n"
          "  index     build the FM-index (.sai/.bwt/.rsai/.rbwt) of READSFILE\n"
          "  overlap   compute pairwise overlaps between all the sequences in READSFILE (GPU)\n");
   return 256;
@@ -198,11 +198,84 @@ static int run_rmdup(int argc, char** argv) {
   return 0;
 }
 
+static int correct_help() {
+  printf("siga correct [OPTION] ... READSFILE\n"
+         "Correct sequencing errors in all the reads in READSFILE\n"
+         "\n"
+         "      -h, --help                       display this help and exit\n"
+         "\n"
+         "      -p, --prefix=PREFIX              use PREFIX instead of prefix of READSFILE for the names of the index files\n"
+         "      -o, --outfile=FILE               write the corrected reads to FILE (default READFILE.ec.fa)\n"
+         "      -t, --threads=NUM                use NUM threads for the computation (default: 1)\n"
+         "      -a, --algorithm=STR              specify the correction algorithm to use. Only kmer is built. (default: kmer)\n"
+         "\n"
+         "      -k, --kmer-size=N                the length of the kmer to user (default: 31)\n"
+         "      -x, --kmer-threshold=N           attempt to correct kmers that are seen less than N times (default: 3)\n"
+         "      -i, --kmer-rounds=N              perform up to N rounds of kmer correction (default: 10)\n"
+         "      -O, --kmer-count-offset=N        when correcting a kmer, require the count of the new kmer is at least +N higher than the count of the old kmer. (default: 1)\n"
+         "          --device=NUM                 GPU to use (default: 0)\n"
+         "\n");
+  return 256;
+}
+
+// src/correct.cpp:22-60
+static int run_correct(int argc, char** argv) {
+  enum { OPT_DEVICE = 1 };
+  static const option longopts[] = {{"log4cxx", required_argument, nullptr, 'c'},   {"ini", required_argument, nullptr, 's'},
+                                    {"prefix", required_argument, nullptr, 'p'},    {"outfile", required_argument, nullptr, 'o'},
+                                    {"threads", required_argument, nullptr, 't'},   {"algorithm", required_argument, nullptr, 'a'},
+                                    {"kmer-size", required_argument, nullptr, 'k'}, {"kmer-threshold", required_argument, nullptr, 'x'},
+                                    {"kmer-rounds", required_argument, nullptr, 'i'}, {"kmer-count-offset", required_argument, nullptr, 'O'},
+                                    {"device", required_argument, nullptr, OPT_DEVICE}, {"help", no_argument, nullptr, 'h'},
+                                    {nullptr, 0, nullptr, 0}};
+  std::string prefix, outfile, algorithm = "kmer";
+  sigah::CorrectProcessor::Options o;
+  size_t threads = 1;
+  bool help = false;
+  int device = 0, c;
+  while ((c = getopt_long(argc, argv, "c:s:p:o:t:a:k:x:i:O:h", longopts, nullptr)) != -1) {
+    switch (c) {
+      case 'p': prefix = optarg; break;
+      case 'o': outfile = optarg; break;
+      case 't': threads = strtoull(optarg, nullptr, 10); break;
+      case 'a': algorithm = optarg; break;
+      case 'k': o.kmerSize = strtoull(optarg, nullptr, 10); break;
+      case 'x': o.kmerThreshold = strtoull(optarg, nullptr, 10); break;
+      case 'i': o.kmerRounds = strtoull(optarg, nullptr, 10); break;
+      case 'O': o.kmerCountOffset = strtoull(optarg, nullptr, 10); break;
+      case OPT_DEVICE: device = atoi(optarg); break;
+      case 'h': help = true; break;
+      default: break;
+    }
+  }
+  if (help || argc - optind != 1) return correct_help();
+  std::string input = argv[optind];
+  std::string stem = sigah::Utils::stem(input);
+  if (outfile.empty()) outfile = stem + ".ec.fa";
+  if (prefix.empty()) prefix = stem;
+  if (algorithm != "kmer") {  // AbstractCorrector::create returns NULL / the overlap corrector is an empty stub
+    fprintf(stderr, "Failed to do error correction for reads %s: algorithm %s is not built\n", input.c_str(), algorithm.c_str());
+    return -1;
+  }
+  sigah::FMIndex fmi;
+  if (!sigah::FMIndex::load(prefix, fmi, device)) {
+    fprintf(stderr, "Failed to load FMIndex from %s: %s\n", prefix.c_str(), sigax_last_error());
+    return -1;
+  }
+  sigah::CorrectProcessor proc(o);
+  if (!proc.process(fmi, input, outfile, threads)) {
+    fprintf(stderr, "Failed to do error correction for reads %s: %s\n", input.c_str(), proc.error().c_str());
+    return -1;
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) return usage();
   std::string cmd = argv[1];
   if (cmd == "index") return run_index(argc - 1, argv + 1);
   if (cmd == "rmdup") return run_rmdup(argc - 1, argv + 1);
+  if (cmd == "correct") return run_correct(argc - 1, argv + 1);
   if (cmd == "overlap") return run_overlap(argc - 1, argv + 1);
   return usage();
 }

@@ -52,7 +52,7 @@ def test_product_does_not_import_the_oracle():
                 assert "oracle" not in text.replace("the oracle", "").replace("oracle-", ""), os.path.join(dirpath, f)
 
 
-@pytest.mark.parametrize("name", ["corner", "rep", "dup", "tiny", "toy"])
+@pytest.mark.parametrize("name", ["corner", "rep", "dup", "tiny", "toy", "ragged_n"])
 def test_siga_index_matches_oracle_builder(name, tmp_path):
     """`siga index` (own SA-IS, siga_amd/host) is byte-identical to the oracle's naive suffix sort (model B)."""
     fx = fixture(name)

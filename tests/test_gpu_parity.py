@@ -204,3 +204,62 @@ def test_duplicate_blocks_match_oracle(sa):
     for r, s in enumerate(fx.seqs):
         got = res["blocks"][int(offs[r]):int(offs[r + 1])]
         assert all(int(b["length"]) == len(s) for b in got)
+
+
+# ---- `siga correct` k-mer path (BASELINE configs[3]) ------------------------------------------------
+def _noisy(reads, frac, seed, with_n=False):
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for n, s in reads:
+        if rnd.random() < frac:
+            for _ in range(rnd.choice([1, 1, 2])):
+                p = rnd.randrange(len(s))
+                s = s[:p] + rnd.choice([c for c in "ACGT" if c != s[p]]) + s[p + 1:]
+        if with_n and rnd.random() < 0.02:
+            p = rnd.randrange(len(s))
+            s = s[:p] + "N" + s[p + 1:]
+        out.append((n, s))
+    return out
+
+
+@pytest.mark.parametrize("k,fmt", [(21, "fa"), (31, "fq"), (15, "fa")])
+def test_correct_matches_oracle(sa, tmp_path, k, fmt):
+    import random
+    from oracle import pyoracle as po
+    from siga_amd import host
+    fx = fixture("toy")
+    reads = _noisy(fx.reads, 0.3, 11 + k, with_n=(k == 15))
+    path = str(tmp_path / ("reads." + fmt))
+    rnd = random.Random(5)
+    with open(path, "w") as f:
+        for i, (n, s) in enumerate(reads):
+            if fmt == "fq":
+                q = "".join(chr(33 + rnd.choice([2, 12, 19, 20, 30, 40])) for _ in s)
+                f.write("@%s%s\n%s\n+\n%s\n" % (n, " c%d" % i if i % 5 == 0 else "", s, q))
+            else:
+                f.write(">%s\n%s\n" % (n, s))
+        if fmt == "fa":
+            f.write(">short\nACGTACGT\n")  # shorter than k: never written
+    prefix = str(tmp_path / "reads")
+    host.index_file(path, prefix)
+    st = po.correct(po.Index.load(prefix + ".bwt"), path, str(tmp_path / "o.ec"), k=k)
+    host.correct_file(path, prefix, str(tmp_path / "g.ec"), k=k)
+    assert open(tmp_path / "g.ec").read() == open(tmp_path / "o.ec").read()
+    assert st["changed"] > 100 and st["written"] > 2000
+
+
+def test_correct_cli_defaults(sa, tmp_path):
+    """`siga correct reads.fa` -> reads.ec.fa in the CWD (src/correct.cpp:34-37), defaults k=31 x=3 i=10 O=1."""
+    import subprocess
+    from oracle import pyoracle as po
+    from siga_amd import host
+    fx = fixture("toy")
+    cwd = str(tmp_path)
+    with open(cwd + "/reads.fa", "w") as f:
+        for n, s in _noisy(fx.reads, 0.2, 3):
+            f.write(">%s\n%s\n" % (n, s))
+    assert subprocess.run([host.CLI_PATH, "index", "reads.fa"], cwd=cwd).returncode == 0
+    assert subprocess.run([host.CLI_PATH, "correct", "reads.fa"], cwd=cwd).returncode == 0
+    po.correct(po.Index.load(cwd + "/reads.bwt"), cwd + "/reads.fa", cwd + "/o.ec")
+    assert open(cwd + "/reads.ec.fa").read() == open(cwd + "/o.ec").read()
