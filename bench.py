@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--subbatches", type=int, default=0,
                     help="sub-batches per step (0 = library default: 4 at this size; their find and filter/extract kernels overlap)")
+    ap.add_argument("--isolated", action="store_true",
+                    help="after the timed steps, also time 2 steps with sub-batching off and report them under roofline.isolated")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow on fewer GPUs than ranks (edge records gathered via host)")
     args = ap.parse_args()
@@ -174,7 +176,7 @@ def main():
 
     # the same kernels with sub-batching off (no overlap between find and filter/extract): untimed extra steps
     iso = None
-    if launches > 1:
+    if launches > 1 and args.isolated:
         assert lib.sigax_batch_set_subbatches(batch, 1) == 0
         isum = np.zeros(5)
         for _ in range(2):
@@ -198,7 +200,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = "k_find/%d/%d/%d" % (args.reads_per_gpu, args.genome_per_gpu, L)
+                key = "k_find/%d/%d/%d/%d" % (args.reads_per_gpu, args.genome_per_gpu, L, launches)
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -215,7 +217,7 @@ def main():
             "kernel_ms_per_step": {k: float(v) for k, v in zip(KERNELS, kavg)},
             "launches_per_step": launches,
             "roofline": {"bound": "hbm", "kernel": "k_find", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic / launches if traffic else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": find_ms,
                          "note": "launch durations in the timed region, where sub-batch i+1's k_find runs beside "
                                  "sub-batch i's filter/extract kernels" if launches > 1 else "kernels run back to back",
