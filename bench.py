@@ -95,7 +95,7 @@ def main():
         os.makedirs(workdir, exist_ok=True)
         if not all(os.path.exists(prefix + e) for e in (".bwt", ".rbwt", ".sai", ".rsai")):
             offs_all = np.arange(0, (n_total + 1) * L, L, dtype=np.uint64)
-            host.index_build(reads.reshape(-1), offs_all, prefix, threads=2)
+            host.index_build(reads.reshape(-1), offs_all, prefix, threads=max(2, min(os.cpu_count() or 2, 96)))
         log("reads + index ready in %.1f s (%d reads, %d symbols per strand)" % (time.time() - t0, n_total, n_total * (L + 1)))
     if world > 1:
         dist.barrier()

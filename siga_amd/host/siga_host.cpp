@@ -5,6 +5,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -206,8 +207,94 @@ static inline int torank(char c) {  // src/alphabet.h:19-39
   }
 }
 
+// Multi-threaded suffix sort for many-core hosts: bucket every suffix by its first KP symbols (counting sort over
+// base-6 keys), then comparison-sort the buckets in parallel.  The terminator is unique, so memcmp from offset KP
+// decides every pair.  Same total order as SA-IS by construction (plain suffix array, end of text smallest).  Returns
+// false (caller falls back to SA-IS) when a bucket is so large that long repeats would make it crawl.
 template <typename I>
-static bool build_strand(const char* seqs, const uint64_t* offs, uint64_t nReads, bool reverse, StrandIndex* out) {
+static bool parallel_suffix_sort(const uint8_t* T, uint64_t n /* incl. terminator */, I* SA, unsigned threads) {
+  const int KP = 9;
+  uint64_t nb = 1;
+  for (int i = 0; i < KP; ++i) nb *= 6;
+  auto key_at = [&](uint64_t p) {
+    uint64_t k = 0;
+    for (int i = 0; i < KP; ++i) k = k * 6 + (p + i < n ? T[p + i] : 0);
+    return k;
+  };
+  std::vector<uint64_t> start(nb + 1, 0);
+  std::vector<std::vector<uint32_t>> hist(threads);
+  const uint64_t chunk = (n + threads - 1) / threads;
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < threads; ++t)
+      th.emplace_back([&, t] {
+        hist[t].assign(nb, 0);
+        uint64_t b = t * chunk, e = std::min(n, b + chunk);
+        for (uint64_t p = b; p < e; ++p) ++hist[t][key_at(p)];
+      });
+    for (auto& x : th) x.join();
+  }
+  uint64_t acc = 0, biggest = 0;
+  for (uint64_t k = 0; k < nb; ++k) {
+    start[k] = acc;
+    uint64_t c = 0;
+    for (unsigned t = 0; t < threads; ++t) {
+      uint32_t h = hist[t][k];
+      hist[t][k] = (uint32_t)c;  // this thread's offset inside the bucket (< 2^32 checked below)
+      c += h;
+    }
+    if (c > 0xFFFFFFF0ull) return false;
+    biggest = std::max(biggest, c);
+    acc += c;
+  }
+  start[nb] = acc;
+  if (biggest > (64ull << 20)) return false;
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < threads; ++t)
+      th.emplace_back([&, t] {
+        uint64_t b = t * chunk, e = std::min(n, b + chunk);
+        for (uint64_t p = b; p < e; ++p) {
+          uint64_t k = key_at(p);
+          SA[start[k] + hist[t][k]++] = (I)p;
+        }
+      });
+    for (auto& x : th) x.join();
+  }
+  // sort the buckets, largest first, pulled from a shared counter
+  std::vector<uint64_t> order;
+  order.reserve(1 << 20);
+  for (uint64_t k = 0; k < nb; ++k)
+    if (start[k + 1] - start[k] > 1) order.push_back(k);
+  std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return start[a + 1] - start[a] > start[b + 1] - start[b]; });
+  std::atomic<uint64_t> next(0);
+  auto less = [&](I a, I b) {
+    uint64_t pa = (uint64_t)a + KP, pb = (uint64_t)b + KP;
+    if (pa >= n || pb >= n) return a > b;  // the shorter suffix (later start) is smaller
+    uint64_t la = n - pa, lb = n - pb;
+    int c = memcmp(T + pa, T + pb, std::min(la, lb));
+    if (c != 0) return c < 0;
+    return la < lb;
+  };
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < threads; ++t)
+      th.emplace_back([&] {
+        while (true) {
+          uint64_t i = next.fetch_add(1);
+          if (i >= order.size()) break;
+          uint64_t k = order[i];
+          std::sort(SA + start[k], SA + start[k + 1], less);
+        }
+      });
+    for (auto& x : th) x.join();
+  }
+  return true;
+}
+
+template <typename I>
+static bool build_strand(const char* seqs, const uint64_t* offs, uint64_t nReads, bool reverse, StrandIndex* out,
+                         unsigned threads) {
   uint64_t total = 0;
   for (uint64_t i = 0; i < nReads; ++i) total += (offs[i + 1] - offs[i]) + 1;
   // text over {terminator 0, $ 1, A 2, C 3, G 4, T 5}; one '$' after every read, unique terminator at the end
@@ -226,7 +313,8 @@ static bool build_strand(const char* seqs, const uint64_t* offs, uint64_t nReads
   }
   T[p] = 0;
   std::vector<I> SA(total + 1);
-  sais<uint8_t, I>(T.data(), SA.data(), (I)(total + 1), (I)6);
+  if (threads < 2 || total < (1u << 20) || !parallel_suffix_sort<I>(T.data(), total + 1, SA.data(), threads))
+    sais<uint8_t, I>(T.data(), SA.data(), (I)(total + 1), (I)6);
   out->runs.clear();
   out->sai.clear();
   out->sai.reserve(nReads);
@@ -259,7 +347,7 @@ static bool build_strand(const char* seqs, const uint64_t* offs, uint64_t nReads
 }
 
 bool BuildStrandIndex(const char* seqs, const uint64_t* offs, uint64_t nReads, bool reverse, StrandIndex* out,
-                      std::string* error) {
+                      std::string* error, unsigned threads) {
   uint64_t total = 0;
   for (uint64_t i = 0; i < nReads; ++i) {
     if (offs[i + 1] < offs[i]) {
@@ -273,8 +361,8 @@ bool BuildStrandIndex(const char* seqs, const uint64_t* offs, uint64_t nReads, b
     return false;
   }
   try {
-    if (total + 1 < 0x7FFFFFF0ull) return build_strand<int32_t>(seqs, offs, nReads, reverse, out);
-    return build_strand<int64_t>(seqs, offs, nReads, reverse, out);
+    if (total + 1 < 0x7FFFFFF0ull) return build_strand<int32_t>(seqs, offs, nReads, reverse, out, threads);
+    return build_strand<int64_t>(seqs, offs, nReads, reverse, out, threads);
   } catch (const std::bad_alloc&) {
     if (error) *error = "out of memory building the suffix array";
     return false;
@@ -727,13 +815,13 @@ int sigah_index_build(const char* seqs, const uint64_t* offs, uint64_t n_reads, 
   sigah::StrandIndex fwd, rev;
   std::string e1, e2;
   bool ok1 = false, ok2 = false;
-  if (threads > 1) {
+  if (threads == 2) {  // one SA-IS per strand, side by side
     std::thread t([&] { ok2 = sigah::BuildStrandIndex(seqs, offs, n_reads, true, &rev, &e2); });
     ok1 = sigah::BuildStrandIndex(seqs, offs, n_reads, false, &fwd, &e1);
     t.join();
-  } else {
-    ok1 = sigah::BuildStrandIndex(seqs, offs, n_reads, false, &fwd, &e1);
-    ok2 = sigah::BuildStrandIndex(seqs, offs, n_reads, true, &rev, &e2);
+  } else {  // 1 thread: SA-IS; more: the multi-threaded bucket sort, one strand after the other
+    ok1 = sigah::BuildStrandIndex(seqs, offs, n_reads, false, &fwd, &e1, (unsigned)std::max(threads, 1));
+    ok2 = sigah::BuildStrandIndex(seqs, offs, n_reads, true, &rev, &e2, (unsigned)std::max(threads, 1));
   }
   std::string p(prefix);
   if (ok1 && ok2) {

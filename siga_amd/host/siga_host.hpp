@@ -56,8 +56,9 @@ struct StrandIndex {
 };
 
 // SuffixArrayBuilder "sais2" + BWT(sa, reads) (src/suffix_array_builder.cpp:472-674, src/bwt.cpp:7-32)
+// threads >= 2 selects a multi-threaded bucket sort (same suffix order), 1 the SA-IS
 bool BuildStrandIndex(const char* seqs, const uint64_t* offs, uint64_t nReads, bool reverse, StrandIndex* out,
-                      std::string* error);
+                      std::string* error, unsigned threads = 1);
 
 // FMIndex pair resident on a GPU (FMIndex::load x2, src/overlap.cpp:41-42)
 class FMIndex {

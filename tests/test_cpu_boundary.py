@@ -108,3 +108,13 @@ def test_vertex_tags_and_edge_coords():
 def test_name_ranks_are_string_order():
     r = ov.name_ranks(["r10", "r9", "r1", "r10"])
     assert list(r) == [1, 2, 0, 1]  # "r1" < "r10" < "r9"; equal names share a rank (overlap_builder.cpp:358,365)
+
+
+@pytest.mark.slow
+def test_parallel_suffix_sort_equals_sais(tmp_path):
+    """threads >= 3 selects the multi-threaded bucket sort: same files as the SA-IS path (and as the oracle) on `mid`."""
+    fx = fixture("mid")
+    prefix = str(tmp_path / "mid")
+    host.index_file(fx.fa, prefix, threads=4)
+    for ext in (".bwt", ".rbwt", ".sai", ".rsai"):
+        assert open(prefix + ext, "rb").read() == open(fx.prefix + ext, "rb").read(), ext
