@@ -221,16 +221,29 @@ static bool parallel_suffix_sort(const uint8_t* T, uint64_t n /* incl. terminato
     for (int i = 0; i < KP; ++i) k = k * 6 + (p + i < n ? T[p + i] : 0);
     return k;
   };
+  // counting passes: a modest number of threads (each holds a histogram of nb counters), rolling base-6 keys
+  const unsigned ct = std::min<unsigned>(threads, 16);
+  uint64_t top = 1;
+  for (int i = 0; i < KP - 1; ++i) top *= 6;
   std::vector<uint64_t> start(nb + 1, 0);
-  std::vector<std::vector<uint32_t>> hist(threads);
-  const uint64_t chunk = (n + threads - 1) / threads;
+  std::vector<std::vector<uint32_t>> hist(ct);
+  const uint64_t chunk = (n + ct - 1) / ct;
+  auto sweep = [&](unsigned t, bool scatter) {
+    uint64_t b = t * chunk, e = std::min(n, b + chunk);
+    if (b >= e) return;
+    uint64_t k = key_at(b);
+    for (uint64_t p = b; p < e; ++p) {
+      if (scatter) SA[start[k] + hist[t][k]++] = (I)p;
+      else ++hist[t][k];
+      k = (k % top) * 6 + (p + KP < n ? T[p + KP] : 0);
+    }
+  };
   {
     std::vector<std::thread> th;
-    for (unsigned t = 0; t < threads; ++t)
+    for (unsigned t = 0; t < ct; ++t)
       th.emplace_back([&, t] {
         hist[t].assign(nb, 0);
-        uint64_t b = t * chunk, e = std::min(n, b + chunk);
-        for (uint64_t p = b; p < e; ++p) ++hist[t][key_at(p)];
+        sweep(t, false);
       });
     for (auto& x : th) x.join();
   }
@@ -238,7 +251,7 @@ static bool parallel_suffix_sort(const uint8_t* T, uint64_t n /* incl. terminato
   for (uint64_t k = 0; k < nb; ++k) {
     start[k] = acc;
     uint64_t c = 0;
-    for (unsigned t = 0; t < threads; ++t) {
+    for (unsigned t = 0; t < ct; ++t) {
       uint32_t h = hist[t][k];
       hist[t][k] = (uint32_t)c;  // this thread's offset inside the bucket (< 2^32 checked below)
       c += h;
@@ -251,14 +264,7 @@ static bool parallel_suffix_sort(const uint8_t* T, uint64_t n /* incl. terminato
   if (biggest > (64ull << 20)) return false;
   {
     std::vector<std::thread> th;
-    for (unsigned t = 0; t < threads; ++t)
-      th.emplace_back([&, t] {
-        uint64_t b = t * chunk, e = std::min(n, b + chunk);
-        for (uint64_t p = b; p < e; ++p) {
-          uint64_t k = key_at(p);
-          SA[start[k] + hist[t][k]++] = (I)p;
-        }
-      });
+    for (unsigned t = 0; t < ct; ++t) th.emplace_back([&, t] { sweep(t, true); });
     for (auto& x : th) x.join();
   }
   // sort the buckets, largest first, pulled from a shared counter
