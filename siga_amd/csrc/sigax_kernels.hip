@@ -27,6 +27,13 @@ struct Cnt4 {
   u64 a, c, g, t;
 };
 
+// Position type of an index: u32 while the BWT has fewer than 2^32 symbols (half the registers and ALU work), else u64.
+template <bool WIDE> struct PosOf { typedef u32 type; };
+template <> struct PosOf<true> { typedef u64 type; };
+template <typename P> struct Cnt4P {
+  P a, c, g, t;
+};
+
 __device__ __forceinline__ void chunk_count(const uint4& k, int take, u32& a, u32& c, u32& g, u32& t) {
   u32 m = take >= 32 ? 0xFFFFFFFFu : (take <= 0 ? 0u : ((1u << take) - 1u));
   u32 x0 = k.y & m, x1 = k.z & m, x2 = k.w & m;
@@ -102,6 +109,28 @@ __device__ __forceinline__ void fm_rank5(const FmRef& s, u64 p, u64 v[5]) {
   Cnt4 k = fm_rank<WIDE>(s, pc);
   v[1] = k.a; v[2] = k.c; v[3] = k.g; v[4] = k.t;
   v[0] = pc - (k.a + k.c + k.g + k.t);
+}
+
+// A,C,G,T counts of BWT[0, p) in the index's position type
+template <bool WIDE>
+__device__ __forceinline__ Cnt4P<typename PosOf<WIDE>::type> fm_rank4p(const FmRef& s, typename PosOf<WIDE>::type p) {
+  typedef typename PosOf<WIDE>::type P;
+  u64 pc = (u64)p > s.n ? s.n : (u64)p;
+  const uint4* q = s.g + (pc >> 7) * 4;
+  int r = (int)(pc & 127u);
+  uint4 k0 = q[0], k1 = q[1], k2 = q[2], k3 = q[3];
+  u32 a = k0.x, c = k1.x, g = k2.x, t = k3.x;
+  chunk_count(k0, r, a, c, g, t);
+  chunk_count(k1, r - 32, a, c, g, t);
+  chunk_count(k2, r - 64, a, c, g, t);
+  chunk_count(k3, r - 96, a, c, g, t);
+  Cnt4P<P> o;
+  o.a = a; o.c = c; o.g = g; o.t = t;
+  if (WIDE) {
+    const u64* sb = s.super + (pc >> SIGAX_SUPER_SHIFT) * 4;
+    o.a += (P)sb[0]; o.c += (P)sb[1]; o.g += (P)sb[2]; o.t += (P)sb[3];
+  }
+  return o;
 }
 
 // BWT symbol at position i (FMIndex::getChar, src/fmindex.cpp:233-246)
@@ -181,7 +210,8 @@ __global__ __launch_bounds__(256) void k_find(FindArgs A) {
 
   u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
   u32 read = A.read_begin + (u32)(gid >> 2), o = (u32)gid & 3u;
-  u64 nocc = 0;
+  typedef typename PosOf<WIDE>::type P;
+  u32 nocc = 0;
   u32 nb = 0, flagbits = 0;
   bool live = read < A.read_end && ((A.chain_mask >> o) & 1u);  // overlap: 0xF, or 0x5 without the opposite strand; duplicate: 0x9
   u64 b0 = 0, L = 0;
@@ -193,10 +223,10 @@ __global__ __launch_bounds__(256) void k_find(FindArgs A) {
   if (live) {
     const bool pf = o < 2;  // primary index: fmi for chains 0,1; rfmi for 2,3 (overlap_builder.cpp:1120-1132)
     const FmRef F = fm_ref(A.fwd, 0), R = fm_ref(A.rev, 1);
-    const FmRef P = fm_pick(pf, F, R);
-    const FmRef O = fm_pick(pf, R, F);
-    const u64* CP = tb.C[P.which];
-    const u64* CO = tb.C[O.which];
+    const FmRef PI = fm_pick(pf, F, R);
+    const FmRef OI = fm_pick(pf, R, F);
+    const u64* CP = tb.C[PI.which];
+    const u64* CO = tb.C[OI.which];
     const bool comp = (o & 1u) != 0;            // chains 1 (revcomp) and 3 (complement)
     const bool fromStart = (o == 1 || o == 2);  // reversed strings are consumed from the read's first base
     const u32 af = o == 0 ? SIGAX_AF_CHAIN0 : o == 1 ? SIGAX_AF_CHAIN1 : o == 2 ? SIGAX_AF_CHAIN2 : SIGAX_AF_CHAIN3;
@@ -206,21 +236,21 @@ __global__ __launch_bounds__(256) void k_find(FindArgs A) {
     u32 r = base_rank(sq[fromStart ? 0 : L - 1]);
     if (comp) r = comp_rank(r);
     // IntervalPair::init (overlap_builder.cpp:91-94, fmindex.h:90-93)
-    u64 lo0 = CP[r], sz = tb.T[P.which][r], lo1 = CO[r];
+    P lo0 = (P)CP[r], sz = (P)tb.T[PI.which][r], lo1 = (P)CO[r];
     u32 s = 1;
     for (; s < L; ++s) {
       if (sz == 0) break;  // an empty range stays empty, nothing more can be emitted
-      Cnt4 l = fm_rank<WIDE>(P, lo0);
-      Cnt4 u = fm_rank<WIDE>(P, lo0 + sz);
+      const Cnt4P<P> l = fm_rank4p<WIDE>(PI, lo0);
+      const Cnt4P<P> u = fm_rank4p<WIDE>(PI, (P)(lo0 + sz));
       nocc += 2;
       u32 ch = sq[fromStart ? s : L - 1 - s];
-      u64 da = u.a - l.a, dc = u.c - l.c, dg = u.g - l.g, dt = u.t - l.t;
-      u64 dd = sz - (da + dc + dg + dt);  // '$' extensions
+      P da = u.a - l.a, dc = u.c - l.c, dg = u.g - l.g, dt = u.t - l.t;
+      P dd = sz - (da + dc + dg + dt);  // '$' extensions
       if (s >= A.minov && dd > 0) {
         // probe = ranges; probe.updateL('$') (overlap_builder.cpp:861-865): valid <=> dd > 0
-        u64 ld = lo0 - (l.a + l.c + l.g + l.t);
+        P ld = lo0 - (l.a + l.c + l.g + l.t);
         if (nb < A.cap - 1) {
-          store_block(slots + nb, ld, ld + dd - 1, lo1, lo1 + dd - 1, lo0, lo0 + sz - 1, lo1, lo1 + sz - 1, s, af);
+          store_block(slots + nb, ld, (u64)ld + dd - 1, lo1, (u64)lo1 + dd - 1, lo0, (u64)lo0 + sz - 1, lo1, (u64)lo1 + sz - 1, s, af);
         } else {
           flagbits |= 1u;  // cannot happen when cap was sized from the longest read
         }
@@ -229,22 +259,22 @@ __global__ __launch_bounds__(256) void k_find(FindArgs A) {
       r = base_rank(ch);
       if (comp) r = comp_rank(r);
       // ranges.updateL(c) (overlap_builder.cpp:112-122)
-      u64 acc, lc, dcur;
+      P acc, lc, dcur;
       if (r == 0)      { acc = 0;                 lc = lo0 - (l.a + l.c + l.g + l.t); dcur = dd; }
       else if (r == 1) { acc = dd;                lc = l.a; dcur = da; }
       else if (r == 2) { acc = dd + da;           lc = l.c; dcur = dc; }
       else if (r == 3) { acc = dd + da + dc;      lc = l.g; dcur = dg; }
       else             { acc = dd + da + dc + dg; lc = l.t; dcur = dt; }
       lo1 += acc;
-      lo0 = CP[r] + lc;
+      lo0 = (P)CP[r] + lc;
       sz = dcur;
     }
     if (sz != 0 && s >= L) {
       // full-length interval: substring test and containment block (overlap_builder.cpp:889-904)
-      Cnt4 l = fm_rank<WIDE>(P, lo0);
-      Cnt4 u = fm_rank<WIDE>(P, lo0 + sz);
-      Cnt4 lp = fm_rank<WIDE>(O, lo1);
-      Cnt4 up = fm_rank<WIDE>(O, lo1 + sz);
+      const Cnt4P<P> l = fm_rank4p<WIDE>(PI, lo0);
+      const Cnt4P<P> u = fm_rank4p<WIDE>(PI, (P)(lo0 + sz));
+      const Cnt4P<P> lp = fm_rank4p<WIDE>(OI, lo1);
+      const Cnt4P<P> up = fm_rank4p<WIDE>(OI, (P)(lo1 + sz));
       nocc += 4;
       bool dna = (u.a - l.a) | (u.c - l.c) | (u.g - l.g) | (u.t - l.t) | (up.a - lp.a) | (up.c - lp.c) | (up.g - lp.g) |
                  (up.t - lp.t);
@@ -253,9 +283,9 @@ __global__ __launch_bounds__(256) void k_find(FindArgs A) {
       } else {
         // no DNA extension on either side: all sz extensions are '$', so probe.updateL('$') keeps the whole
         // range and probe.updateR('$') reuses the two positions of rext.
-        u64 ld = lo0 - (l.a + l.c + l.g + l.t);
-        u64 lpd = lo1 - (lp.a + lp.c + lp.g + lp.t);
-        store_block(slots + (A.cap - 1), ld, ld + sz - 1, lpd, lpd + sz - 1, lo0, lo0 + sz - 1, lo1, lo1 + sz - 1, (u32)L, af);
+        P ld = lo0 - (l.a + l.c + l.g + l.t);
+        P lpd = lo1 - (lp.a + lp.c + lp.g + lp.t);
+        store_block(slots + (A.cap - 1), ld, (u64)ld + sz - 1, lpd, (u64)lpd + sz - 1, lo0, (u64)lo0 + sz - 1, lo1, (u64)lo1 + sz - 1, (u32)L, af);
         flagbits |= SIGAX_CC_CONTAIN;
       }
     }
@@ -264,7 +294,7 @@ __global__ __launch_bounds__(256) void k_find(FindArgs A) {
     u32 word = (nb & SIGAX_CC_COUNT_MASK) | (flagbits & (SIGAX_CC_SUBSTRING | SIGAX_CC_CONTAIN));
     A.chain_cnt[(u64)read * 4 + o] = word;
   }
-  u64 tot_occ = wave_sum(nocc);
+  u64 tot_occ = wave_sum((u64)nocc);
   u64 tot_blk = wave_sum((u64)nb + ((flagbits & SIGAX_CC_CONTAIN) ? 1u : 0u));
   u64 tot_err = wave_sum((u64)(flagbits & 1u));
   if ((threadIdx.x & 63) == 0) {
@@ -743,8 +773,6 @@ __global__ __launch_bounds__(256) void k_filter_extract(FxArgs A) {
 #define OCC_SIDE_SUB 0x40000000u
 #define OCC_SIDE_MASK 0x3FFFFFFFu
 
-template <bool WIDE> struct PosOf { typedef u32 type; };
-template <> struct PosOf<true> { typedef u64 type; };
 
 template <bool WIDE>
 struct SideSh {
