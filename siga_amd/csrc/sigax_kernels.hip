@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_find(FindArgs A) {
   __shared__ FmTables tb;
   fm_tables_load(tb, A.fwd, A.rev);
 
-  u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
+  u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   u32 read = A.read_begin + (u32)(gid >> 2), o = (u32)gid & 3u;
   typedef typename PosOf<WIDE>::type P;
   u32 nocc = 0;
@@ -1554,15 +1554,17 @@ void launch_correct(const CorrectArgs& a, bool wide, hipStream_t st) {
 
 void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
   if (a.read_end <= a.read_begin) return;
-  unsigned g = nblk((u64)(a.read_end - a.read_begin) * 4, 256);
+  static const char* envb = getenv("SIGAX_FIND_BLOCK");
+  const unsigned bs = envb ? (unsigned)atoi(envb) : 256u;
+  unsigned g = nblk((u64)(a.read_end - a.read_begin) * 4, bs);
   // Unused dynamic LDS caps the finder's residency (it saturates the memory request rate with few waves), leaving
   // wave slots and registers for the filter/extract kernel that runs beside it on the other stream.
   // Measured on MI355X at C2: 28 resident waves/CU 15.7 ms, 12 waves 14.5 ms, 8 waves 13.4 ms, 4 waves 14.9 ms.
   // 60 KB per workgroup = two workgroups (8 waves) per CU and 40 KB of LDS left for filter/extract workgroups.
   static const char* env = getenv("SIGAX_FIND_LDS");
   unsigned lds = env ? (unsigned)atoi(env) : 60000u;
-  if (wide) hipLaunchKernelGGL(k_find<true>, dim3(g), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL(k_find<false>, dim3(g), dim3(256), lds, st, a);
+  if (wide) hipLaunchKernelGGL(k_find<true>, dim3(g), dim3(bs), lds, st, a);
+  else hipLaunchKernelGGL(k_find<false>, dim3(g), dim3(bs), lds, st, a);
 }
 
 void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid32, unsigned grid64, hipStream_t st) {
