@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -434,39 +435,97 @@ uint64_t FMIndex::length() const {
 // ------------------------------------------------------------------------------------------------------
 // ASQG output
 // ------------------------------------------------------------------------------------------------------
-class OutFile {  // Utils::ofstream (src/utils.cpp:92-126): gzip when the name ends with .gz
+// Utils::ofstream (src/utils.cpp:92-126): gzip when the name ends with .gz.  The gzip stream is ONE member (what any
+// gzip reader, boost's gzip_decompressor included, accepts) whose deflate data is produced block-wise by a pool of
+// threads: every 1 MiB block is deflated on its own as raw deflate ending in a sync flush, the blocks are concatenated
+// in order and the CRC-32s are combined (the pigz scheme, without dictionary priming).
+class OutFile {
  public:
-  explicit OutFile(const std::string& path) : _gz(nullptr), _f(nullptr) {
-    if (path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0) _gz = gzopen(path.c_str(), "wb");
-    else _f = fopen(path.c_str(), "wb");
-    _buf.reserve(1 << 22);
+  explicit OutFile(const std::string& path) : _f(nullptr), _gz(false), _crc(0), _total(0) {
+    _gz = path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
+    _f = fopen(path.c_str(), "wb");
+    _buf.reserve(kFlush + (1 << 20));
+    if (_f && _gz) {
+      static const unsigned char hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
+      fwrite(hdr, 1, 10, _f);
+      _crc = crc32(0L, Z_NULL, 0);
+    }
   }
   ~OutFile() { close(); }
-  bool ok() const { return _gz || _f; }
+  bool ok() const { return _f != nullptr; }
   void write(const char* p, size_t n) {
     _buf.append(p, n);
-    if (_buf.size() >= (1 << 22)) flush();
+    if (_buf.size() >= kFlush) flush(false);
   }
   void write(const std::string& s) { write(s.data(), s.size()); }
-  void flush() {
-    if (_buf.empty()) return;
-    if (_gz) gzwrite(_gz, _buf.data(), (unsigned)_buf.size());
-    else if (_f) fwrite(_buf.data(), 1, _buf.size(), _f);
-    _buf.clear();
-  }
   bool close() {
-    flush();
-    bool ok = true;
-    if (_gz) ok = gzclose(_gz) == Z_OK;
-    if (_f) ok = fclose(_f) == 0;
-    _gz = nullptr;
+    if (!_f) return true;
+    flush(true);
+    if (_gz) {
+      unsigned char tail[8];
+      uint32_t c = (uint32_t)_crc, n = (uint32_t)_total;
+      for (int i = 0; i < 4; ++i) { tail[i] = (unsigned char)(c >> (8 * i)); tail[4 + i] = (unsigned char)(n >> (8 * i)); }
+      fwrite(tail, 1, 8, _f);
+    }
+    bool ok = fclose(_f) == 0;
     _f = nullptr;
     return ok;
   }
 
  private:
-  gzFile _gz;
+  static const size_t kBlock = 1 << 20, kFlush = 64u << 20;
+  static void deflate_block(const char* in, size_t n, bool last, std::string* out, uLong* crc) {
+    z_stream z;
+    memset(&z, 0, sizeof(z));
+    deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    out->resize(deflateBound(&z, (uLong)n) + 16);
+    z.next_in = (Bytef*)in;
+    z.avail_in = (uInt)n;
+    z.next_out = (Bytef*)&(*out)[0];
+    z.avail_out = (uInt)out->size();
+    deflate(&z, last ? Z_FINISH : Z_SYNC_FLUSH);
+    out->resize(out->size() - z.avail_out);
+    deflateEnd(&z);
+    *crc = crc32(crc32(0L, Z_NULL, 0), (const Bytef*)in, (uInt)n);
+  }
+  void flush(bool last) {
+    if (!_f) return;
+    if (!_gz) {
+      if (!_buf.empty()) fwrite(_buf.data(), 1, _buf.size(), _f);
+      _buf.clear();
+      return;
+    }
+    size_t nblocks = (_buf.size() + kBlock - 1) / kBlock;
+    if (nblocks == 0 && last) nblocks = 1;  // an empty final block terminates the deflate stream
+    std::vector<std::string> outs(nblocks);
+    std::vector<uLong> crcs(nblocks, 0);
+    std::atomic<size_t> next(0);
+    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32);
+    nt = (unsigned)std::min<size_t>(nt, nblocks);
+    auto work = [&] {
+      while (true) {
+        size_t i = next.fetch_add(1);
+        if (i >= nblocks) break;
+        size_t b = i * kBlock, e = std::min(_buf.size(), b + kBlock);
+        deflate_block(_buf.data() + b, e > b ? e - b : 0, last && i + 1 == nblocks, &outs[i], &crcs[i]);
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    for (size_t i = 0; i < nblocks; ++i) {
+      size_t b = i * kBlock, e = std::min(_buf.size(), b + kBlock);
+      fwrite(outs[i].data(), 1, outs[i].size(), _f);
+      _crc = crc32_combine(_crc, crcs[i], (z_off_t)(e > b ? e - b : 0));
+    }
+    _total += _buf.size();
+    _buf.clear();
+  }
   FILE* _f;
+  bool _gz;
+  uLong _crc;
+  uint64_t _total;
   std::string _buf;
 };
 
@@ -573,9 +632,21 @@ static void write_edge(std::string& o, const sigax_edge& e, const DNASeqList& re
 
 static bool set_read_info(const FMIndex* fmi, const DNASeqList& reads, std::string* error);
 
+struct PhaseTimer {  // SIGA_TIMING=1: phase times on stderr
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  PhaseTimer() : on(getenv("SIGA_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void lap(const char* what) {
+    auto n = std::chrono::steady_clock::now();
+    if (on) fprintf(stderr, "[siga] %-28s %8.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+
 bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const std::string& output, size_t threads,
                            size_t batch, size_t* processed) const {
   (void)processed;  // accepted and never written, like the reference (src/overlap_builder.cpp:423-424)
+  PhaseTimer pt;
   _error.clear();
   if (!_fmi || !_fmi->handle()) {
     _error = "FMIndex not loaded";
@@ -598,9 +669,19 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
   }
   const size_t n = reads.size();
   // ReadInfo{name,length} for the edge converter (src/overlap_builder.cpp:333-343) as lengths + name ranks
+  pt.lap("parse reads");
   if (!set_read_info(_fmi, reads, &_error)) return false;
+  pt.lap("read info (name ranks)");
   uint32_t flags = SIGAX_EDGES | (_irreducible ? SIGAX_IRREDUCIBLE : 0u) | (_rc ? SIGAX_RC : 0u);
-  size_t per = std::max<size_t>(std::max<size_t>(threads, 1) * std::max<size_t>(batch, 1), 131072);
+  // one device batch object for the whole run (its arenas are allocated once); the reference's threads*batch is a
+  // lower bound for the device batch size, which defaults to up to a million reads
+  size_t per = std::max<size_t>(std::max<size_t>(threads, 1) * std::max<size_t>(batch, 1), 1u << 20);
+  per = std::min(per, std::max<size_t>(n, 1));
+  sigax_batch* dev = nullptr;
+  if (sigax_batch_create(_fmi->handle(), (uint32_t)per, 0, 0, &dev) != SIGAX_OK) {
+    _error = std::string("overlap failed: ") + sigax_last_error();
+    return false;
+  }
   std::vector<sigax_edge> edges;
   std::string seqs, text;
   std::vector<uint64_t> offs;
@@ -613,18 +694,24 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
       offs.push_back(seqs.size());
     }
     sigax_result res;
-    int rc = sigax_overlap_batch(_fmi->handle(), seqs.data(), offs.data(), (uint32_t)cnt, (uint32_t)base,
-                                 (uint32_t)minOverlap, flags, &res);
+    int rc = sigax_batch_upload(dev, seqs.data(), offs.data(), (uint32_t)cnt, nullptr);
+    if (rc == SIGAX_OK) rc = sigax_batch_run(dev, (uint32_t)base, (uint32_t)minOverlap, flags, nullptr);
+    if (rc == SIGAX_OK) rc = sigax_batch_finish(dev, nullptr, nullptr);
+    if (rc == SIGAX_OK) rc = sigax_batch_download(dev, &res);
     if (rc != SIGAX_OK) {
       _error = std::string("overlap failed: ") + sigax_last_error();
+      sigax_batch_destroy(dev);
       return false;
     }
+    pt.lap("GPU batch (upload..download)");
     text.clear();
     for (size_t i = 0; i < cnt; ++i) write_vertex(text, reads[base + i], res.substring[i] != 0);
     out.write(text);
     edges.insert(edges.end(), res.edges, res.edges + res.n_edges);
     sigax_result_free(&res);
+    pt.lap("VT lines");
   }
+  sigax_batch_destroy(dev);
   text.clear();
   for (const sigax_edge& e : edges) {
     write_edge(text, e, reads);
@@ -638,6 +725,7 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
     _error = "Failed to write ASQG " + output;
     return false;
   }
+  pt.lap("ED lines + close");
   return true;
 }
 
