@@ -552,7 +552,6 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   // slots per chain: overlaps of length max(m,1)..L-1, plus one for the containment block
   uint32_t mm = std::max<uint32_t>(b->minov, 1u);
   b->cap = (b->cur_max_len > mm ? b->cur_max_len - mm : 0u) + 1u;
-  if (const char* ov = getenv("SIGAX_CAP_EXPERIMENT")) b->cap = (uint32_t)atoi(ov);  // measurement aid only
   int rc;
   if ((rc = ensure(&b->arena, (size_t)n * 4 * b->cap * sizeof(sigax_block))) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->chain_cnt, (size_t)n * 4 * 4)) != SIGAX_OK) return rc;

@@ -792,12 +792,7 @@ __device__ __forceinline__ u64 readlane64(u64 v, u32 l) {
 // Tell the compiler a value is the same in every lane (it cannot see that for values derived from the wave index or
 // loaded through vector memory / LDS): keeps loop counters, masks and branch conditions in SGPRs.
 __device__ __forceinline__ u32 uni(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ u64 uni64(u64 v) {
-  return ((u64)__builtin_amdgcn_readfirstlane((u32)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)v);
-}
 
-__device__ __forceinline__ u32 readlaneP(u32 v, u32 l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ __forceinline__ u64 readlaneP(u64 v, u32 l) { return readlane64(v, l); }
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -1554,8 +1549,7 @@ void launch_correct(const CorrectArgs& a, bool wide, hipStream_t st) {
 
 void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
   if (a.read_end <= a.read_begin) return;
-  static const char* envb = getenv("SIGAX_FIND_BLOCK");
-  const unsigned bs = envb ? (unsigned)atoi(envb) : 256u;
+  const unsigned bs = 256u;
   unsigned g = nblk((u64)(a.read_end - a.read_begin) * 4, bs);
   // Unused dynamic LDS caps the finder's residency (it saturates the memory request rate with few waves), leaving
   // wave slots and registers for the filter/extract kernel that runs beside it on the other stream.
