@@ -21,6 +21,7 @@ def lib():
         L.sigah_overlap_file.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_int, C.c_int, C.c_uint64,
                                          C.c_uint64, C.c_int, C.c_char_p, C.c_uint64]
         L.sigah_stem.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64]
+        L.sigah_write_file.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64]
         L.sigah_correct_file.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                          C.c_int, C.c_char_p, C.c_uint64]
         L.sigah_rmdup_file.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_uint64]
@@ -65,6 +66,12 @@ def correct_file(reads_path, prefix, output, k=31, threshold=3, rounds=10, offse
     if lib().sigah_correct_file(reads_path.encode(), prefix.encode(), output.encode(), k, threshold, rounds, offset, device,
                                 err, 512) != 0:
         raise RuntimeError("siga correct failed: " + err.value.decode())
+
+
+def write_file(path, data, pieces=1):
+    """The host library's output stream (multi-threaded single-member gzip when the name ends with .gz)."""
+    if lib().sigah_write_file(path.encode(), data, len(data), pieces) != 0:
+        raise IOError("cannot write " + path)
 
 
 def stem(path):

@@ -996,6 +996,15 @@ int sigah_correct_file(const char* reads_path, const char* prefix, const char* o
   return 0;
 }
 
+// Utils::ofstream as used for <prefix>.asqg.gz: write `n` bytes in `pieces` write() calls (gz when the name ends with .gz)
+int sigah_write_file(const char* path, const char* data, uint64_t n, uint64_t pieces) {
+  sigah::OutFile out(path);
+  if (!out.ok()) return -1;
+  uint64_t step = pieces ? (n + pieces - 1) / pieces : n;
+  for (uint64_t b = 0; b < n; b += step ? step : 1) out.write(data + b, (size_t)std::min<uint64_t>(step, n - b));
+  return out.close() ? 0 : -1;
+}
+
 void sigah_stem(const char* path, char* out, uint64_t cap) { snprintf(out, cap, "%s", sigah::Utils::stem(path).c_str()); }
 
 }  // extern "C"

@@ -27,9 +27,9 @@ def gather_edges(local_edges, group=None, dst=0):
     rank = dist.get_rank(group)
     dev = local_edges.device
     cnt = torch.tensor([local_edges.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, cnt, group=group)
-    counts = [int(c.item()) for c in counts]
+    allc = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allc, cnt, group=group)
+    counts = [int(c) for c in allc.tolist()]  # one device->host sync for all ranks' counts
     mx = max(max(counts), 1)
     padded = torch.zeros((mx, 4), dtype=torch.int32, device=dev)
     padded[: local_edges.shape[0]] = local_edges

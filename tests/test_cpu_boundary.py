@@ -118,3 +118,25 @@ def test_parallel_suffix_sort_equals_sais(tmp_path):
     host.index_file(fx.fa, prefix, threads=4)
     for ext in (".bwt", ".rbwt", ".sai", ".rsai"):
         assert open(prefix + ext, "rb").read() == open(fx.prefix + ext, "rb").read(), ext
+
+
+def test_gzip_writer_single_member_roundtrip(tmp_path):
+    """The ASQG writer's gzip stream: one member, valid for zlib/gzip, across block (1 MiB) and flush (64 MiB) edges."""
+    import gzip
+    import zlib
+    rng = np.random.default_rng(3)
+    line = b"ED\tr123 r45 0 104 150 45 149 150 0 0\n"
+    for n, pieces in ((0, 1), (1, 1), (len(line) * 1000, 7), ((1 << 20) + 17, 3), (70 << 20, 41)):
+        data = (line * (n // len(line) + 1))[:n]
+        if n > 100:
+            noise = rng.integers(65, 90, size=min(n, 1 << 16), dtype=np.uint8).tobytes()
+            data = noise + data[len(noise):]
+        path = str(tmp_path / ("x%d.gz" % n))
+        host.write_file(path, data, pieces)
+        assert gzip.open(path, "rb").read() == data
+        raw = open(path, "rb").read()
+        d = zlib.decompressobj(16 + zlib.MAX_WBITS)  # exactly one gzip member, nothing after it
+        assert d.decompress(raw) == data and d.eof and d.unused_data == b""
+    plain = str(tmp_path / "x.txt")
+    host.write_file(plain, line * 10, 3)
+    assert open(plain, "rb").read() == line * 10
