@@ -849,7 +849,7 @@ struct GFx {
       : A(a), tb(t), sh(s), F(fm_ref(a.fwd, 0)), R(fm_ref(a.rev, 1)), wpool(wp), lane(threadIdx.x & 63u),
         gb(W == 64 ? 0u : (threadIdx.x & 32u)), gl(W == 64 ? (threadIdx.x & 63u) : (threadIdx.x & 31u)),
         glt((1ull << (W == 64 ? (threadIdx.x & 63u) : (threadIdx.x & 31u))) - 1ull), slots(nullptr), nout(0), nocc(0),
-        xerror(false), fin_cur(0), fin_end(0) {}
+        xerror(false), fin_cur(0), fin_end(0), nslot(1), ni(0), gAlive(0), gD(0), gI(0) {}
 
   // ---- lane-group primitives: a group is the whole wave (W == 64) or one half of it (W == 32) ----
   __device__ u64 gballot(bool p) const {
@@ -908,97 +908,254 @@ struct GFx {
     e.c1hi = pb + ub - 1;
   }
 
-  // IrreducibleBlockListExtractor::extract (overlap_builder.cpp:711-809) over the n entries held one per group lane,
-  // already sorted by length descending.  Returns false when the item has to be redone by a wider kernel.
-  // The group table lives in VGPR lanes of the group: lane s holds slot s's alive mask, lane i holds the i-th group
-  // of the list (gD) / of this pass's incomings (gI).  Every scalar of the algorithm (ng, p, slot, masks) is a
-  // per-lane value that is equal across the lane group, so two groups of one wave can be at different points.
-  __device__ bool extract(E e, u32 n) {
-    if (n == 0) return true;
+  // ---- IrreducibleBlockListExtractor::extract (overlap_builder.cpp:711-809) ----
+  // The group table lives in VGPR lanes of the lane group: lane s holds slot s's alive mask (gAlive), lane i holds
+  // the i-th group of the list (gD) / of this pass's incomings (gI).  Every scalar of the algorithm (ng, p, slot,
+  // masks) is a per-lane value that is equal across the lane group, so two lane groups of one wave can be at
+  // different points of their extractions.
+  u32 nslot, ni;  // slots handed out, incomings of the current pass
+  u64 gAlive;
+  u32 gD, gI;
+
+  enum { RD_ENDED = 0, RD_UPDATED, RD_BRANCHED, RD_BAIL, RD_XERROR };
+
+  // One extension round of one group (the body of the loop at :728-802).  `alive` = the group's blocks, in lane order.
+  // RD_UPDATED: the blocks were right-extended in place, *newAlive = those still valid.  RD_ENDED / RD_BRANCHED: the
+  // group is finished (top-level blocks emitted, or copies pushed to the incomings).
+  __device__ int round(E& e, u64 alive, u64* newAlive) {
     const u32 OUTCAP = W == 64 ? FX_OUTCAP : FX_OUTCAP / 2;
     const u32 NSLOT = W == 64 ? FX_NSLOT : 32 < FX_NSLOT ? 32 : FX_NSLOT;
-    u32 cur = 0, ng = 1, nslot = 1;
-    u64 gAlive = gl == 0 ? (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) : 0ull;
-    u32 gD = 0, gI = 0;
+    const bool mine = (alive >> gl) & 1ull;
+    const u32 first = ffs0(alive);
+    const u32 topLen = gshfl(e.len, first);
+    const bool isTop = mine && e.len == topLen;
+    const FmRef ix = ext_index(e.src);
+    const bool qcomp = (af_of(e.src) & 4u) != 0;
+    P l[5] = {0, 0, 0, 0, 0}, u[5] = {0, 0, 0, 0, 0};
+    if (mine) {
+      fm_rank5p<WIDE>(ix, e.c1lo, l);
+      fm_rank5p<WIDE>(ix, (P)(e.c1hi + 1), u);
+    }
+    // OverlapBlock::ext (overlap_builder.cpp:181-187), complemented for QUERYCOMP blocks
+    const bool x0 = mine && (u[0] != l[0]);
+    const bool xa = mine && (qcomp ? (u[4] != l[4]) : (u[1] != l[1]));
+    const bool xc = mine && (qcomp ? (u[3] != l[3]) : (u[2] != l[2]));
+    const bool xg = mine && (qcomp ? (u[2] != l[2]) : (u[3] != l[3]));
+    const bool xt = mine && (qcomp ? (u[1] != l[1]) : (u[4] != l[4]));
+    const u64 topMask = gballot(isTop);
+    if (gballot(isTop && x0)) {
+      // the top-level block has ended: emit the top-level blocks in list order (:747-766)
+      u64 bad = gballot(isTop && !x0);
+      u64 emitMask = topMask;
+      if (bad) emitMask &= (1ull << ffs0(bad)) - 1ull;
+      nocc += 2u * pop(topMask);
+      u32 ne = pop(emitMask);
+      if (nout + ne > OUTCAP) return RD_BAIL;
+      if ((emitMask >> gl) & 1ull) {
+        E br = e;
+        apply_updateR(br, 0, ix.which, l, u);
+        out_put(nout + pop(emitMask & glt), br);
+      }
+      nout += ne;
+      if (bad) {
+        xerror = true;  // "substring read found during overlap computation" (:754-757): extract() returns false
+        return RD_XERROR;
+      }
+      return RD_ENDED;
+    }
+    nocc += 2u * pop(alive);
+    u64 any0 = gballot(x0), any1 = gballot(xa), any2 = gballot(xc), any3 = gballot(xg), any4 = gballot(xt);
+    u32 nz = (any0 != 0) + (any1 != 0) + (any2 != 0) + (any3 != 0) + (any4 != 0);
+    if (nz == 1) {
+      u32 c = any0 ? 0u : any1 ? 1u : any2 ? 2u : any3 ? 3u : 4u;
+      u32 b = qcomp ? comp_rank(c) : c;
+      if (mine) apply_updateR(e, b, ix.which, l, u);
+      bool ok = mine && valid(e.c0lo, e.c0hi) && valid(e.c1lo, e.c1hi);
+      *newAlive = gballot(ok);
+      return RD_UPDATED;
+    }
+    for (u32 c = 0; c < 5; ++c) {
+      u64 ak = c == 0 ? any0 : c == 1 ? any1 : c == 2 ? any2 : c == 3 ? any3 : any4;
+      if (!ak) continue;
+      if (nslot >= NSLOT || ni >= NSLOT) return RD_BAIL;
+      u32 ns = nslot++;
+      E br = e;
+      u32 b = qcomp ? comp_rank(c) : c;
+      if (mine) apply_updateR(br, b, ix.which, l, u);
+      bool ok = mine && valid(br.c0lo, br.c0hi) && valid(br.c1lo, br.c1hi);
+      if (ok) pool_put(wpool + ns * 64 + lane, br);
+      u64 m = gballot(ok);
+      if (gl == ns) gAlive = m;
+      if (gl == ni) gI = ns;
+      ++ni;
+    }
+    return RD_BRANCHED;
+  }
+
+  // The usual round, cheaply.  When every alive block's capped[1] range lies inside one rank granule, which symbols
+  // follow the range is a bit test on the granule's planes (no counting), and when exactly one symbol c follows all
+  // blocks, IntervalPair::updateR(b) collapses: every extension of a block is b, so diff[k < b] = 0 and diff[b] = the
+  // range size, i.e. capped[0] does not move and capped[1] = C[b] + Occ(b, lower - 1) keeps its size: one symbol's rank
+  // at one position.  Anything else (range across granules, a branch, '$' as the single symbol) goes to round().
+  __device__ int round_fast(E& e, u64 alive, u64* newAlive) {
+    const u32 OUTCAP = W == 64 ? FX_OUTCAP : FX_OUTCAP / 2;
+    const bool mine = (alive >> gl) & 1ull;
+    const FmRef ix = ext_index(e.src);
+    const u64 p0 = (u64)e.c1lo, p1 = (u64)e.c1hi + 1ull;  // [p0, p1) in the extension index
+    const u64 g0 = p0 >> 7;
+    const bool inside = mine && p1 > p0 && ((p1 - 1) >> 7) == g0 && p1 <= ix.n;
+    if (gballot(mine && !inside)) return round(e, alive, newAlive);
+    const u32 first = ffs0(alive);
+    const u32 topLen = gshfl(e.len, first);
+    const bool isTop = mine && e.len == topLen;
+    const bool qcomp = (af_of(e.src) & 4u) != 0;
+    uint4 k[4];
+    k[0] = k[1] = k[2] = k[3] = make_uint4(0, 0, 0, 0);
+    if (mine) {
+      const uint4* q = ix.g + g0 * 4;
+      k[0] = q[0]; k[1] = q[1]; k[2] = q[2]; k[3] = q[3];
+    }
+    const int r0 = (int)(p0 & 127u), r1 = (int)(p1 - (g0 << 7));  // 0 <= r0 < r1 <= 128
+    u32 lom[4], pa = 0, pc = 0, pg = 0, pt = 0, pd = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int t0 = r0 - 32 * j, t1 = r1 - 32 * j;
+      u32 m0 = t0 >= 32 ? 0xFFFFFFFFu : (t0 <= 0 ? 0u : ((1u << t0) - 1u));
+      u32 m1 = t1 >= 32 ? 0xFFFFFFFFu : (t1 <= 0 ? 0u : ((1u << t1) - 1u));
+      u32 rm = m1 & ~m0;
+      lom[j] = m0;
+      u32 y = k[j].y, z = k[j].z, w = k[j].w;
+      pa |= y & ~z & rm;
+      pc |= z & ~y & rm;
+      pg |= y & z & rm;
+      pt |= w & rm;
+      pd |= ~(y | z | w) & rm;
+    }
+    // OverlapBlock::ext > 0 per symbol, complemented for QUERYCOMP blocks (overlap_builder.cpp:181-187)
+    const bool x0 = mine && pd != 0;
+    const bool xa = mine && (qcomp ? pt : pa) != 0;
+    const bool xc = mine && (qcomp ? pg : pc) != 0;
+    const bool xg = mine && (qcomp ? pc : pg) != 0;
+    const bool xt = mine && (qcomp ? pa : pt) != 0;
+    if (gballot(isTop && x0)) {
+      // the top-level block has ended (:747-766): capped.updateR('$') needs Occ('$') at both ends of the range
+      const u64 topMask = gballot(isTop);
+      u64 bad = gballot(isTop && !x0);
+      u64 emitMask = topMask;
+      if (bad) emitMask &= (1ull << ffs0(bad)) - 1ull;
+      nocc += 2u * pop(topMask);
+      u32 ne = pop(emitMask);
+      if (nout + ne > OUTCAP) return RD_BAIL;
+      if ((emitMask >> gl) & 1ull) {
+        u32 below = k[0].x + k[1].x + k[2].x + k[3].x, nd = 0;  // A+C+G+T before the granule, then inside up to p0
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int t1 = r1 - 32 * j;
+          u32 m1 = t1 >= 32 ? 0xFFFFFFFFu : (t1 <= 0 ? 0u : ((1u << t1) - 1u));
+          u32 y = k[j].y, z = k[j].z, w = k[j].w;
+          below += __popc((y | z | w) & lom[j]);
+          nd += __popc(~(y | z | w) & m1 & ~lom[j]);
+        }
+        P acgt = (P)below;
+        if (WIDE) {
+          const u64* sb = ix.super + (p0 >> SIGAX_SUPER_SHIFT) * 4;
+          acgt += (P)(sb[0] + sb[1] + sb[2] + sb[3]);
+        }
+        const P ld = (P)p0 - acgt;  // Occ('$', lower - 1); C['$'] = 0
+        E br = e;
+        br.c0hi = br.c0lo + (P)nd - 1;
+        br.c1lo = ld;
+        br.c1hi = ld + (P)nd - 1;
+        out_put(nout + pop(emitMask & glt), br);
+      }
+      nout += ne;
+      if (bad) {
+        xerror = true;
+        return RD_XERROR;
+      }
+      return RD_ENDED;
+    }
+    const u64 any0 = gballot(x0), any1 = gballot(xa), any2 = gballot(xc), any3 = gballot(xg), any4 = gballot(xt);
+    const u32 nz = (any0 != 0) + (any1 != 0) + (any2 != 0) + (any3 != 0) + (any4 != 0);
+    if (nz != 1 || any0) return round(e, alive, newAlive);
+    nocc += 2u * pop(alive);
+    const u32 c = any1 ? 1u : any2 ? 2u : any3 ? 3u : 4u;
+    const u32 b = qcomp ? 5u - c : c;
+    if (mine) {
+      u32 lb = b == 1 ? k[0].x : b == 2 ? k[1].x : b == 3 ? k[2].x : k[3].x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u32 y = k[j].y, z = k[j].z, w = k[j].w;
+        u32 bits = b == 1 ? (y & ~z) : b == 2 ? (z & ~y) : b == 3 ? (y & z) : w;
+        lb += __popc(bits & lom[j]);
+      }
+      P lbp = (P)lb;
+      if (WIDE) lbp += (P)ix.super[(p0 >> SIGAX_SUPER_SHIFT) * 4 + (b - 1)];
+      const P size = e.c1hi - e.c1lo;
+      e.c1lo = (P)tb.C[ix.which][b] + lbp;
+      e.c1hi = e.c1lo + size;
+    }
+    *newAlive = alive;
+    return RD_UPDATED;
+  }
+
+  // extract() over the n entries held one per group lane, already sorted by length descending.  Returns false when
+  // the item has to be redone by a wider kernel.
+  __device__ bool extract(E e, u32 n) {
+    if (n == 0) return true;
+    const u32 NSLOT = W == 64 ? FX_NSLOT : 32 < FX_NSLOT ? 32 : FX_NSLOT;
+    nslot = 1;
+    ni = 0;
+    gAlive = 0;
+    gD = 0;
+    gI = 0;
+    // Phase 1: a single group (the usual case: every overlapping read agrees on the next base).  With one group the
+    // stride-2 ring walk of :728-802 visits it over and over, so this is a plain loop with the group in registers.
+    {
+      u64 alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+      u32 guard = 0;
+      while (alive) {
+        u64 na = 0;
+        int st = round_fast(e, alive, &na);
+        if (st == RD_BAIL) return false;
+        if (st == RD_XERROR) return true;
+        if (st != RD_UPDATED) break;
+        alive = na;
+        if (++guard > (1u << 20)) return false;
+      }
+    }
+    if (ni == 0) return true;
+    // Phase 2: the group branched.  General form: groups in a list, walked as the reference's loop walks it.
+    u32 cur = 0xFFFFFFFFu, ng = 0;
+    for (u32 i = 0; i < ni; ++i) {
+      u32 v = gshfl(gI, i);
+      if (gl == ng) gD = v;
+      ++ng;
+    }
     u32 guard = 0;
     while (ng > 0) {
-      u32 ni = 0, p = 0;
+      ni = 0;
+      u32 p = 0;
       while (p != ng) {
         const u32 slot = gshfl(gD, p);
         const u64 alive = gshfl(gAlive, slot);
         if (slot != cur) {
-          const u64 was = gshfl(gAlive, cur);
-          if ((was >> gl) & 1ull) pool_put(wpool + cur * 64 + lane, e);
+          if (cur != 0xFFFFFFFFu) {
+            const u64 was = gshfl(gAlive, cur);
+            if ((was >> gl) & 1ull) pool_put(wpool + cur * 64 + lane, e);
+          }
           if ((alive >> gl) & 1ull) pool_get(e, wpool + slot * 64 + lane);
           cur = slot;
         }
         bool eraseGroup = true;
         if (alive) {
-          const bool mine = (alive >> gl) & 1ull;
-          const u32 first = ffs0(alive);
-          const u32 topLen = gshfl(e.len, first);
-          const bool isTop = mine && e.len == topLen;
-          const FmRef ix = ext_index(e.src);
-          const bool qcomp = (af_of(e.src) & 4u) != 0;
-          P l[5] = {0, 0, 0, 0, 0}, u[5] = {0, 0, 0, 0, 0};
-          if (mine) {
-            fm_rank5p<WIDE>(ix, e.c1lo, l);
-            fm_rank5p<WIDE>(ix, (P)(e.c1hi + 1), u);
-          }
-          // OverlapBlock::ext (overlap_builder.cpp:181-187), complemented for QUERYCOMP blocks
-          const bool x0 = mine && (u[0] != l[0]);
-          const bool xa = mine && (qcomp ? (u[4] != l[4]) : (u[1] != l[1]));
-          const bool xc = mine && (qcomp ? (u[3] != l[3]) : (u[2] != l[2]));
-          const bool xg = mine && (qcomp ? (u[2] != l[2]) : (u[3] != l[3]));
-          const bool xt = mine && (qcomp ? (u[1] != l[1]) : (u[4] != l[4]));
-          const u64 topMask = gballot(isTop);
-          if (gballot(isTop && x0)) {
-            // the top-level block has ended: emit the top-level blocks in list order (:747-766)
-            u64 bad = gballot(isTop && !x0);
-            u64 emitMask = topMask;
-            if (bad) emitMask &= (1ull << ffs0(bad)) - 1ull;
-            nocc += 2u * pop(topMask);
-            u32 ne = pop(emitMask);
-            if (nout + ne > OUTCAP) return false;
-            if ((emitMask >> gl) & 1ull) {
-              E br = e;
-              apply_updateR(br, 0, ix.which, l, u);
-              out_put(nout + pop(emitMask & glt), br);
-            }
-            nout += ne;
-            if (bad) {
-              xerror = true;  // "substring read found during overlap computation" (:754-757): extract() returns
-              return true;
-            }
-          } else {
-            nocc += 2u * pop(alive);
-            u64 any0 = gballot(x0), any1 = gballot(xa), any2 = gballot(xc), any3 = gballot(xg), any4 = gballot(xt);
-            u32 nz = (any0 != 0) + (any1 != 0) + (any2 != 0) + (any3 != 0) + (any4 != 0);
-            if (nz == 1) {
-              u32 c = any0 ? 0u : any1 ? 1u : any2 ? 2u : any3 ? 3u : 4u;
-              u32 b = qcomp ? comp_rank(c) : c;
-              if (mine) apply_updateR(e, b, ix.which, l, u);
-              bool ok = mine && valid(e.c0lo, e.c0hi) && valid(e.c1lo, e.c1hi);
-              u64 m = gballot(ok);
-              if (gl == slot) gAlive = m;
-              eraseGroup = false;
-            } else {
-              for (u32 c = 0; c < 5; ++c) {
-                u64 ak = c == 0 ? any0 : c == 1 ? any1 : c == 2 ? any2 : c == 3 ? any3 : any4;
-                if (!ak) continue;
-                if (nslot >= NSLOT || ni >= NSLOT) return false;
-                u32 ns = nslot++;
-                E br = e;
-                u32 b = qcomp ? comp_rank(c) : c;
-                if (mine) apply_updateR(br, b, ix.which, l, u);
-                bool ok = mine && valid(br.c0lo, br.c0hi) && valid(br.c1lo, br.c1hi);
-                if (ok) pool_put(wpool + ns * 64 + lane, br);
-                u64 m = gballot(ok);
-                if (gl == ns) gAlive = m;
-                if (gl == ni) gI = ns;
-                ++ni;
-              }
-            }
+          u64 na = 0;
+          int st = round_fast(e, alive, &na);
+          if (st == RD_BAIL) return false;
+          if (st == RD_XERROR) return true;
+          if (st == RD_UPDATED) {
+            if (gl == slot) gAlive = na;
+            eraseGroup = false;
           }
         }
         // body `i = erase(i)` / `++i`, then the loop header's `++i` on the ring [g0..g(k-1), end]
