@@ -828,8 +828,11 @@ struct GFx {
   typedef typename PosOf<WIDE>::type P;
   struct E {  // a block's capped pair in registers
     P c0lo, c0hi, c1lo, c1hi;
-    u32 src, len;
+    u32 src;  // bits 30-31: which find produced it (0..3); bits 0-29: slot in the read's candidate region
+    u32 len;
   };
+  static __device__ u32 slot_of(u32 src) { return src & 0x3FFFFFFFu; }
+  static __device__ u32 find_of(u32 src) { return src >> 30; }
   const FxArgs& A;
   const FmTables& tb;
   SideSh<WIDE>& sh;
@@ -867,13 +870,14 @@ struct GFx {
   static __device__ bool valid(P lo, P hi) { return hi != (P)~(P)0 && hi >= lo; }  // fmindex.h:87-89
 
   __device__ u32 af_of(u32 src) const {
-    u32 ch = src / A.cap;
+    u32 ch = find_of(src);
     return ch == 0 ? SIGAX_AF_CHAIN0 : ch == 1 ? SIGAX_AF_CHAIN1 : ch == 2 ? SIGAX_AF_CHAIN2 : SIGAX_AF_CHAIN3;
   }
-  __device__ FmRef ext_index(u32 src) const { return fm_pick((src / A.cap) < 2, R, F); }
+  // OverlapBlock::index (overlap_builder.cpp:177-179): !TARGETREV ? rfmi : fmi.  Finds 0,1 are !TARGETREV.
+  __device__ FmRef ext_index(u32 src) const { return fm_pick(find_of(src) < 2, R, F); }
 
   __device__ void load_block(E& e, u32 src) const {
-    const ulonglong2* b = reinterpret_cast<const ulonglong2*>(slots + src);
+    const ulonglong2* b = reinterpret_cast<const ulonglong2*>(slots + slot_of(src));
     ulonglong2 c0 = b[0], c1 = b[1], t = b[4];
     e.c0lo = (P)c0.x; e.c0hi = (P)c0.y; e.c1lo = (P)c1.x; e.c1hi = (P)c1.y;
     e.src = src; e.len = (u32)t.x;
@@ -1198,7 +1202,7 @@ struct GFx {
       u64 m = gballot(has);
       if (has) {
         E e;
-        load_block(e, gl * A.cap + (A.cap - 1));
+        load_block(e, (gl << 30) | (gl * A.cap + (A.cap - 1)));
         out_put(pop(m & glt), e);
       }
       nout = pop(m);
@@ -1216,8 +1220,11 @@ struct GFx {
     const u32 k = list ? gl - nX : gl;
     u32 src = 0;
     if (active) {
-      if (!list) src = k < nA ? chA * A.cap + k : ((k == nA && c0) ? 0u : 1u) * A.cap + (A.cap - 1);
-      else src = k < nB ? chB * A.cap + k : ((k == nB && c2) ? 2u : 3u) * A.cap + (A.cap - 1);
+      u32 ch;
+      if (!list) ch = k < nA ? chA : ((k == nA && c0) ? 0u : 1u);
+      else ch = k < nB ? chB : ((k == nB && c2) ? 2u : 3u);
+      const u32 inchain = (!list ? k < nA : k < nB) ? k : A.cap - 1;
+      src = (ch << 30) | (ch * A.cap + inchain);
     }
     E e;
     e.c0lo = e.c0hi = e.c1lo = e.c1hi = 0; e.src = 0; e.len = 0;
@@ -1302,7 +1309,7 @@ struct GFx {
       if (gl == 0) A.item_base[2ull * r + sd] = base;
       if (gl < nout && base + gl < A.fin_cap) {
         const u32 src = sh.osrc[lane];
-        const ulonglong2* b = reinterpret_cast<const ulonglong2*>(slots + src);
+        const ulonglong2* b = reinterpret_cast<const ulonglong2*>(slots + slot_of(src));
         ulonglong2 r0 = b[2], r1 = b[3], t4 = b[4];
         ulonglong2* d = reinterpret_cast<ulonglong2*>(A.fin + base + gl);
         d[0] = make_ulonglong2(widen(sh.o0[lane]), widen(sh.o1[lane]));
