@@ -78,7 +78,7 @@ def main():
     from siga_amd import _lib, host
     from siga_amd import build as sbuild
     from siga_amd.overlap import FMIndexPair
-    from siga_amd.sharding import gather_edges, shard_range
+    from siga_amd.sharding import gather_edges_async, shard_range
     from tests.golden.make_reads import fast_reads
 
     n_total = args.reads_per_gpu * world
@@ -133,6 +133,15 @@ def main():
     nsub = C.c_uint32(1)
     assert lib.sigax_batch_set_subbatches(batch, args.subbatches) == 0, _lib.last_error()
 
+    pending = []  # edge gathers in flight: step k's gather runs beside step k+1's kernels
+
+    def drain():
+        tot = None
+        while pending:
+            _, counts = pending.pop(0).wait()
+            tot = sum(counts)
+        return tot
+
     def step():
         rc = lib.sigax_batch_run(batch, lo, args.min_overlap, flags, sptr)
         if rc == 0:
@@ -143,15 +152,19 @@ def main():
             d_edges = C.c_void_p()
             lib.sigax_batch_device_outputs(batch, None, None, None, C.byref(d_edges))
             ne = int(stats.n_edges)
-            local = torch.as_tensor(_EdgeView(d_edges.value, ne), device=dev) if ne else torch.zeros((0, 4), dtype=torch.int32, device=dev)
+            # copy out of the batch's buffer (the next run overwrites it), then gather asynchronously
+            local = torch.as_tensor(_EdgeView(d_edges.value, ne), device=dev).clone() if ne else torch.zeros((0, 4), dtype=torch.int32, device=dev)
             if args.backend == "gloo":
                 local = local.cpu()
-            allv, counts = gather_edges(local)
-            return sum(counts)
+            if len(pending) >= 2:
+                pending.pop(0).wait()
+            pending.append(gather_edges_async(local))
+            return None
         return int(stats.n_edges)
 
     for _ in range(args.warmup):
         step()
+    drain()
     ksum = np.zeros(5)
     if world > 1:
         dist.barrier()
@@ -162,6 +175,8 @@ def main():
         total_edges = step()
         lib.sigax_batch_kernel_ms(batch, C.byref(kms), C.byref(nsub))  # HIP events on the streams the kernels run on
         ksum += np.array(list(kms))
+    if world > 1:
+        total_edges = drain()  # every step's edge records have reached rank 0 before the clock stops
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -183,6 +198,7 @@ def main():
             step()
             lib.sigax_batch_kernel_ms(batch, C.byref(kms), C.byref(nsub))
             isum += np.array(list(kms))
+        drain()
         iso = isum / 2
 
     out = None

@@ -485,8 +485,11 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
     for (int i = 0; i < EV_COUNT && e == hipSuccess; ++i) e = hipEventCreate(&b->ev[i]);
     for (int i = 0; i < SIGAX_MAX_SUB && e == hipSuccess; ++i)
       for (int j = 0; j < SV_COUNT && e == hipSuccess; ++j) e = hipEventCreate(&b->sev[i][j]);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->s_find, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->s_fx, hipStreamNonBlocking);
+    // the finder is the critical path of a step: its stream gets the higher priority
+    int prio_least = 0, prio_greatest = 0;
+    if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->s_find, hipStreamNonBlocking, prio_greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->s_fx, hipStreamNonBlocking, prio_least);
     if (e != hipSuccess) {
       sigax_batch_destroy(b);
       return fail(SIGAX_E_DEVICE, "creating events/streams: %s", hipGetErrorString(e));

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from siga_amd.sharding import gather_edges, shard_range
+from siga_amd.sharding import gather_edges, gather_edges_async, shard_range
 
 
 def test_shard_range_partitions():
@@ -37,6 +37,13 @@ def _worker(rank, world, port, out):
             out.put((bool(torch.equal(allv, want)), counts))
         else:
             assert allv is None
+        pend = [gather_edges_async(_edges_of(rank) + 7 * i) for i in range(3)]  # several gathers in flight
+        for i, pg in enumerate(pend):
+            got, cs = pg.wait()
+            if rank == 0:
+                assert torch.equal(got, torch.cat([_edges_of(r) + 7 * i for r in range(world)])) and cs == [5, 12]
+            else:
+                assert got is None
         empty, c2 = gather_edges(torch.zeros((0, 4), dtype=torch.int32))  # ragged: nobody has edges
         if rank == 0:
             out.put((empty.shape[0] == 0, c2))
