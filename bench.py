@@ -47,8 +47,13 @@ def main():
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--subbatches", type=int, default=0,
                     help="sub-batches per step (0 = library default: 4 at this size; their find and filter/extract kernels overlap)")
+    ap.add_argument("--depth", type=int, default=2,
+                    help="batches in flight on the index (2 = batch k+1's finder starts beside batch k's filter/extract tail)")
     ap.add_argument("--isolated", action="store_true",
                     help="after the timed steps, also time 2 steps with sub-batching off and report them under roofline.isolated")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="measurement aid: build the index of an N-GPU job (N x reads, N x genome) but run only rank 0's shard "
+                         "in this single process, to see what one GPU of that job achieves")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow on fewer GPUs than ranks (edge records gathered via host)")
     args = ap.parse_args()
@@ -81,8 +86,9 @@ def main():
     from siga_amd.sharding import gather_edges_async, shard_range
     from tests.golden.make_reads import fast_reads
 
-    n_total = args.reads_per_gpu * world
-    G = args.genome_per_gpu * world
+    job_world = args.emulate_world if (args.emulate_world and world == 1) else world
+    n_total = args.reads_per_gpu * job_world
+    G = args.genome_per_gpu * job_world
     L = args.read_len
     workdir = args.workdir or os.path.join(tempfile.gettempdir(), "siga_bench_%d_%d_%d_%d" % (n_total, G, L, args.seed))
     prefix = os.path.join(workdir, "reads")
@@ -109,20 +115,29 @@ def main():
     pair.set_reads(np.full(n_total, L, dtype=np.uint32), name_rank)
     log("index on GPU: %.1f MB, wide=%d (%.1f s since start)" % (info["device_bytes"] / 1e6, info["wide"], time.time() - t0))
 
-    lo, hi = shard_range(n_total, rank, world)
+    lo, hi = shard_range(n_total, rank, job_world)
     n_local = hi - lo
     d_seqs = torch.from_numpy(reads[lo:hi].reshape(-1).copy()).to(dev)
     d_offs = torch.arange(0, (n_local + 1) * L, L, dtype=torch.int64, device=dev)
     lib = _lib.lib()
-    batch = C.c_void_p()
-    rc = lib.sigax_batch_create(pair.handle, n_local, n_local * L, L, C.byref(batch))
-    if rc != 0:
-        raise SystemExit("sigax_batch_create: " + _lib.last_error())
-    rc = lib.sigax_batch_set_device_reads(batch, d_seqs.data_ptr(), d_offs.data_ptr(), n_local, n_local * L, L)
-    assert rc == 0, _lib.last_error()
     flags = _lib.SIGAX_IRREDUCIBLE | _lib.SIGAX_RC | _lib.SIGAX_EDGES
-    stream = torch.cuda.current_stream(dev)
-    sptr = C.c_void_p(stream.cuda_stream)
+    # --depth batches in flight on one index: the library queues every batch's finder launches on one stream and its
+    # filter/extract launches on another, so batch k+1's first finder launch runs beside batch k's last filter/extract
+    # launch.  Each batch has its own workspace and is driven from its own stream; a step = one batch run to completion.
+    depth = max(1, args.depth)
+    batches, streams = [], []
+    for _ in range(depth):
+        bt = C.c_void_p()
+        rc = lib.sigax_batch_create(pair.handle, n_local, n_local * L, L, C.byref(bt))
+        if rc != 0:
+            raise SystemExit("sigax_batch_create: " + _lib.last_error())
+        rc = lib.sigax_batch_set_device_reads(bt, d_seqs.data_ptr(), d_offs.data_ptr(), n_local, n_local * L, L)
+        assert rc == 0, _lib.last_error()
+        assert lib.sigax_batch_set_subbatches(bt, args.subbatches) == 0, _lib.last_error()
+        batches.append(bt)
+        streams.append(torch.cuda.Stream(device=dev) if depth > 1 else torch.cuda.current_stream(dev))
+    batch = batches[0]
+    torch.cuda.synchronize(dev)
 
     class _EdgeView:  # zero-copy view of the library's device edge buffer for torch.distributed
         def __init__(self, ptr, n):
@@ -131,9 +146,10 @@ def main():
     stats = _lib.Stats()
     kms = (C.c_float * 5)()
     nsub = C.c_uint32(1)
-    assert lib.sigax_batch_set_subbatches(batch, args.subbatches) == 0, _lib.last_error()
-
+    ksum = np.zeros(5)
+    inflight = [False] * depth
     pending = []  # edge gathers in flight: step k's gather runs beside step k+1's kernels
+    last_edges = [0]
 
     def drain():
         tot = None
@@ -142,39 +158,54 @@ def main():
             tot = sum(counts)
         return tot
 
-    def step():
-        rc = lib.sigax_batch_run(batch, lo, args.min_overlap, flags, sptr)
-        if rc == 0:
-            rc = lib.sigax_batch_finish(batch, sptr, C.byref(stats))
+    def complete(i):
+        """finish batch i's run: stats, kernel times, and (N > 1) start the gather of its edge records"""
+        if not inflight[i]:
+            return
+        inflight[i] = False
+        sp = C.c_void_p(streams[i].cuda_stream)
+        rc = lib.sigax_batch_finish(batches[i], sp, C.byref(stats))
         if rc != 0:
             raise SystemExit("overlap step failed: " + _lib.last_error())
+        lib.sigax_batch_kernel_ms(batches[i], C.byref(kms), C.byref(nsub))  # HIP events on the streams the kernels run on
+        ksum[:] += np.array(list(kms))
+        last_edges[0] = int(stats.n_edges)
         if world > 1:
             d_edges = C.c_void_p()
-            lib.sigax_batch_device_outputs(batch, None, None, None, C.byref(d_edges))
+            lib.sigax_batch_device_outputs(batches[i], None, None, None, C.byref(d_edges))
             ne = int(stats.n_edges)
-            # copy out of the batch's buffer (the next run overwrites it), then gather asynchronously
-            local = torch.as_tensor(_EdgeView(d_edges.value, ne), device=dev).clone() if ne else torch.zeros((0, 4), dtype=torch.int32, device=dev)
-            if args.backend == "gloo":
-                local = local.cpu()
-            if len(pending) >= 2:
-                pending.pop(0).wait()
-            pending.append(gather_edges_async(local))
-            return None
-        return int(stats.n_edges)
+            with torch.cuda.stream(streams[i]):
+                # copy out of the batch's buffer (its next run overwrites it), then gather asynchronously
+                local = torch.as_tensor(_EdgeView(d_edges.value, ne), device=dev).clone() if ne else torch.zeros((0, 4), dtype=torch.int32, device=dev)
+                if args.backend == "gloo":
+                    local = local.cpu()
+                if len(pending) >= 2:
+                    pending.pop(0).wait()
+                pending.append(gather_edges_async(local))
 
-    for _ in range(args.warmup):
-        step()
+    def submit(k):
+        i = k % depth
+        complete(i)  # the batch's previous run must be done before its workspace is reused
+        rc = lib.sigax_batch_run(batches[i], lo, args.min_overlap, flags, C.c_void_p(streams[i].cuda_stream))
+        if rc != 0:
+            raise SystemExit("overlap step failed: " + _lib.last_error())
+        inflight[i] = True
+
+    def run_steps(n, k0=0):
+        for k in range(k0, k0 + n):
+            submit(k)
+        for k in range(k0 + n, k0 + n + depth):  # complete in submission order
+            complete(k % depth)
+
+    run_steps(args.warmup)
     drain()
-    ksum = np.zeros(5)
+    ksum[:] = 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t_start = time.perf_counter()
-    total_edges = 0
-    for _ in range(args.steps):
-        total_edges = step()
-        lib.sigax_batch_kernel_ms(batch, C.byref(kms), C.byref(nsub))  # HIP events on the streams the kernels run on
-        ksum += np.array(list(kms))
+    run_steps(args.steps, args.warmup)
+    total_edges = last_edges[0]
     if world > 1:
         total_edges = drain()  # every step's edge records have reached rank 0 before the clock stops
     torch.cuda.synchronize(dev)
@@ -193,17 +224,16 @@ def main():
     iso = None
     if launches > 1 and args.isolated:
         assert lib.sigax_batch_set_subbatches(batch, 1) == 0
-        isum = np.zeros(5)
-        for _ in range(2):
-            step()
-            lib.sigax_batch_kernel_ms(batch, C.byref(kms), C.byref(nsub))
-            isum += np.array(list(kms))
+        ksum[:] = 0
+        for k in range(2):
+            submit(k * depth)  # always batch 0, one run at a time
+            complete(0)
         drain()
-        iso = isum / 2
+        iso = ksum / 2
 
     out = None
     if rank == 0:
-        reads_per_s = n_total * args.steps / elapsed
+        reads_per_s = (n_total if job_world == world else n_local) * args.steps / elapsed
         # algorithmic bytes: 64 B per distinct Occ evaluation + L per read + 64 B per block out
         n_occ = st["n_occ_find"] + st["n_occ_extract"]
         bytes_find = 64 * st["n_occ_find"] + n_local * L + 64 * st["n_candidate_blocks"]
@@ -229,7 +259,7 @@ def main():
                                        n_total, L, G, args.min_overlap, world),
                        "reads_per_gpu": n_local, "edges": total_edges, "blocks_per_read": st["n_blocks"] / max(n_local, 1),
                        "n_occ_min_per_read": n_occ / max(n_local, 1), "algorithmic_bytes_per_read": bytes_read,
-                       "slow_path_reads": st["n_slow_reads"]},
+                       "slow_path_reads": st["n_slow_reads"], "batches_in_flight": depth},
             "kernel_ms_per_step": {k: float(v) for k, v in zip(KERNELS, kavg)},
             "launches_per_step": launches,
             "roofline": {"bound": "hbm", "kernel": "k_find", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -248,7 +278,8 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(prefix, reads, min(args.cpu_sample, n_total), args.min_overlap, st, lib, batch)
 
-    lib.sigax_batch_destroy(batch)
+    for bt in batches:
+        lib.sigax_batch_destroy(bt)
     pair.close()
     if world > 1:
         dist.barrier()

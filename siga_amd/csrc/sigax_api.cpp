@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -63,6 +64,11 @@ struct sigax_index {
   uint32_t* d_name_rank;
   u64 n_meta;
   u64 n_symbols, n_strings, device_bytes;
+  // The internal pipeline streams belong to the index, not to a batch: every batch on this index queues its finder
+  // launches on s_find and its filter/extract launches on s_fx, so with two batches in flight batch B's first finder
+  // launch runs beside batch A's last filter/extract launch and finder launches never run beside each other.
+  hipStream_t s_find, s_fx;
+  std::mutex* enqueue_mu;
 };
 
 // RL units (src/rlstring.h:10-63) -> 64-byte rank granules (fm_layout.h)
@@ -181,6 +187,9 @@ extern "C" void sigax_index_close(sigax_index* ix) {
   }
   if (ix->d_read_len) hipFree(ix->d_read_len);
   if (ix->d_name_rank) hipFree(ix->d_name_rank);
+  if (ix->s_find) hipStreamDestroy(ix->s_find);
+  if (ix->s_fx) hipStreamDestroy(ix->s_fx);
+  delete ix->enqueue_mu;
   delete ix;
 }
 
@@ -197,6 +206,18 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
   sigax_index* ix = new sigax_index();
   memset(ix, 0, sizeof(*ix));
   ix->device = device;
+  ix->enqueue_mu = new std::mutex();
+  {
+    // the finder is the critical path of a step: its stream gets the higher priority
+    int prio_least = 0, prio_greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_find, hipStreamNonBlocking, prio_greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_fx, hipStreamNonBlocking, prio_least);
+    if (e != hipSuccess) {
+      sigax_index_close(ix);
+      return fail(SIGAX_E_DEVICE, "creating the pipeline streams: %s", hipGetErrorString(e));
+    }
+  }
   ix->n_symbols = n_symbols;
   ix->n_strings = n_strings;
   // 64-bit positions when the BWT does not fit 32 bits (SIGAX_FORCE_WIDE=1 exercises that path on small inputs)
@@ -424,7 +445,6 @@ struct sigax_batch {
   bool fin_grown;
   hipEvent_t ev[EV_COUNT];
   hipEvent_t sev[SIGAX_MAX_SUB][SV_COUNT];
-  hipStream_t s_find, s_fx;  // internal pipeline: sub-batch i's filter/extract overlaps sub-batch i+1's find
   unsigned nsub;
   unsigned nsub_req;  // 0 = automatic
   sigax_stats last;
@@ -445,8 +465,6 @@ extern "C" void sigax_batch_destroy(sigax_batch* b) {
   for (int i = 0; i < SIGAX_MAX_SUB; ++i)
     for (int j = 0; j < SV_COUNT; ++j)
       if (b->sev[i][j]) hipEventDestroy(b->sev[i][j]);
-  if (b->s_find) hipStreamDestroy(b->s_find);
-  if (b->s_fx) hipStreamDestroy(b->s_fx);
   delete b;
 }
 
@@ -477,7 +495,6 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
   for (int i = 0; i < EV_COUNT; ++i) b->ev[i] = nullptr;
   for (int i = 0; i < SIGAX_MAX_SUB; ++i)
     for (int j = 0; j < SV_COUNT; ++j) b->sev[i][j] = nullptr;
-  b->s_find = b->s_fx = nullptr;
   b->nsub = 1;
   b->nsub_req = 0;
   {
@@ -485,11 +502,6 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
     for (int i = 0; i < EV_COUNT && e == hipSuccess; ++i) e = hipEventCreate(&b->ev[i]);
     for (int i = 0; i < SIGAX_MAX_SUB && e == hipSuccess; ++i)
       for (int j = 0; j < SV_COUNT && e == hipSuccess; ++j) e = hipEventCreate(&b->sev[i][j]);
-    // the finder is the critical path of a step: its stream gets the higher priority
-    int prio_least = 0, prio_greatest = 0;
-    if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->s_find, hipStreamNonBlocking, prio_greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&b->s_fx, hipStreamNonBlocking, prio_least);
     if (e != hipSuccess) {
       sigax_batch_destroy(b);
       return fail(SIGAX_E_DEVICE, "creating events/streams: %s", hipGetErrorString(e));
@@ -546,6 +558,7 @@ extern "C" int sigax_batch_set_device_reads(sigax_batch* b, const void* d_seqs, 
 
 static int enqueue(sigax_batch* b, hipStream_t st) {
   sigax_index* ix = b->ix;
+  std::lock_guard<std::mutex> lock(*ix->enqueue_mu);  // one batch's launch sequence at a time on the shared streams
   const uint32_t n = b->n_reads;
   const bool edges = (b->flags & SIGAX_EDGES) != 0;
   if (edges && (!ix->d_sai[0] || !ix->d_read_len))
@@ -555,8 +568,9 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   // slots per chain: overlaps of length max(m,1)..L-1, plus one for the containment block
   uint32_t mm = std::max<uint32_t>(b->minov, 1u);
   b->cap = (b->cur_max_len > mm ? b->cur_max_len - mm : 0u) + 1u;
+  b->cap = (b->cap + 1u) & ~1u;  // even: each chain's slots start on a 64-byte line (k_find's quad stores write whole lines)
   int rc;
-  if ((rc = ensure(&b->arena, (size_t)n * 4 * b->cap * sizeof(sigax_block))) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->arena, (size_t)n * 4 * b->cap * cand_bytes(ix->wide))) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->chain_cnt, (size_t)n * 4 * 4)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->fin_cnt, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->occ_side, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
@@ -565,7 +579,8 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   if ((rc = ensure(&b->substring, (size_t)n + 16)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->block_offs, ((size_t)n + 2) * 8)) != SIGAX_OK) return rc;
   // fast filter/extract kernel: persistent waves (one read at a time per wave) with a private pool each
-  unsigned fast_grid = (unsigned)std::min<u64>(2048, ((u64)n + 3) / 4);  // two items per wave
+  static const char* env_fxg = getenv("SIGAX_FX_GRID");
+  unsigned fast_grid = (unsigned)std::min<u64>(env_fxg ? (u64)atoi(env_fxg) : 2048, ((u64)n + 3) / 4);  // two items per wave
   if (fast_grid == 0) fast_grid = 1;
   if ((rc = ensure(&b->wpool, (size_t)fast_grid * 4 * fast_pool_entries_per_wave() * SIGAX_ENT_BYTES)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->work, ((size_t)n + 1) * 4)) != SIGAX_OK) return rc;
@@ -606,8 +621,8 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   if (nsub > SIGAX_MAX_SUB) nsub = SIGAX_MAX_SUB;
   b->nsub = nsub;
   static const bool only_general = getenv("SIGAX_GENERAL_ONLY") != nullptr;  // debugging aid: skip the fast kernel
-  HIP_TRY(hipStreamWaitEvent(b->s_find, b->ev[EV_START], 0));
-  HIP_TRY(hipStreamWaitEvent(b->s_fx, b->ev[EV_START], 0));
+  HIP_TRY(hipStreamWaitEvent(ix->s_find, b->ev[EV_START], 0));
+  HIP_TRY(hipStreamWaitEvent(ix->s_fx, b->ev[EV_START], 0));
   for (unsigned i = 0; i < nsub; ++i) {
     const uint32_t rb = (uint32_t)((u64)n * i / nsub), re = (uint32_t)((u64)n * (i + 1) / nsub);
     FindArgs fa;
@@ -621,13 +636,13 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.cap = b->cap;
     fa.read_begin = rb;
     fa.read_end = re;
-    fa.arena = (sigax_block*)b->arena.p;
+    fa.arena = b->arena.p;
     fa.chain_cnt = (uint32_t*)b->chain_cnt.p;
     fa.dstat = dstat;
-    HIP_TRY(hipEventRecord(b->sev[i][SV_F0], b->s_find));
-    launch_find(fa, ix->wide, b->s_find);
-    HIP_TRY(hipEventRecord(b->sev[i][SV_F1], b->s_find));
-    HIP_TRY(hipStreamWaitEvent(b->s_fx, b->sev[i][SV_F1], 0));
+    HIP_TRY(hipEventRecord(b->sev[i][SV_F0], ix->s_find));
+    launch_find(fa, ix->wide, ix->s_find);
+    HIP_TRY(hipEventRecord(b->sev[i][SV_F1], ix->s_find));
+    HIP_TRY(hipStreamWaitEvent(ix->s_fx, b->sev[i][SV_F1], 0));
 
     FxArgs xa;
     xa.fwd = ix->st[0];
@@ -636,7 +651,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     xa.n_reads = n;
     xa.cap = b->cap;
     xa.irreducible = (b->flags & SIGAX_IRREDUCIBLE) ? 1u : 0u;
-    xa.arena = (const sigax_block*)b->arena.p;
+    xa.arena = b->arena.p;
     xa.chain_cnt = (const uint32_t*)b->chain_cnt.p;
     xa.pool = (Ent*)b->pool.p;
     xa.pool_cap = b->pool_cap;
@@ -655,12 +670,12 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     xa.slow_flag = (uint32_t*)b->slow_flag.p;
     xa.substring = (uint8_t*)b->substring.p;
     xa.dstat = dstat;
-    HIP_TRY(hipEventRecord(b->sev[i][SV_X0], b->s_fx));
+    HIP_TRY(hipEventRecord(b->sev[i][SV_X0], ix->s_fx));
     if (!only_general) {
       xa.work = nullptr;
       xa.n_work = 0;
       xa.n_work_ptr = nullptr;
-      launch_filter_extract_fast(xa, ix->wide, fast_grid, std::min(fast_grid, 512u), b->s_fx);
+      launch_filter_extract_fast(xa, ix->wide, fast_grid, std::min(fast_grid, 512u), ix->s_fx);
       xa.work = (const uint32_t*)b->work.p + rb;  // the general kernel redoes what the fast one queued
       xa.n_work = 0;
       xa.n_work_ptr = dstat + DS_SLOW_BASE + i;
@@ -668,17 +683,17 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
       // every read of the sub-batch through the general kernel
       std::vector<uint32_t> ids(re - rb);
       for (uint32_t k = rb; k < re; ++k) ids[k - rb] = k;
-      HIP_TRY(hipMemcpyAsync((uint32_t*)b->work.p + rb, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, b->s_fx));
-      HIP_TRY(hipStreamSynchronize(b->s_fx));
+      HIP_TRY(hipMemcpyAsync((uint32_t*)b->work.p + rb, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, ix->s_fx));
+      HIP_TRY(hipStreamSynchronize(ix->s_fx));
       xa.work = (const uint32_t*)b->work.p + rb;
       xa.n_work = re - rb;
       xa.n_work_ptr = nullptr;
     }
-    HIP_TRY(hipEventRecord(b->sev[i][SV_X1], b->s_fx));
-    launch_filter_extract(xa, ix->wide, b->fx_grid, b->s_fx);
-    HIP_TRY(hipEventRecord(b->sev[i][SV_G1], b->s_fx));
+    HIP_TRY(hipEventRecord(b->sev[i][SV_X1], ix->s_fx));
+    launch_filter_extract(xa, ix->wide, b->fx_grid, ix->s_fx);
+    HIP_TRY(hipEventRecord(b->sev[i][SV_G1], ix->s_fx));
   }
-  HIP_TRY(hipEventRecord(b->ev[EV_FX_DONE], b->s_fx));
+  HIP_TRY(hipEventRecord(b->ev[EV_FX_DONE], ix->s_fx));
   HIP_TRY(hipStreamWaitEvent(st, b->ev[EV_FX_DONE], 0));
 
   launch_scan((const uint32_t*)b->fin_cnt.p, 2 * (u64)n, (u64*)b->partial.p, (u64*)b->offs2.p, dstat + DS_TOTAL_BLOCKS, st);
@@ -744,9 +759,9 @@ extern "C" int sigax_batch_finish(sigax_batch* b, void* stream, sigax_stats* sta
   HIP_TRY(hipSetDevice(b->ix->device));
   hipStream_t st = (hipStream_t)stream;
   for (int attempt = 0; attempt < 8; ++attempt) {
-    HIP_TRY(hipStreamSynchronize(st));
     u64 ds[DS_COUNT];
-    HIP_TRY(hipMemcpy(ds, b->dstat.p, sizeof(ds), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(ds, b->dstat.p, sizeof(ds), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     if (ds[DS_FIND_OVERFLOW]) return fail(SIGAX_E_CAPACITY, "candidate arena overflow (max read length given too small?)");
     bool again = false;
     if (ds[DS_POOL_OVERFLOW]) {

@@ -38,7 +38,7 @@ struct FindArgs {
   const unsigned long long* offs;
   uint32_t n_reads, minov, chain_mask, cap;  // chain_mask bit o = find o runs; cap = slots per chain, last = containment
   uint32_t read_begin, read_end;     // this launch's sub-batch
-  sigax_block* arena;                // [n_reads][4][cap]
+  void* arena;                       // [n_reads][4][cap] candidate records of cand_bytes(wide) each
   uint32_t* chain_cnt;               // [n_reads][4]
   unsigned long long* dstat;
 };
@@ -47,7 +47,7 @@ struct FxArgs {
   FmStrand fwd, rev;
   const unsigned long long* offs;
   uint32_t n_reads, cap, irreducible;
-  const sigax_block* arena;
+  const void* arena;
   const uint32_t* chain_cnt;
   Ent* pool;          // [lanes][pool_cap]
   uint32_t pool_cap;
@@ -123,6 +123,7 @@ void launch_scan(const uint32_t* cnt, unsigned long long n, unsigned long long* 
 unsigned long long scan_partials_needed(unsigned long long n);
 void launch_order_scatter(const OrderArgs& a, hipStream_t st);
 unsigned long long fast_fin_chunk();
+unsigned long long cand_bytes(bool wide);
 void launch_pick_read_offsets(const unsigned long long* offs2, unsigned long long n_reads, unsigned long long* block_offs,
                               hipStream_t st);
 void launch_edges(const EdgeArgs& a, bool fill, unsigned long long max_blocks, hipStream_t st);

@@ -34,6 +34,59 @@ template <typename P> struct Cnt4P {
   P a, c, g, t;
 };
 
+// A candidate block as the finder leaves it in the arena: one naturally aligned record (32 B with u32 positions, 64 B
+// with u64) = one or two 16-byte stores per half instead of the five scattered ones of an 80-byte sigax_block.
+//   capped[0] = [c0lo, c0lo + d - 1], capped[1] = [c1lo, c1lo + d - 1]   (both intervals of a pair have one size)
+//   raw[0]    = [r0lo, r0lo + sz - 1], raw[1]   = [r1lo, r1lo + sz - 1]
+#ifndef SIGAX_FIND_ATTR
+#define SIGAX_FIND_ATTR
+#endif
+#ifndef SIGAX_FX_ATTR
+#define SIGAX_FX_ATTR
+#endif
+template <bool WIDE> struct Cand;
+template <> struct __attribute__((aligned(32))) Cand<false> {
+  u32 c0lo, d, c1lo, r0lo, r1lo, sz, len, af;
+};
+template <> struct __attribute__((aligned(64))) Cand<true> {
+  u64 c0lo, d, c1lo, r0lo, r1lo, sz;
+  u32 len, af;
+  u64 pad;
+};
+static_assert(sizeof(Cand<false>) == 32 && sizeof(Cand<true>) == 64, "candidate record sizes");
+
+__device__ __forceinline__ void cand_store(Cand<false>* dst, u32 c0lo, u32 d, u32 c1lo, u32 r0lo, u32 r1lo, u32 sz, u32 len, u32 af) {
+  uint4* q = reinterpret_cast<uint4*>(dst);
+  q[0] = make_uint4(c0lo, d, c1lo, r0lo);
+  q[1] = make_uint4(r1lo, sz, len, af);
+}
+__device__ __forceinline__ void cand_store(Cand<true>* dst, u64 c0lo, u64 d, u64 c1lo, u64 r0lo, u64 r1lo, u64 sz, u32 len, u32 af) {
+  ulonglong2* q = reinterpret_cast<ulonglong2*>(dst);
+  q[0] = make_ulonglong2(c0lo, d);
+  q[1] = make_ulonglong2(c1lo, r0lo);
+  q[2] = make_ulonglong2(r1lo, sz);
+  q[3] = make_ulonglong2((u64)len | ((u64)af << 32), 0ull);
+}
+template <bool WIDE>
+__device__ __forceinline__ Cand<WIDE> cand_load(const Cand<WIDE>* src);
+template <>
+__device__ __forceinline__ Cand<false> cand_load<false>(const Cand<false>* src) {
+  const uint4* q = reinterpret_cast<const uint4*>(src);
+  uint4 a = q[0], b = q[1];
+  Cand<false> c;
+  c.c0lo = a.x; c.d = a.y; c.c1lo = a.z; c.r0lo = a.w; c.r1lo = b.x; c.sz = b.y; c.len = b.z; c.af = b.w;
+  return c;
+}
+template <>
+__device__ __forceinline__ Cand<true> cand_load<true>(const Cand<true>* src) {
+  const ulonglong2* q = reinterpret_cast<const ulonglong2*>(src);
+  ulonglong2 a = q[0], b = q[1], c2 = q[2], d = q[3];
+  Cand<true> c;
+  c.c0lo = a.x; c.d = a.y; c.c1lo = b.x; c.r0lo = b.y; c.r1lo = c2.x; c.sz = c2.y; c.len = (u32)d.x; c.af = (u32)(d.x >> 32);
+  c.pad = 0;
+  return c;
+}
+
 __device__ __forceinline__ void chunk_count(const uint4& k, int take, u32& a, u32& c, u32& g, u32& t) {
   u32 m = take >= 32 ? 0xFFFFFFFFu : (take <= 0 ? 0u : ((1u << take) - 1u));
   u32 x0 = k.y & m, x1 = k.z & m, x2 = k.w & m;
@@ -133,6 +186,57 @@ __device__ __forceinline__ Cnt4P<typename PosOf<WIDE>::type> fm_rank4p(const FmR
   return o;
 }
 
+// The finder's loads of one step, issued back to back and waited for once: both rank granules (4 x 16 B each; the
+// pieces of a granule share a line) and the read's base for this step.  Left to the compiler, the conditional record
+// stores of the loop make it wait with vmcnt(0) part-way through issuing these loads and issue the base's load after
+// that wait, which puts one or two extra cache round trips on every step of the chain.
+typedef u32 v4u __attribute__((ext_vector_type(4)));
+struct Gran {
+  v4u k0, k1, k2, k3;
+};
+__device__ __forceinline__ void find_step_loads(const void* qa, const void* qb, const unsigned char* pc, Gran& a, Gran& b, u32& ch) {
+  asm volatile(
+      "global_load_dwordx4 %0, %9, off\n\t"
+      "global_load_dwordx4 %4, %10, off\n\t"
+      "global_load_ubyte %8, %11, off\n\t"
+      "global_load_dwordx4 %1, %9, off offset:16\n\t"
+      "global_load_dwordx4 %2, %9, off offset:32\n\t"
+      "global_load_dwordx4 %3, %9, off offset:48\n\t"
+      "global_load_dwordx4 %5, %10, off offset:16\n\t"
+      "global_load_dwordx4 %6, %10, off offset:32\n\t"
+      "global_load_dwordx4 %7, %10, off offset:48\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a.k0), "=&v"(a.k1), "=&v"(a.k2), "=&v"(a.k3), "=&v"(b.k0), "=&v"(b.k1), "=&v"(b.k2), "=&v"(b.k3), "=&v"(ch)
+      : "v"(qa), "v"(qb), "v"(pc)
+      : "memory");
+}
+__device__ __forceinline__ void chunk_count(const v4u& k, int take, u32& a, u32& c, u32& g, u32& t) {
+  u32 m = take >= 32 ? 0xFFFFFFFFu : (take <= 0 ? 0u : ((1u << take) - 1u));
+  u32 x0 = k.y & m, x1 = k.z & m, x2 = k.w & m;
+  a += __popc(x0 & ~x1);
+  c += __popc(x1 & ~x0);
+  g += __popc(x0 & x1);
+  t += __popc(x2);
+}
+// fm_rank4p on a granule that is already in registers; pc = the clamped position
+template <bool WIDE>
+__device__ __forceinline__ Cnt4P<typename PosOf<WIDE>::type> fm_rank4p_from(const FmRef& s, u64 pc, const Gran& q) {
+  typedef typename PosOf<WIDE>::type P;
+  int r = (int)(pc & 127u);
+  u32 a = q.k0.x, c = q.k1.x, g = q.k2.x, t = q.k3.x;
+  chunk_count(q.k0, r, a, c, g, t);
+  chunk_count(q.k1, r - 32, a, c, g, t);
+  chunk_count(q.k2, r - 64, a, c, g, t);
+  chunk_count(q.k3, r - 96, a, c, g, t);
+  Cnt4P<P> o;
+  o.a = a; o.c = c; o.g = g; o.t = t;
+  if (WIDE) {
+    const u64* sb = s.super + (pc >> SIGAX_SUPER_SHIFT) * 4;
+    o.a += (P)sb[0]; o.c += (P)sb[1]; o.g += (P)sb[2]; o.t += (P)sb[3];
+  }
+  return o;
+}
+
 // BWT symbol at position i (FMIndex::getChar, src/fmindex.cpp:233-246)
 __device__ __forceinline__ u32 fm_char(const FmRef& s, u64 i) {
   const u32* q = reinterpret_cast<const u32*>(s.g) + (i >> 7) * 16 + ((i >> 5) & 3) * 4;
@@ -141,8 +245,21 @@ __device__ __forceinline__ u32 fm_char(const FmRef& s, u64 i) {
 }
 
 // alphabet.h:19-39 and kseq.cpp:18-27: byte -> rank; complement in rank space (non-ACGT -> 0 either way)
+// Branch-free (a chain of equality tests on one value is lowered to a divergent branch tree): bits 1-2 of 'A','C','T','G'
+// are 0,1,2,3; the byte expected at that index and its rank come out of two constants.
 __device__ __forceinline__ u32 base_rank(u32 ch) {
-  return ch == 'A' ? 1u : ch == 'C' ? 2u : ch == 'G' ? 3u : ch == 'T' ? 4u : 0u;
+  const u32 i = (ch >> 1) & 3u;
+  const u32 expect = (0x47544341u >> (i * 8)) & 0xFFu;  // "ACTG"
+  const u32 rank = (0x3421u >> (i * 4)) & 0xFu;         // 1, 2, 4, 3
+  return expect == ch ? rank : 0u;
+}
+// v[r] for r in 0..4 out of registers, as a select tree on the bits of r (again: no equality chain, no branches)
+template <typename T>
+__device__ __forceinline__ T sel5(u32 r, T v0, T v1, T v2, T v3, T v4) {
+  const bool b0 = (r & 1u) != 0, b1 = (r & 2u) != 0, b2 = (r & 4u) != 0;
+  const T t01 = b0 ? v1 : v0, t23 = b0 ? v3 : v2;
+  const T t = b1 ? t23 : t01;
+  return b2 ? v4 : t;
 }
 __device__ __forceinline__ u32 comp_rank(u32 r) { return r ? 5u - r : 0u; }
 
@@ -203,93 +320,164 @@ __device__ __forceinline__ void store_block(sigax_block* dst, u64 c0lo, u64 c0hi
   d[4] = make_ulonglong2((u64)len | ((u64)af << 32), 0ull);
 }
 
+// Candidate records leave the finder as full 64-byte lines.  A lane that produced a record parks it in its LDS row
+// (two 32-byte records per row with u32 positions, one 64-byte record with u64); once the row is full the FOUR lanes
+// of the lane's quad -- the four chains of one read, which walk the loop together -- each take a 16-byte piece of
+// that row and write the pieces with one store instruction: one 64-byte request per line instead of one 16-byte
+// request per piece (measured at C2: the finder's 160 M scattered piece stores cost 1.8 of its 12.3 ms; the memory
+// system counts requests, not bytes).  `tag` = destination byte address | number of 16-byte pieces to write - 1.
+struct FindStage {
+  uint4 row[256][4];
+  u64 tag[256];
+};
+
+__device__ __forceinline__ void find_flush(FindStage& sg, bool want, u32 tid) {
+  const u32 lane = tid & 63u, q0 = tid & ~3u, piece = tid & 3u;
+  __builtin_amdgcn_wave_barrier();
+  u64 bal = __ballot(want);
+  u32 qm = (u32)(bal >> (lane & 60u)) & 0xFu;  // lanes of my quad with a full row
+  while (__ballot(qm != 0) != 0) {             // wave-uniform trip count; quads with nothing left idle through
+    if (qm != 0) {
+      const u32 src = q0 + (u32)__builtin_ctz(qm);
+      const u64 tag = sg.tag[src];
+      if (piece <= (u32)(tag & 3u)) {
+        const uint4 v = sg.row[src][piece];
+        *reinterpret_cast<uint4*>((tag & ~(u64)3) + piece * 16u) = v;
+      }
+      qm &= qm - 1u;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <bool WIDE>
-__global__ __launch_bounds__(256) void k_find(FindArgs A) {
+__global__ __launch_bounds__(256) SIGAX_FIND_ATTR void k_find(FindArgs A) {
   __shared__ FmTables tb;
+  __shared__ FindStage sg;
+#ifdef SIGAX_FIND_PRIO
+  __builtin_amdgcn_s_setprio(SIGAX_FIND_PRIO);  // the finder's short dependent chain wins issue arbitration over filter/extract waves
+#endif
   fm_tables_load(tb, A.fwd, A.rev);
 
-  u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 tid = threadIdx.x;
+  u64 gid = (u64)blockIdx.x * blockDim.x + tid;
   u32 read = A.read_begin + (u32)(gid >> 2), o = (u32)gid & 3u;
   typedef typename PosOf<WIDE>::type P;
   u32 nocc = 0;
   u32 nb = 0, flagbits = 0;
   bool live = read < A.read_end && ((A.chain_mask >> o) & 1u);  // overlap: 0xF, or 0x5 without the opposite strand; duplicate: 0x9
-  u64 b0 = 0, L = 0;
+  u64 b0 = 0;
+  u32 L = 0;
   if (live) {
     b0 = A.offs[read];
-    L = A.offs[read + 1] - b0;
+    L = (u32)(A.offs[read + 1] - b0);
     live = L > 0;
   }
-  if (live) {
-    const bool pf = o < 2;  // primary index: fmi for chains 0,1; rfmi for 2,3 (overlap_builder.cpp:1120-1132)
-    const FmRef F = fm_ref(A.fwd, 0), R = fm_ref(A.rev, 1);
-    const FmRef PI = fm_pick(pf, F, R);
-    const FmRef OI = fm_pick(pf, R, F);
-    const u64* CP = tb.C[PI.which];
-    const u64* CO = tb.C[OI.which];
-    const bool comp = (o & 1u) != 0;            // chains 1 (revcomp) and 3 (complement)
-    const bool fromStart = (o == 1 || o == 2);  // reversed strings are consumed from the read's first base
-    const u32 af = o == 0 ? SIGAX_AF_CHAIN0 : o == 1 ? SIGAX_AF_CHAIN1 : o == 2 ? SIGAX_AF_CHAIN2 : SIGAX_AF_CHAIN3;
-    const unsigned char* sq = A.seqs + b0;
-    sigax_block* slots = A.arena + ((u64)read * 4 + o) * A.cap;
+  const bool pf = o < 2;  // primary index: fmi for chains 0,1; rfmi for 2,3 (overlap_builder.cpp:1120-1132)
+  const FmRef F = fm_ref(A.fwd, 0), R = fm_ref(A.rev, 1);
+  const FmRef PI = fm_pick(pf, F, R);
+  const FmRef OI = fm_pick(pf, R, F);
+  const u64* CP = tb.C[PI.which];
+  const u64* CO = tb.C[OI.which];
+  const bool comp = (o & 1u) != 0;            // chains 1 (revcomp) and 3 (complement)
+  const bool fromStart = (o == 1 || o == 2);  // reversed strings are consumed from the read's first base
+  const u32 af = o == 0 ? SIGAX_AF_CHAIN0 : o == 1 ? SIGAX_AF_CHAIN1 : o == 2 ? SIGAX_AF_CHAIN2 : SIGAX_AF_CHAIN3;
+  const unsigned char* sq = A.seqs + b0;
+  // cap is even (sigax_api.cpp) so every chain's slots start on a 64-byte line
+  const u64 slots = reinterpret_cast<u64>(A.arena) + ((u64)(live ? read : 0u) * 4 + o) * A.cap * sizeof(Cand<WIDE>);
 
+  P lo0 = 0, sz = 0, lo1 = 0;
+  if (live) {
     u32 r = base_rank(sq[fromStart ? 0 : L - 1]);
     if (comp) r = comp_rank(r);
     // IntervalPair::init (overlap_builder.cpp:91-94, fmindex.h:90-93)
-    P lo0 = (P)CP[r], sz = (P)tb.T[PI.which][r], lo1 = (P)CO[r];
-    u32 s = 1;
-    for (; s < L; ++s) {
-      if (sz == 0) break;  // an empty range stays empty, nothing more can be emitted
-      const Cnt4P<P> l = fm_rank4p<WIDE>(PI, lo0);
-      const Cnt4P<P> u = fm_rank4p<WIDE>(PI, (P)(lo0 + sz));
+    lo0 = (P)CP[r]; sz = (P)tb.T[PI.which][r]; lo1 = (P)CO[r];
+  }
+  // All 64 lanes stay in the loop until the wave's last chain is done (a finished chain idles, predicated off):
+  // the quad-cooperative record stores need every lane of a quad present.
+  u32 s = 1;                  // this chain's current match length
+  bool full = !live;          // the arena slots of this chain ran out ("cannot happen": cap comes from the longest read)
+  for (;;) {
+    const bool on = live && sz != 0 && s < L;  // an empty range stays empty, nothing more can be emitted
+    if (__ballot(on) == 0) break;
+    bool flush = false;
+    if (on) {
+      const u64 pl = (u64)lo0 > PI.n ? PI.n : (u64)lo0;  // never leave the table, whatever an invalid interval holds
+      const u64 pu0 = (u64)(P)(lo0 + sz);
+      const u64 pu = pu0 > PI.n ? PI.n : pu0;
+      Gran gl, gu;
+      u32 ch;
+      find_step_loads(PI.g + (pl >> 7) * 4, PI.g + (pu >> 7) * 4, sq + (fromStart ? s : L - 1 - s), gl, gu, ch);
+      const Cnt4P<P> l = fm_rank4p_from<WIDE>(PI, pl, gl);
+      const Cnt4P<P> u = fm_rank4p_from<WIDE>(PI, pu, gu);
       nocc += 2;
-      u32 ch = sq[fromStart ? s : L - 1 - s];
+      u32 r = base_rank(ch & 0xFFu);
+      if (comp) r = comp_rank(r);
       P da = u.a - l.a, dc = u.c - l.c, dg = u.g - l.g, dt = u.t - l.t;
       P dd = sz - (da + dc + dg + dt);  // '$' extensions
+      const P ld = lo0 - (l.a + l.c + l.g + l.t);
       if (s >= A.minov && dd > 0) {
         // probe = ranges; probe.updateL('$') (overlap_builder.cpp:861-865): valid <=> dd > 0
-        P ld = lo0 - (l.a + l.c + l.g + l.t);
-        if (nb < A.cap - 1) {
-          store_block(slots + nb, ld, (u64)ld + dd - 1, lo1, (u64)lo1 + dd - 1, lo0, (u64)lo0 + sz - 1, lo1, (u64)lo1 + sz - 1, s, af);
+        if (nb < A.cap - 1 && !full) {
+          if (WIDE) {
+            cand_store(reinterpret_cast<Cand<WIDE>*>(&sg.row[tid][0]), ld, dd, lo1, lo0, lo1, sz, s, af);
+            sg.tag[tid] = (slots + (u64)nb * sizeof(Cand<WIDE>)) | 3u;
+            flush = true;
+          } else {
+            cand_store(reinterpret_cast<Cand<WIDE>*>(&sg.row[tid][(nb & 1u) * 2]), ld, dd, lo1, lo0, lo1, sz, s, af);
+            if (nb & 1u) {
+              sg.tag[tid] = (slots + (u64)(nb - 1) * sizeof(Cand<WIDE>)) | 3u;
+              flush = true;
+            }
+          }
         } else {
-          flagbits |= 1u;  // cannot happen when cap was sized from the longest read
+          flagbits |= 1u;
+          full = true;
         }
         ++nb;
       }
-      r = base_rank(ch);
-      if (comp) r = comp_rank(r);
-      // ranges.updateL(c) (overlap_builder.cpp:112-122)
-      P acc, lc, dcur;
-      if (r == 0)      { acc = 0;                 lc = lo0 - (l.a + l.c + l.g + l.t); dcur = dd; }
-      else if (r == 1) { acc = dd;                lc = l.a; dcur = da; }
-      else if (r == 2) { acc = dd + da;           lc = l.c; dcur = dc; }
-      else if (r == 3) { acc = dd + da + dc;      lc = l.g; dcur = dg; }
-      else             { acc = dd + da + dc + dg; lc = l.t; dcur = dt; }
+      // ranges.updateL(c) (overlap_builder.cpp:112-122), branch-free: acc = extensions by smaller symbols
+      const P p1 = dd, p2 = dd + da, p3 = p2 + dc, p4 = p3 + dg;
+      const P acc = sel5<P>(r, (P)0, p1, p2, p3, p4);
+      const P lc = sel5<P>(r, ld, l.a, l.c, l.g, l.t);
+      const P dcur = sel5<P>(r, dd, da, dc, dg, dt);
       lo1 += acc;
       lo0 = (P)CP[r] + lc;
       sz = dcur;
+      ++s;
     }
-    if (sz != 0 && s >= L) {
-      // full-length interval: substring test and containment block (overlap_builder.cpp:889-904)
-      const Cnt4P<P> l = fm_rank4p<WIDE>(PI, lo0);
-      const Cnt4P<P> u = fm_rank4p<WIDE>(PI, (P)(lo0 + sz));
-      const Cnt4P<P> lp = fm_rank4p<WIDE>(OI, lo1);
-      const Cnt4P<P> up = fm_rank4p<WIDE>(OI, (P)(lo1 + sz));
-      nocc += 4;
-      bool dna = (u.a - l.a) | (u.c - l.c) | (u.g - l.g) | (u.t - l.t) | (up.a - lp.a) | (up.c - lp.c) | (up.g - lp.g) |
-                 (up.t - lp.t);
-      if (dna) {
-        flagbits |= SIGAX_CC_SUBSTRING;
-      } else {
-        // no DNA extension on either side: all sz extensions are '$', so probe.updateL('$') keeps the whole
-        // range and probe.updateR('$') reuses the two positions of rext.
-        P ld = lo0 - (l.a + l.c + l.g + l.t);
-        P lpd = lo1 - (lp.a + lp.c + lp.g + lp.t);
-        store_block(slots + (A.cap - 1), ld, (u64)ld + sz - 1, lpd, (u64)lpd + sz - 1, lo0, (u64)lo0 + sz - 1, lo1, (u64)lo1 + sz - 1, (u32)L, af);
-        flagbits |= SIGAX_CC_CONTAIN;
-      }
+    find_flush(sg, flush, tid);
+  }
+  // a single record left in the row (u32 positions, odd count): 32 bytes = two pieces
+  {
+    const bool tail = !WIDE && live && !full && (nb & 1u);
+    if (tail) sg.tag[tid] = (slots + (u64)(nb - 1) * sizeof(Cand<WIDE>)) | 1u;
+    find_flush(sg, tail, tid);
+  }
+  bool contain = false;
+  if (live && sz != 0 && s >= L) {
+    // full-length interval: substring test and containment block (overlap_builder.cpp:889-904)
+    const Cnt4P<P> l = fm_rank4p<WIDE>(PI, lo0);
+    const Cnt4P<P> u = fm_rank4p<WIDE>(PI, (P)(lo0 + sz));
+    const Cnt4P<P> lp = fm_rank4p<WIDE>(OI, lo1);
+    const Cnt4P<P> up = fm_rank4p<WIDE>(OI, (P)(lo1 + sz));
+    nocc += 4;
+    bool dna = (u.a - l.a) | (u.c - l.c) | (u.g - l.g) | (u.t - l.t) | (up.a - lp.a) | (up.c - lp.c) | (up.g - lp.g) |
+               (up.t - lp.t);
+    if (dna) {
+      flagbits |= SIGAX_CC_SUBSTRING;
+    } else {
+      // no DNA extension on either side: all sz extensions are '$', so probe.updateL('$') keeps the whole
+      // range and probe.updateR('$') reuses the two positions of rext.
+      P ld = lo0 - (l.a + l.c + l.g + l.t);
+      P lpd = lo1 - (lp.a + lp.c + lp.g + lp.t);
+      cand_store(reinterpret_cast<Cand<WIDE>*>(&sg.row[tid][0]), ld, sz, lpd, lo0, lo1, sz, L, af);
+      sg.tag[tid] = (slots + (u64)(A.cap - 1) * sizeof(Cand<WIDE>)) | (WIDE ? 3u : 1u);
+      flagbits |= SIGAX_CC_CONTAIN;
+      contain = true;
     }
   }
+  find_flush(sg, contain, tid);
   if (read < A.read_end) {
     u32 word = (nb & SIGAX_CC_COUNT_MASK) | (flagbits & (SIGAX_CC_SUBSTRING | SIGAX_CC_CONTAIN));
     A.chain_cnt[(u64)read * 4 + o] = word;
@@ -327,7 +515,7 @@ struct Fx {
   bool xerror;    // extract() returned false
   u64 nocc;
   u32 read, nout;
-  const sigax_block* slots;  // this read's 4*cap candidate slots
+  const Cand<WIDE>* slots;  // this read's 4*cap candidate slots
 
   __device__ Fx(const FxArgs& a, const FmTables& t, Ent* p)
       : A(a), tb(t), F(fm_ref(a.fwd, 0)), R(fm_ref(a.rev, 1)), pool(p), top(0), overflow(false), xerror(false), nocc(0),
@@ -346,9 +534,9 @@ struct Fx {
   }
 
   __device__ void load_ent(Ent& e, u32 src) const {
-    const sigax_block& b = slots[src];
-    e.c0lo = b.capped0_lo; e.c0hi = b.capped0_hi; e.c1lo = b.capped1_lo; e.c1hi = b.capped1_hi;
-    e.src = src; e.len = b.length; e.pad0 = e.pad1 = 0;
+    const Cand<WIDE> b = cand_load<WIDE>(slots + src);
+    e.c0lo = b.c0lo; e.c0hi = (u64)b.c0lo + b.d - 1; e.c1lo = b.c1lo; e.c1hi = (u64)b.c1lo + b.d - 1;
+    e.src = src; e.len = b.len; e.pad0 = e.pad1 = 0;
   }
 
   // outblocks->push_back: emitted entries wait at the tail of the pool (growing downwards) until the read is done
@@ -369,8 +557,8 @@ struct Fx {
       u64 slot = fin_cur + i;
       if (slot >= A.fin_cap) break;
       const Ent& e = pool[A.pool_cap - 1 - i];
-      const sigax_block& b = slots[e.src];
-      store_block(A.fin + slot, e.c0lo, e.c0hi, e.c1lo, e.c1hi, b.raw0_lo, b.raw0_hi, b.raw1_lo, b.raw1_hi, b.length, b.af);
+      const Cand<WIDE> b = cand_load<WIDE>(slots + e.src);
+      store_block(A.fin + slot, e.c0lo, e.c0hi, e.c1lo, e.c1hi, b.r0lo, (u64)b.r0lo + b.sz - 1, b.r1lo, (u64)b.r1lo + b.sz - 1, b.len, b.af);
     }
     fin_cur += nout;
   }
@@ -449,12 +637,12 @@ struct Fx {
     if (higher->len == lower->len) return k;  // equal lengths: same coordinates (else the reference only logs)
     if (!(lower->c0lo < higher->c0lo || lower->c0hi > higher->c0hi)) return k;
     // re-map every reverse position of the lower block to its forward position by walking the BWT
-    const sigax_block& lb = slots[lower->src];
+    const Cand<WIDE> lb = cand_load<WIDE>(slots + lower->src);
     u64* used = reinterpret_cast<u64*>(pool + rb + rcap);  // pairs (key, next); room checked by the caller
     u32 nused = 0;
     for (u64 j = lower->c1lo; j <= lower->c1hi; ++j) {
       Ent ti;  // ti.ranges = lower->raw
-      ti.c0lo = lb.raw0_lo; ti.c0hi = lb.raw0_hi; ti.c1lo = lb.raw1_lo; ti.c1hi = lb.raw1_hi;
+      ti.c0lo = lb.r0lo; ti.c0hi = (u64)lb.r0lo + lb.sz - 1; ti.c1lo = lb.r1lo; ti.c1hi = (u64)lb.r1lo + lb.sz - 1;
       ti.src = lower->src; ti.len = lower->len; ti.pad0 = ti.pad1 = 0;
       u64 tlo = j, thi = j;
       bool done = false;
@@ -668,7 +856,7 @@ struct Fx {
     top = 0;
     overflow = false;
     xerror = false;
-    slots = A.arena + (u64)r * 4 * A.cap;
+    slots = reinterpret_cast<const Cand<WIDE>*>(A.arena) + (u64)r * 4 * A.cap;
     u64 L = A.offs[r + 1] - A.offs[r];
     u32 cc[4];
     for (int o = 0; o < 4; ++o) cc[o] = A.chain_cnt[(u64)r * 4 + o];
@@ -842,7 +1030,7 @@ struct GFx {
   u32 gb;      // first lane of this lane's group (0, or 32 for the second group when W == 32)
   u32 gl;      // lane inside the group
   u64 glt;     // group lanes below this one, as a mask over group lanes
-  const sigax_block* slots;
+  const Cand<WIDE>* slots;
   u32 nout;
   u32 nocc;
   bool xerror;
@@ -877,10 +1065,9 @@ struct GFx {
   __device__ FmRef ext_index(u32 src) const { return fm_pick(find_of(src) < 2, R, F); }
 
   __device__ void load_block(E& e, u32 src) const {
-    const ulonglong2* b = reinterpret_cast<const ulonglong2*>(slots + slot_of(src));
-    ulonglong2 c0 = b[0], c1 = b[1], t = b[4];
-    e.c0lo = (P)c0.x; e.c0hi = (P)c0.y; e.c1lo = (P)c1.x; e.c1hi = (P)c1.y;
-    e.src = src; e.len = (u32)t.x;
+    const Cand<WIDE> b = cand_load<WIDE>(slots + slot_of(src));
+    e.c0lo = b.c0lo; e.c0hi = b.c0lo + b.d - 1; e.c1lo = b.c1lo; e.c1hi = b.c1lo + b.d - 1;
+    e.src = src; e.len = b.len;
   }
   __device__ void pool_put(Ent* dst, const E& e) const {
     ulonglong2* d = reinterpret_cast<ulonglong2*>(dst);
@@ -1189,7 +1376,7 @@ struct GFx {
     nout = 0;
     nocc = 0;
     xerror = false;
-    slots = A.arena + (u64)r * 4 * A.cap;
+    slots = reinterpret_cast<const Cand<WIDE>*>(A.arena) + (u64)r * 4 * A.cap;
     const u32 L = (u32)(A.offs[r + 1] - A.offs[r]);
     u32 cc[4];
     {
@@ -1309,12 +1496,13 @@ struct GFx {
       if (gl == 0) A.item_base[2ull * r + sd] = base;
       if (gl < nout && base + gl < A.fin_cap) {
         const u32 src = sh.osrc[lane];
-        const ulonglong2* b = reinterpret_cast<const ulonglong2*>(slots + slot_of(src));
-        ulonglong2 r0 = b[2], r1 = b[3], t4 = b[4];
+        const Cand<WIDE> b = cand_load<WIDE>(slots + slot_of(src));
         ulonglong2* d = reinterpret_cast<ulonglong2*>(A.fin + base + gl);
         d[0] = make_ulonglong2(widen(sh.o0[lane]), widen(sh.o1[lane]));
         d[1] = make_ulonglong2(widen(sh.o2[lane]), widen(sh.o3[lane]));
-        d[2] = r0; d[3] = r1; d[4] = t4;
+        d[2] = make_ulonglong2((u64)b.r0lo, (u64)b.r0lo + b.sz - 1);
+        d[3] = make_ulonglong2((u64)b.r1lo, (u64)b.r1lo + b.sz - 1);
+        d[4] = make_ulonglong2((u64)b.len | ((u64)b.af << 32), 0ull);
       }
     }
     return done;
@@ -1342,7 +1530,7 @@ struct GFx {
 // the half's slots, output beyond its share) are queued for the W == 64 launch, which in turn queues what it cannot
 // finish for the general kernel.
 template <bool WIDE, int W>
-__global__ __launch_bounds__(256) void k_filter_extract_fast(FxArgs A) {
+__global__ __launch_bounds__(256) SIGAX_FX_ATTR void k_filter_extract_fast(FxArgs A) {
   __shared__ FmTables tb;
   __shared__ SideSh<WIDE> shm[4];
   fm_tables_load(tb, A.fwd, A.rev);
@@ -1721,6 +1909,7 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
   // 60 KB per workgroup = two workgroups (8 waves) per CU and 40 KB of LDS left for filter/extract workgroups.
   static const char* env = getenv("SIGAX_FIND_LDS");
   unsigned lds = env ? (unsigned)atoi(env) : 60000u;
+  lds = lds > (unsigned)sizeof(FindStage) ? lds - (unsigned)sizeof(FindStage) : 0u;  // the record staging rows are part of the budget
   if (wide) hipLaunchKernelGGL(k_find<true>, dim3(g), dim3(bs), lds, st, a);
   else hipLaunchKernelGGL(k_find<false>, dim3(g), dim3(bs), lds, st, a);
 }
@@ -1738,6 +1927,7 @@ void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid32, uns
 
 unsigned long long fast_pool_entries_per_wave() { return FX_WPOOL; }
 unsigned long long fast_fin_chunk() { return FX_FIN_CHUNK; }
+unsigned long long cand_bytes(bool wide) { return wide ? sizeof(Cand<true>) : sizeof(Cand<false>); }
 
 void launch_filter_extract(const FxArgs& a, bool wide, unsigned grid, hipStream_t st) {
   if (a.n_work == 0 && !a.n_work_ptr) return;
