@@ -69,6 +69,7 @@ struct sigax_index {
   // launch runs beside batch A's last filter/extract launch and finder launches never run beside each other.
   hipStream_t s_find, s_fx;
   std::mutex* enqueue_mu;
+  int n_cu;  // compute units of the device
 };
 
 // RL units (src/rlstring.h:10-63) -> 64-byte rank granules (fm_layout.h)
@@ -207,6 +208,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
   memset(ix, 0, sizeof(*ix));
   ix->device = device;
   ix->enqueue_mu = new std::mutex();
+  if (hipDeviceGetAttribute(&ix->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ix->n_cu <= 0) ix->n_cu = 256;
   {
     // the finder is the critical path of a step: its stream gets the higher priority
     int prio_least = 0, prio_greatest = 0;
@@ -579,8 +581,10 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   if ((rc = ensure(&b->substring, (size_t)n + 16)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->block_offs, ((size_t)n + 2) * 8)) != SIGAX_OK) return rc;
   // fast filter/extract kernel: persistent waves (one read at a time per wave) with a private pool each
+  // Three workgroups per CU: all of them are resident beside the finder's two (register file: 2 x 64 + 3 x 128 per
+  // SIMD), so no filter/extract workgroup is left waiting to take the slot a finished finder workgroup frees.
   static const char* env_fxg = getenv("SIGAX_FX_GRID");
-  unsigned fast_grid = (unsigned)std::min<u64>(env_fxg ? (u64)atoi(env_fxg) : 2048, ((u64)n + 3) / 4);  // two items per wave
+  unsigned fast_grid = (unsigned)std::min<u64>(env_fxg ? (u64)atoi(env_fxg) : 3u * (unsigned)ix->n_cu, ((u64)n + 3) / 4);  // two items per wave
   if (fast_grid == 0) fast_grid = 1;
   if ((rc = ensure(&b->wpool, (size_t)fast_grid * 4 * fast_pool_entries_per_wave() * SIGAX_ENT_BYTES)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->work, ((size_t)n + 1) * 4)) != SIGAX_OK) return rc;
@@ -636,6 +640,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.cap = b->cap;
     fa.read_begin = rb;
     fa.read_end = re;
+    fa.stage_bytes = 0;  // set by launch_find
     fa.arena = b->arena.p;
     fa.chain_cnt = (uint32_t*)b->chain_cnt.p;
     fa.dstat = dstat;

@@ -38,6 +38,7 @@ struct FindArgs {
   const unsigned long long* offs;
   uint32_t n_reads, minov, chain_mask, cap;  // chain_mask bit o = find o runs; cap = slots per chain, last = containment
   uint32_t read_begin, read_end;     // this launch's sub-batch
+  uint32_t stage_bytes;              // dynamic LDS per workgroup that may hold the workgroup's reads (set by launch_find)
   void* arena;                       // [n_reads][4][cap] candidate records of cand_bytes(wide) each
   uint32_t* chain_cnt;               // [n_reads][4]
   unsigned long long* dstat;

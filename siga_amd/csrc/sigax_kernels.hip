@@ -38,12 +38,6 @@ template <typename P> struct Cnt4P {
 // with u64) = one or two 16-byte stores per half instead of the five scattered ones of an 80-byte sigax_block.
 //   capped[0] = [c0lo, c0lo + d - 1], capped[1] = [c1lo, c1lo + d - 1]   (both intervals of a pair have one size)
 //   raw[0]    = [r0lo, r0lo + sz - 1], raw[1]   = [r1lo, r1lo + sz - 1]
-#ifndef SIGAX_FIND_ATTR
-#define SIGAX_FIND_ATTR
-#endif
-#ifndef SIGAX_FX_ATTR
-#define SIGAX_FX_ATTR
-#endif
 template <bool WIDE> struct Cand;
 template <> struct __attribute__((aligned(32))) Cand<false> {
   u32 c0lo, d, c1lo, r0lo, r1lo, sz, len, af;
@@ -210,6 +204,56 @@ __device__ __forceinline__ void find_step_loads(const void* qa, const void* qb, 
       : "v"(qa), "v"(qb), "v"(pc)
       : "memory");
 }
+// Same with wave-uniform bases in scalar registers and 32-bit byte offsets per lane (granule table < 4 GiB, i.e. the
+// u32-position index; the reads of one wave lie within 4 GiB of the wave's first read).
+__device__ __forceinline__ void find_step_loads_s(const void* gbase, u32 offa, u32 offb, const void* sbase, u32 offc, Gran& a, Gran& b,
+                                                  u32& ch) {
+  asm volatile(
+      "global_load_dwordx4 %0, %9, %12\n\t"
+      "global_load_dwordx4 %4, %10, %12\n\t"
+      "global_load_ubyte %8, %11, %13\n\t"
+      "global_load_dwordx4 %1, %9, %12 offset:16\n\t"
+      "global_load_dwordx4 %2, %9, %12 offset:32\n\t"
+      "global_load_dwordx4 %3, %9, %12 offset:48\n\t"
+      "global_load_dwordx4 %5, %10, %12 offset:16\n\t"
+      "global_load_dwordx4 %6, %10, %12 offset:32\n\t"
+      "global_load_dwordx4 %7, %10, %12 offset:48\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a.k0), "=&v"(a.k1), "=&v"(a.k2), "=&v"(a.k3), "=&v"(b.k0), "=&v"(b.k1), "=&v"(b.k2), "=&v"(b.k3), "=&v"(ch)
+      : "v"(offa), "v"(offb), "v"(offc), "s"(gbase), "s"(sbase)
+      : "memory");
+}
+// The two variants without the base load: the workgroup's reads are staged in LDS (the usual case)
+__device__ __forceinline__ void find_step_loads8(const void* qa, const void* qb, Gran& a, Gran& b) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off\n\t"
+      "global_load_dwordx4 %4, %9, off\n\t"
+      "global_load_dwordx4 %1, %8, off offset:16\n\t"
+      "global_load_dwordx4 %2, %8, off offset:32\n\t"
+      "global_load_dwordx4 %3, %8, off offset:48\n\t"
+      "global_load_dwordx4 %5, %9, off offset:16\n\t"
+      "global_load_dwordx4 %6, %9, off offset:32\n\t"
+      "global_load_dwordx4 %7, %9, off offset:48\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a.k0), "=&v"(a.k1), "=&v"(a.k2), "=&v"(a.k3), "=&v"(b.k0), "=&v"(b.k1), "=&v"(b.k2), "=&v"(b.k3)
+      : "v"(qa), "v"(qb)
+      : "memory");
+}
+__device__ __forceinline__ void find_step_loads8_s(const void* gbase, u32 offa, u32 offb, Gran& a, Gran& b) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, %10\n\t"
+      "global_load_dwordx4 %4, %9, %10\n\t"
+      "global_load_dwordx4 %1, %8, %10 offset:16\n\t"
+      "global_load_dwordx4 %2, %8, %10 offset:32\n\t"
+      "global_load_dwordx4 %3, %8, %10 offset:48\n\t"
+      "global_load_dwordx4 %5, %9, %10 offset:16\n\t"
+      "global_load_dwordx4 %6, %9, %10 offset:32\n\t"
+      "global_load_dwordx4 %7, %9, %10 offset:48\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a.k0), "=&v"(a.k1), "=&v"(a.k2), "=&v"(a.k3), "=&v"(b.k0), "=&v"(b.k1), "=&v"(b.k2), "=&v"(b.k3)
+      : "v"(offa), "v"(offb), "s"(gbase)
+      : "memory");
+}
 __device__ __forceinline__ void chunk_count(const v4u& k, int take, u32& a, u32& c, u32& g, u32& t) {
   u32 m = take >= 32 ? 0xFFFFFFFFu : (take <= 0 ? 0u : ((1u << take) - 1u));
   u32 x0 = k.y & m, x1 = k.z & m, x2 = k.w & m;
@@ -305,7 +349,7 @@ __global__ __launch_bounds__(256) void k_kmer_count(FmStrand s, const unsigned c
 }
 
 // -------------------------------------------------------------------------------------------------------
-// k_find: one lane per (read, orientation) chain.  Per step: two rank granules on the chain's primary index
+// k_find: one lane per (read, orientation) chain; the four waves of a workgroup are the four chains of 64 reads.  Per step: two rank granules on the chain's primary index
 // (positions lower-1 and upper of IntervalPair::updateL, src/overlap_builder.cpp:95-122); the '$' probe of
 // src/overlap_builder.cpp:861-871 reuses them.  Blocks go to the chain's slots of the candidate arena in
 // increasing overlap length = the reference's push order.
@@ -322,7 +366,7 @@ __device__ __forceinline__ void store_block(sigax_block* dst, u64 c0lo, u64 c0hi
 
 // Candidate records leave the finder as full 64-byte lines.  A lane that produced a record parks it in its LDS row
 // (two 32-byte records per row with u32 positions, one 64-byte record with u64); once the row is full the FOUR lanes
-// of the lane's quad -- the four chains of one read, which walk the loop together -- each take a 16-byte piece of
+// of the lane's quad (all lanes of a wave stay in the loop until its last chain is done) each take a 16-byte piece of
 // that row and write the pieces with one store instruction: one 64-byte request per line instead of one 16-byte
 // request per piece (measured at C2: the finder's 160 M scattered piece stores cost 1.8 of its 12.3 ms; the memory
 // system counts requests, not bytes).  `tag` = destination byte address | number of 16-byte pieces to write - 1.
@@ -350,18 +394,18 @@ __device__ __forceinline__ void find_flush(FindStage& sg, bool want, u32 tid) {
   __builtin_amdgcn_wave_barrier();
 }
 
-template <bool WIDE>
-__global__ __launch_bounds__(256) SIGAX_FIND_ATTR void k_find(FindArgs A) {
-  __shared__ FmTables tb;
-  __shared__ FindStage sg;
+// STAGED: the workgroup's 64 reads (one contiguous byte range of the batch) are in LDS at `rd`, first byte = the
+// 4-byte-aligned address at or below the first read's first base; rd_base = that address's offset in A.seqs.
+template <bool WIDE, bool STAGED>
+__device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindStage& sg, const unsigned char* rd, u64 rd_base) {
 #ifdef SIGAX_FIND_PRIO
   __builtin_amdgcn_s_setprio(SIGAX_FIND_PRIO);  // the finder's short dependent chain wins issue arbitration over filter/extract waves
 #endif
-  fm_tables_load(tb, A.fwd, A.rev);
-
+  // A workgroup = 64 reads; wave o of it walks chain o of each, so everything that depends on the chain (which index
+  // is primary, complementing, the direction the read is consumed in) is wave-uniform and lives in scalar registers.
   const u32 tid = threadIdx.x;
-  u64 gid = (u64)blockIdx.x * blockDim.x + tid;
-  u32 read = A.read_begin + (u32)(gid >> 2), o = (u32)gid & 3u;
+  const u32 o = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const u32 read = A.read_begin + blockIdx.x * 64u + (tid & 63u);
   typedef typename PosOf<WIDE>::type P;
   u32 nocc = 0;
   u32 nb = 0, flagbits = 0;
@@ -383,12 +427,20 @@ __global__ __launch_bounds__(256) SIGAX_FIND_ATTR void k_find(FindArgs A) {
   const bool fromStart = (o == 1 || o == 2);  // reversed strings are consumed from the read's first base
   const u32 af = o == 0 ? SIGAX_AF_CHAIN0 : o == 1 ? SIGAX_AF_CHAIN1 : o == 2 ? SIGAX_AF_CHAIN2 : SIGAX_AF_CHAIN3;
   const unsigned char* sq = A.seqs + b0;
+  const u32 rdo = (u32)(b0 - rd_base);  // this read's first base in the staged copy
+  // wave-uniform base of the wave's reads (lane 0's read always exists) + this lane's distance from it
+  const u64 b0w = ((u64)__builtin_amdgcn_readfirstlane((u32)(b0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)b0);
+  const unsigned char* sq0 = A.seqs + b0w;
+  const u32 sqd = (u32)(b0 - b0w);
   // cap is even (sigax_api.cpp) so every chain's slots start on a 64-byte line
-  const u64 slots = reinterpret_cast<u64>(A.arena) + ((u64)(live ? read : 0u) * 4 + o) * A.cap * sizeof(Cand<WIDE>);
+  // byte address of this chain's slot i (computed where a record is parked: cheaper than two live registers)
+  auto slot_addr = [&](u32 i) -> u64 {
+    return reinterpret_cast<u64>(A.arena) + (((u64)read * 4 + o) * A.cap + i) * sizeof(Cand<WIDE>);
+  };
 
   P lo0 = 0, sz = 0, lo1 = 0;
   if (live) {
-    u32 r = base_rank(sq[fromStart ? 0 : L - 1]);
+    u32 r = base_rank(STAGED ? rd[rdo + (fromStart ? 0 : L - 1)] : sq[fromStart ? 0 : L - 1]);
     if (comp) r = comp_rank(r);
     // IntervalPair::init (overlap_builder.cpp:91-94, fmindex.h:90-93)
     lo0 = (P)CP[r]; sz = (P)tb.T[PI.which][r]; lo1 = (P)CO[r];
@@ -407,10 +459,17 @@ __global__ __launch_bounds__(256) SIGAX_FIND_ATTR void k_find(FindArgs A) {
       const u64 pu = pu0 > PI.n ? PI.n : pu0;
       Gran gl, gu;
       u32 ch;
-      find_step_loads(PI.g + (pl >> 7) * 4, PI.g + (pu >> 7) * 4, sq + (fromStart ? s : L - 1 - s), gl, gu, ch);
+      if (STAGED) {
+        ch = rd[rdo + (fromStart ? s : L - 1 - s)];
+        if (WIDE) find_step_loads8(PI.g + (pl >> 7) * 4, PI.g + (pu >> 7) * 4, gl, gu);
+        else find_step_loads8_s(PI.g, (u32)(pl >> 7) * 64u, (u32)(pu >> 7) * 64u, gl, gu);
+      } else if (WIDE) {
+        find_step_loads(PI.g + (pl >> 7) * 4, PI.g + (pu >> 7) * 4, sq + (fromStart ? s : L - 1 - s), gl, gu, ch);
+      } else {
+        find_step_loads_s(PI.g, (u32)(pl >> 7) * 64u, (u32)(pu >> 7) * 64u, sq0, sqd + (fromStart ? s : L - 1 - s), gl, gu, ch);
+      }
       const Cnt4P<P> l = fm_rank4p_from<WIDE>(PI, pl, gl);
       const Cnt4P<P> u = fm_rank4p_from<WIDE>(PI, pu, gu);
-      nocc += 2;
       u32 r = base_rank(ch & 0xFFu);
       if (comp) r = comp_rank(r);
       P da = u.a - l.a, dc = u.c - l.c, dg = u.g - l.g, dt = u.t - l.t;
@@ -421,12 +480,12 @@ __global__ __launch_bounds__(256) SIGAX_FIND_ATTR void k_find(FindArgs A) {
         if (nb < A.cap - 1 && !full) {
           if (WIDE) {
             cand_store(reinterpret_cast<Cand<WIDE>*>(&sg.row[tid][0]), ld, dd, lo1, lo0, lo1, sz, s, af);
-            sg.tag[tid] = (slots + (u64)nb * sizeof(Cand<WIDE>)) | 3u;
+            sg.tag[tid] = slot_addr(nb) | 3u;
             flush = true;
           } else {
             cand_store(reinterpret_cast<Cand<WIDE>*>(&sg.row[tid][(nb & 1u) * 2]), ld, dd, lo1, lo0, lo1, sz, s, af);
             if (nb & 1u) {
-              sg.tag[tid] = (slots + (u64)(nb - 1) * sizeof(Cand<WIDE>)) | 3u;
+              sg.tag[tid] = slot_addr(nb - 1) | 3u;
               flush = true;
             }
           }
@@ -451,16 +510,25 @@ __global__ __launch_bounds__(256) SIGAX_FIND_ATTR void k_find(FindArgs A) {
   // a single record left in the row (u32 positions, odd count): 32 bytes = two pieces
   {
     const bool tail = !WIDE && live && !full && (nb & 1u);
-    if (tail) sg.tag[tid] = (slots + (u64)(nb - 1) * sizeof(Cand<WIDE>)) | 1u;
+    if (tail) sg.tag[tid] = slot_addr(nb - 1) | 1u;
     find_flush(sg, tail, tid);
   }
   bool contain = false;
+  nocc = live ? 2u * (s - 1u) : 0u;  // two rank positions per step taken
   if (live && sz != 0 && s >= L) {
     // full-length interval: substring test and containment block (overlap_builder.cpp:889-904)
-    const Cnt4P<P> l = fm_rank4p<WIDE>(PI, lo0);
-    const Cnt4P<P> u = fm_rank4p<WIDE>(PI, (P)(lo0 + sz));
-    const Cnt4P<P> lp = fm_rank4p<WIDE>(OI, lo1);
-    const Cnt4P<P> up = fm_rank4p<WIDE>(OI, (P)(lo1 + sz));
+    // two granules at a time (the step loader again): four at once would set the kernel's register count
+    auto clampn = [](u64 p, u64 n) { return p > n ? n : p; };
+    const u64 pl = clampn((u64)lo0, PI.n), pu = clampn((u64)(P)(lo0 + sz), PI.n);
+    const u64 ql = clampn((u64)lo1, OI.n), qu = clampn((u64)(P)(lo1 + sz), OI.n);
+    Gran ga, gb;
+    u32 ignored;
+    find_step_loads(PI.g + (pl >> 7) * 4, PI.g + (pu >> 7) * 4, sq, ga, gb, ignored);
+    const Cnt4P<P> l = fm_rank4p_from<WIDE>(PI, pl, ga);
+    const Cnt4P<P> u = fm_rank4p_from<WIDE>(PI, pu, gb);
+    find_step_loads(OI.g + (ql >> 7) * 4, OI.g + (qu >> 7) * 4, sq, ga, gb, ignored);
+    const Cnt4P<P> lp = fm_rank4p_from<WIDE>(OI, ql, ga);
+    const Cnt4P<P> up = fm_rank4p_from<WIDE>(OI, qu, gb);
     nocc += 4;
     bool dna = (u.a - l.a) | (u.c - l.c) | (u.g - l.g) | (u.t - l.t) | (up.a - lp.a) | (up.c - lp.c) | (up.g - lp.g) |
                (up.t - lp.t);
@@ -472,7 +540,7 @@ __global__ __launch_bounds__(256) SIGAX_FIND_ATTR void k_find(FindArgs A) {
       P ld = lo0 - (l.a + l.c + l.g + l.t);
       P lpd = lo1 - (lp.a + lp.c + lp.g + lp.t);
       cand_store(reinterpret_cast<Cand<WIDE>*>(&sg.row[tid][0]), ld, sz, lpd, lo0, lo1, sz, L, af);
-      sg.tag[tid] = (slots + (u64)(A.cap - 1) * sizeof(Cand<WIDE>)) | (WIDE ? 3u : 1u);
+      sg.tag[tid] = slot_addr(A.cap - 1) | (WIDE ? 3u : 1u);
       flagbits |= SIGAX_CC_CONTAIN;
       contain = true;
     }
@@ -490,6 +558,45 @@ __global__ __launch_bounds__(256) SIGAX_FIND_ATTR void k_find(FindArgs A) {
     if (tot_blk) atomicAdd(&A.dstat[DS_CAND_BLOCKS], tot_blk);
     if (tot_err) atomicAdd(&A.dstat[DS_FIND_OVERFLOW], tot_err);
   }
+}
+
+// Copies the workgroup's reads into the dynamic LDS when they fit (whole aligned words: the words holding the first and
+// the last base belong to the same allocation as the bases); returns whether it did.
+extern __shared__ __attribute__((aligned(16))) unsigned char find_dyn_lds[];
+__device__ __forceinline__ bool find_stage_reads(const FindArgs& A, u64* rd_base) {
+  const u32 r0 = A.read_begin + blockIdx.x * 64u;
+  const u32 r1 = r0 + 64u < A.read_end ? r0 + 64u : A.read_end;
+  const u64 lo = A.offs[r0], hi = A.offs[r1];
+  const u64 alo = (reinterpret_cast<u64>(A.seqs) + lo) & ~3ull;
+  const u64 nbytes = reinterpret_cast<u64>(A.seqs) + hi - alo;
+  *rd_base = alo - reinterpret_cast<u64>(A.seqs);
+  if (nbytes + 4 > (u64)A.stage_bytes) return false;
+  const u32* src = reinterpret_cast<const u32*>(alo);
+  u32* dst = reinterpret_cast<u32*>(find_dyn_lds);
+  const u32 nw = (u32)((nbytes + 3) >> 2);
+  for (u32 w = threadIdx.x; w < nw; w += 256u) dst[w] = src[w];
+  return true;
+}
+
+// u32 positions: held to 64 registers, so that two finder workgroups and three filter/extract waves per SIMD fit the
+// 512-entry register file together (2 x 64 + 3 x 128)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_find_n(FindArgs A) {
+  __shared__ FmTables tb;
+  __shared__ FindStage sg;
+  u64 rd_base = 0;
+  const bool staged = find_stage_reads(A, &rd_base);
+  fm_tables_load(tb, A.fwd, A.rev);  // ends with the workgroup barrier that also publishes the staged reads
+  if (staged) find_body<false, true>(A, tb, sg, find_dyn_lds, rd_base);
+  else find_body<false, false>(A, tb, sg, find_dyn_lds, rd_base);
+}
+__global__ __launch_bounds__(256) void k_find_w(FindArgs A) {
+  __shared__ FmTables tb;
+  __shared__ FindStage sg;
+  u64 rd_base = 0;
+  const bool staged = find_stage_reads(A, &rd_base);
+  fm_tables_load(tb, A.fwd, A.rev);
+  if (staged) find_body<true, true>(A, tb, sg, find_dyn_lds, rd_base);
+  else find_body<true, false>(A, tb, sg, find_dyn_lds, rd_base);
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -1196,9 +1303,6 @@ struct GFx {
     const u64 g0 = p0 >> 7;
     const bool inside = mine && p1 > p0 && ((p1 - 1) >> 7) == g0 && p1 <= ix.n;
     if (gballot(mine && !inside)) return round(e, alive, newAlive);
-    const u32 first = ffs0(alive);
-    const u32 topLen = gshfl(e.len, first);
-    const bool isTop = mine && e.len == topLen;
     const bool qcomp = (af_of(e.src) & 4u) != 0;
     uint4 k[4];
     k[0] = k[1] = k[2] = k[3] = make_uint4(0, 0, 0, 0);
@@ -1207,7 +1311,48 @@ struct GFx {
       k[0] = q[0]; k[1] = q[1]; k[2] = q[2]; k[3] = q[3];
     }
     const int r0 = (int)(p0 & 127u), r1 = (int)(p1 - (g0 << 7));  // 0 <= r0 < r1 <= 128
+    const u32 first = ffs0(alive);
+    // Cheapest form, and the usual one between two read ends: every alive block's range holds ONE symbol, the same
+    // (after complementing) for all of them.  "One symbol" = no position of the range differs from the symbol at its
+    // first position, a xor/or over the planes; the positions that equal it also give the rank for the update.
+    {
+      const u32 j0 = (u32)r0 >> 5, bit0 = (u32)r0 & 31u;
+      const bool j0b0 = (j0 & 1u) != 0, j0b1 = (j0 & 2u) != 0;
+      const u32 ys = j0b1 ? (j0b0 ? k[3].y : k[2].y) : (j0b0 ? k[1].y : k[0].y);
+      const u32 zs = j0b1 ? (j0b0 ? k[3].z : k[2].z) : (j0b0 ? k[1].z : k[0].z);
+      const u32 ws = j0b1 ? (j0b0 ? k[3].w : k[2].w) : (j0b0 ? k[1].w : k[0].w);
+      const u32 fy = 0u - ((ys >> bit0) & 1u), fz = 0u - ((zs >> bit0) & 1u), fw = 0u - ((ws >> bit0) & 1u);
+      u32 diff = 0, cntb = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int lo = min(max(r0 - 32 * j, 0), 32), hi = min(max(r1 - 32 * j, 0), 32), wd = hi - lo;
+        const u32 rm = wd == 32 ? 0xFFFFFFFFu : (((1u << (wd & 31)) - 1u) << (lo & 31));
+        const u32 below = lo == 32 ? 0xFFFFFFFFu : ((1u << (lo & 31)) - 1u);
+        const u32 d = (k[j].y ^ fy) | (k[j].z ^ fz) | (k[j].w ^ fw);  // positions whose symbol is not the first one's
+        diff |= d & rm;
+        cntb += __popc(~d & below);
+      }
+      const u32 c = fw ? 4u : ((fy & 1u) | (fz & 2u));  // planes -> rank: A = p0 only, C = p1 only, G = both, T = p2
+      const u32 cq = (qcomp && c) ? 5u - c : c;
+      const u32 cfirst = gshfl(cq, first);
+      if (cfirst != 0 && gballot(mine && (diff != 0 || cq != cfirst)) == 0) {
+        nocc += 2u * pop(alive);
+        if (mine) {
+          const bool hb0 = ((c - 1u) & 1u) != 0, hb1 = ((c - 1u) & 2u) != 0;
+          const u32 hdr = hb1 ? (hb0 ? k[3].x : k[2].x) : (hb0 ? k[1].x : k[0].x);
+          P lbp = (P)(hdr + cntb);
+          if (WIDE) lbp += (P)ix.super[(p0 >> SIGAX_SUPER_SHIFT) * 4 + (c - 1u)];
+          const P size = e.c1hi - e.c1lo;
+          e.c1lo = (P)tb.C[ix.which][c] + lbp;
+          e.c1hi = e.c1lo + size;
+        }
+        *newAlive = alive;
+        return RD_UPDATED;
+      }
+    }
     u32 lom[4], pa = 0, pc = 0, pg = 0, pt = 0, pd = 0;
+    const u32 topLen = gshfl(e.len, first);
+    const bool isTop = mine && e.len == topLen;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int t0 = r0 - 32 * j, t1 = r1 - 32 * j;
@@ -1308,6 +1453,9 @@ struct GFx {
       while (alive) {
         u64 na = 0;
         int st = round_fast(e, alive, &na);
+#ifdef FX_PHASE_TIMING
+        ++nrounds;
+#endif
         if (st == RD_BAIL) return false;
         if (st == RD_XERROR) return true;
         if (st != RD_UPDATED) break;
@@ -1371,8 +1519,19 @@ struct GFx {
   }
 
   // one (read, side) item on this lane group; returns false when it must be redone by a wider kernel
+#ifdef FX_PHASE_TIMING
+  u64 tph[6] = {0, 0, 0, 0, 0, 0};
+  u32 nrounds = 0, npass = 0;
+#define PH(i) { u64 t_ = __builtin_readcyclecounter(); tph[i] += t_ - tlast; tlast = t_; }
+#else
+#define PH(i)
+#endif
   __device__ bool body(u32 r, u32 sd) {
     const u32 OUTCAP = W == 64 ? FX_OUTCAP : FX_OUTCAP / 2;
+#ifdef FX_PHASE_TIMING
+    u64 tlast = __builtin_readcyclecounter();
+    ++npass;
+#endif
     nout = 0;
     nocc = 0;
     xerror = false;
@@ -1416,6 +1575,7 @@ struct GFx {
     E e;
     e.c0lo = e.c0hi = e.c1lo = e.c1hi = 0; e.src = 0; e.len = 0;
     if (active) load_block(e, src);
+    PH(0)
     const bool member = active && e.len != L;  // ContainmentBlockRemover (:1094-1111)
     const u32 nm = pop(gballot(member));
     // SubMaximalBlockFilter::filter (:930-953) sorts by capped[0].lower and resolves adjacent intersecting blocks.
@@ -1424,6 +1584,17 @@ struct GFx {
     // list decides exactly whether resolve() is needed; if so the item goes to the general kernel.
     u32 rank = 0;  // stable rank by capped[0].lower inside the own list (only the exhaustive output order needs it)
     bool inter = false;
+    if (A.irreducible) {
+      // only the yes/no is needed: each lane walks its own list's bounds, parked in LDS
+      if (active) { sh.e0[gb + gl] = e.c0lo; sh.e1[gb + gl] = e.c0hi; }
+      wave_lds_sync();
+      const u32 jend = active ? (list ? T : nX) : 0u;
+      for (u32 j = list ? nX : 0u; j < jend; ++j) {
+        const P loj = sh.e0[gb + j], hij = sh.e1[gb + j];
+        inter |= (j != gl) & !(e.c0lo > hij || loj > e.c0hi);  // coord.h:37-40
+      }
+      wave_lds_sync();
+    } else
     for (u32 j = 0; j < T; ++j) {
       P loj = gshfl(e.c0lo, j), hij = gshfl(e.c0hi, j);
       u32 lj = j >= nX ? 1u : 0u, kj = lj ? j - nX : j;
@@ -1431,6 +1602,7 @@ struct GFx {
       if (!A.irreducible && same && (loj < e.c0lo || (loj == e.c0lo && kj < k))) ++rank;
       inter |= same & (j != gl) & !(e.c0lo > hij || loj > e.c0hi);  // coord.h:37-40
     }
+    PH(1)
     if (gballot(inter)) return false;
     if (A.irreducible) {
       // X += Y; stable sort by length descending (:715-716,1169), ties keep list X first.  Both finds pushed their
@@ -1459,7 +1631,10 @@ struct GFx {
         g.src = sh.esrc[lane]; g.len = sh.elen[lane];
       }
       wave_lds_sync();
-      return extract(g, nm);
+      PH(2)
+      bool okx = extract(g, nm);
+      PH(3)
+      return okx;
     }
     // exhaustive: the filtered lists go out as they are, X then Y, each in capped[0].lower order (:1175-1178)
     u32 pos = 0;
@@ -1530,7 +1705,7 @@ struct GFx {
 // the half's slots, output beyond its share) are queued for the W == 64 launch, which in turn queues what it cannot
 // finish for the general kernel.
 template <bool WIDE, int W>
-__global__ __launch_bounds__(256) SIGAX_FX_ATTR void k_filter_extract_fast(FxArgs A) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 1 : 4))) void k_filter_extract_fast(FxArgs A) {
   __shared__ FmTables tb;
   __shared__ SideSh<WIDE> shm[4];
   fm_tables_load(tb, A.fwd, A.rev);
@@ -1551,6 +1726,10 @@ __global__ __launch_bounds__(256) SIGAX_FX_ATTR void k_filter_extract_fast(FxArg
       }
       fx.account(has, done, item, nocc_total, nerr, nsub);
     }
+#ifdef FX_PHASE_TIMING
+    if (blockIdx.x == 7 && threadIdx.x == 0)
+      printf("fxphase npass %u rounds %u load %llu pair %llu sort %llu extract %llu\n", fx.npass, fx.nrounds, fx.tph[0], fx.tph[1], fx.tph[2], fx.tph[3]);
+#endif
   } else {
     const u64 n = *A.w64_counter;
     for (u64 i = wave; i < n; i += nwaves) {
@@ -1902,7 +2081,7 @@ void launch_correct(const CorrectArgs& a, bool wide, hipStream_t st) {
 void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
   if (a.read_end <= a.read_begin) return;
   const unsigned bs = 256u;
-  unsigned g = nblk((u64)(a.read_end - a.read_begin) * 4, bs);
+  unsigned g = nblk((u64)(a.read_end - a.read_begin), 64u);  // 64 reads x 4 chains per workgroup
   // Unused dynamic LDS caps the finder's residency (it saturates the memory request rate with few waves), leaving
   // wave slots and registers for the filter/extract kernel that runs beside it on the other stream.
   // Measured on MI355X at C2: 28 resident waves/CU 15.7 ms, 12 waves 14.5 ms, 8 waves 13.4 ms, 4 waves 14.9 ms.
@@ -1910,8 +2089,10 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
   static const char* env = getenv("SIGAX_FIND_LDS");
   unsigned lds = env ? (unsigned)atoi(env) : 60000u;
   lds = lds > (unsigned)sizeof(FindStage) ? lds - (unsigned)sizeof(FindStage) : 0u;  // the record staging rows are part of the budget
-  if (wide) hipLaunchKernelGGL(k_find<true>, dim3(g), dim3(bs), lds, st, a);
-  else hipLaunchKernelGGL(k_find<false>, dim3(g), dim3(bs), lds, st, a);
+  FindArgs b = a;
+  b.stage_bytes = lds;  // the residency cap doubles as the staging buffer for the workgroup's reads
+  if (wide) hipLaunchKernelGGL(k_find_w, dim3(g), dim3(bs), lds, st, b);
+  else hipLaunchKernelGGL(k_find_n, dim3(g), dim3(bs), lds, st, b);
 }
 
 void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid32, unsigned grid64, hipStream_t st) {
