@@ -197,14 +197,17 @@ def main():
         for k in range(k0 + n, k0 + n + depth):  # complete in submission order
             complete(k % depth)
 
-    run_steps(args.warmup)
+    # every batch object runs once before anything is counted (its first run allocates its device workspace), then the
+    # W warm-up steps
+    run_steps(depth)
+    run_steps(args.warmup, depth)
     drain()
     ksum[:] = 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t_start = time.perf_counter()
-    run_steps(args.steps, args.warmup)
+    run_steps(args.steps, depth + args.warmup)
     total_edges = last_edges[0]
     if world > 1:
         total_edges = drain()  # every step's edge records have reached rank 0 before the clock stops

@@ -67,7 +67,7 @@ struct sigax_index {
   // The internal pipeline streams belong to the index, not to a batch: every batch on this index queues its finder
   // launches on s_find and its filter/extract launches on s_fx, so with two batches in flight batch B's first finder
   // launch runs beside batch A's last filter/extract launch and finder launches never run beside each other.
-  hipStream_t s_find, s_fx;
+  hipStream_t s_find, s_fx, s_tail;
   std::mutex* enqueue_mu;
   int n_cu;  // compute units of the device
 };
@@ -190,6 +190,7 @@ extern "C" void sigax_index_close(sigax_index* ix) {
   if (ix->d_name_rank) hipFree(ix->d_name_rank);
   if (ix->s_find) hipStreamDestroy(ix->s_find);
   if (ix->s_fx) hipStreamDestroy(ix->s_fx);
+  if (ix->s_tail) hipStreamDestroy(ix->s_tail);
   delete ix->enqueue_mu;
   delete ix;
 }
@@ -215,6 +216,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
     hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_find, hipStreamNonBlocking, prio_greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_fx, hipStreamNonBlocking, prio_least);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_tail, hipStreamNonBlocking, prio_greatest);
     if (e != hipSuccess) {
       sigax_index_close(ix);
       return fail(SIGAX_E_DEVICE, "creating the pipeline streams: %s", hipGetErrorString(e));
@@ -699,10 +701,14 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     HIP_TRY(hipEventRecord(b->sev[i][SV_G1], ix->s_fx));
   }
   HIP_TRY(hipEventRecord(b->ev[EV_FX_DONE], ix->s_fx));
-  HIP_TRY(hipStreamWaitEvent(st, b->ev[EV_FX_DONE], 0));
+  // The short tail (scan, ordered scatter, edge records) runs on its own high-priority stream: queued behind the
+  // long kernels of the next batch on an ordinary stream it took ten times its own duration and held up the
+  // batch's completion, i.e. the moment the caller can submit this batch object again.
+  hipStream_t ts = ix->s_tail;
+  HIP_TRY(hipStreamWaitEvent(ts, b->ev[EV_FX_DONE], 0));
 
-  launch_scan((const uint32_t*)b->fin_cnt.p, 2 * (u64)n, (u64*)b->partial.p, (u64*)b->offs2.p, dstat + DS_TOTAL_BLOCKS, st);
-  launch_pick_read_offsets((const u64*)b->offs2.p, n, (u64*)b->block_offs.p, st);
+  launch_scan((const uint32_t*)b->fin_cnt.p, 2 * (u64)n, (u64*)b->partial.p, (u64*)b->offs2.p, dstat + DS_TOTAL_BLOCKS, ts);
+  launch_pick_read_offsets((const u64*)b->offs2.p, n, (u64*)b->block_offs.p, ts);
   OrderArgs oa;
   oa.fin = (const sigax_block*)b->fin.p;
   oa.item_base = (const u64*)b->item_base.p;
@@ -712,8 +718,8 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   oa.offs2 = (const u64*)b->offs2.p;
   oa.out = (sigax_block*)b->outb.p;
   oa.out_cap = b->fin_cap;
-  launch_order_scatter(oa, st);
-  HIP_TRY(hipEventRecord(b->ev[EV_ORDER], st));
+  launch_order_scatter(oa, ts);
+  HIP_TRY(hipEventRecord(b->ev[EV_ORDER], ts));
 
   if (edges) {
     EdgeArgs ea;
@@ -731,12 +737,13 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     ea.edge_offs = (const u64*)b->edge_offs.p;
     ea.edges = (sigax_edge*)b->edges.p;
     ea.edge_cap = b->edge_cap;
-    launch_edges(ea, false, b->fin_cap, st);
+    launch_edges(ea, false, b->fin_cap, ts);
     launch_scan((const uint32_t*)b->edge_cnt.p, b->fin_cap, (u64*)b->partial.p, (u64*)b->edge_offs.p,
-                dstat + DS_TOTAL_EDGES, st);
-    launch_edges(ea, true, b->fin_cap, st);
+                dstat + DS_TOTAL_EDGES, ts);
+    launch_edges(ea, true, b->fin_cap, ts);
   }
-  HIP_TRY(hipEventRecord(b->ev[EV_EDGES], st));
+  HIP_TRY(hipEventRecord(b->ev[EV_EDGES], ts));
+  HIP_TRY(hipStreamWaitEvent(st, b->ev[EV_EDGES], 0));
   HIP_TRY(hipGetLastError());
   return SIGAX_OK;
 }
