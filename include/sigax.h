@@ -142,7 +142,11 @@ int  sigax_batch_set_device_reads(sigax_batch*, const void* d_seqs, const void* 
 /* How many sub-batches a run is cut into (0 = automatic).  With more than one, sub-batch i's filter/extract kernels run on
  * an internal stream beside sub-batch i+1's block finder (the first is VALU-bound, the second memory-request-bound). */
 int  sigax_batch_set_subbatches(sigax_batch*, uint32_t n);
-/* Enqueue the whole path on `stream`: find -> filter/extract -> order -> edges.  Asynchronous. */
+/* Enqueue the whole path: find -> filter/extract -> order -> edges.  Asynchronous.  The kernels run on three internal
+ * streams owned by the index (finder, filter/extract, tail) and ordered against `stream`: work already on `stream` is
+ * waited for, and `stream` waits for the run's last kernel.  Several batch objects of one index may be in flight at
+ * once (each with its own `stream`): their finder launches queue behind each other, so batch k+1's finder starts beside
+ * batch k's filter/extract tail.  A batch object must be finished before it is run again. */
 int  sigax_batch_run(sigax_batch*, uint32_t read_base, uint32_t min_overlap, uint32_t flags, void* stream);
 /* Wait for the stream, check arena overflow flags (growing arenas and re-running if needed), fill stats. */
 int  sigax_batch_finish(sigax_batch*, void* stream, sigax_stats* stats);
