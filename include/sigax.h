@@ -93,6 +93,10 @@ typedef struct sigax_index_info {
 
 const char* sigax_last_error(void);           /* thread-local text of the last failure */
 int  sigax_device_count(int* n);
+/* A HIP stream (non-blocking) for callers that do not link HIP themselves, e.g. to keep two batch objects in flight
+ * (sigax_batch_run).  The handle is a hipStream_t and may be passed wherever this header takes a `stream`. */
+int  sigax_stream_create(int device, void** stream);
+void sigax_stream_destroy(int device, void* stream);
 
 /* FMIndex::load x2 + SuffixArray::load x2 (src/overlap.cpp:41-42, src/overlap_builder.cpp:466).  The .sai
  * paths may be NULL when SIGAX_EDGES is never requested. */

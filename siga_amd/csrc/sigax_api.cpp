@@ -37,6 +37,21 @@ static int fail(int code, const char* fmt, ...) {
 
 extern "C" const char* sigax_last_error(void) { return g_err; }
 
+extern "C" int sigax_stream_create(int device, void** stream) {
+  if (!stream) return fail(SIGAX_E_ARG, "NULL argument");
+  *stream = nullptr;
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t s = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (void*)s;
+  return SIGAX_OK;
+}
+
+extern "C" void sigax_stream_destroy(int device, void* stream) {
+  if (!stream) return;
+  if (hipSetDevice(device) == hipSuccess) hipStreamDestroy((hipStream_t)stream);
+}
+
 extern "C" int sigax_device_count(int* n) {
   if (!n) return fail(SIGAX_E_ARG, "n is NULL");
   int c = 0;

@@ -398,9 +398,6 @@ __device__ __forceinline__ void find_flush(FindStage& sg, bool want, u32 tid) {
 // 4-byte-aligned address at or below the first read's first base; rd_base = that address's offset in A.seqs.
 template <bool WIDE, bool STAGED>
 __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindStage& sg, const unsigned char* rd, u64 rd_base) {
-#ifdef SIGAX_FIND_PRIO
-  __builtin_amdgcn_s_setprio(SIGAX_FIND_PRIO);  // the finder's short dependent chain wins issue arbitration over filter/extract waves
-#endif
   // A workgroup = 64 reads; wave o of it walks chain o of each, so everything that depends on the chain (which index
   // is primary, complementing, the direction the read is consumed in) is wave-uniform and lives in scalar registers.
   const u32 tid = threadIdx.x;
@@ -1453,9 +1450,6 @@ struct GFx {
       while (alive) {
         u64 na = 0;
         int st = round_fast(e, alive, &na);
-#ifdef FX_PHASE_TIMING
-        ++nrounds;
-#endif
         if (st == RD_BAIL) return false;
         if (st == RD_XERROR) return true;
         if (st != RD_UPDATED) break;
@@ -1519,19 +1513,8 @@ struct GFx {
   }
 
   // one (read, side) item on this lane group; returns false when it must be redone by a wider kernel
-#ifdef FX_PHASE_TIMING
-  u64 tph[6] = {0, 0, 0, 0, 0, 0};
-  u32 nrounds = 0, npass = 0;
-#define PH(i) { u64 t_ = __builtin_readcyclecounter(); tph[i] += t_ - tlast; tlast = t_; }
-#else
-#define PH(i)
-#endif
   __device__ bool body(u32 r, u32 sd) {
     const u32 OUTCAP = W == 64 ? FX_OUTCAP : FX_OUTCAP / 2;
-#ifdef FX_PHASE_TIMING
-    u64 tlast = __builtin_readcyclecounter();
-    ++npass;
-#endif
     nout = 0;
     nocc = 0;
     xerror = false;
@@ -1575,7 +1558,6 @@ struct GFx {
     E e;
     e.c0lo = e.c0hi = e.c1lo = e.c1hi = 0; e.src = 0; e.len = 0;
     if (active) load_block(e, src);
-    PH(0)
     const bool member = active && e.len != L;  // ContainmentBlockRemover (:1094-1111)
     const u32 nm = pop(gballot(member));
     // SubMaximalBlockFilter::filter (:930-953) sorts by capped[0].lower and resolves adjacent intersecting blocks.
@@ -1602,7 +1584,6 @@ struct GFx {
       if (!A.irreducible && same && (loj < e.c0lo || (loj == e.c0lo && kj < k))) ++rank;
       inter |= same & (j != gl) & !(e.c0lo > hij || loj > e.c0hi);  // coord.h:37-40
     }
-    PH(1)
     if (gballot(inter)) return false;
     if (A.irreducible) {
       // X += Y; stable sort by length descending (:715-716,1169), ties keep list X first.  Both finds pushed their
@@ -1631,10 +1612,7 @@ struct GFx {
         g.src = sh.esrc[lane]; g.len = sh.elen[lane];
       }
       wave_lds_sync();
-      PH(2)
-      bool okx = extract(g, nm);
-      PH(3)
-      return okx;
+      return extract(g, nm);
     }
     // exhaustive: the filtered lists go out as they are, X then Y, each in capped[0].lower order (:1175-1178)
     u32 pos = 0;
@@ -1726,10 +1704,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 1 : 
       }
       fx.account(has, done, item, nocc_total, nerr, nsub);
     }
-#ifdef FX_PHASE_TIMING
-    if (blockIdx.x == 7 && threadIdx.x == 0)
-      printf("fxphase npass %u rounds %u load %llu pair %llu sort %llu extract %llu\n", fx.npass, fx.nrounds, fx.tph[0], fx.tph[1], fx.tph[2], fx.tph[3]);
-#endif
   } else {
     const u64 n = *A.w64_counter;
     for (u64 i = wave; i < n; i += nwaves) {

@@ -263,3 +263,66 @@ def test_correct_cli_defaults(sa, tmp_path):
     assert subprocess.run([host.CLI_PATH, "correct", "reads.fa"], cwd=cwd).returncode == 0
     po.correct(po.Index.load(cwd + "/reads.bwt"), cwd + "/reads.fa", cwd + "/o.ec")
     assert open(cwd + "/reads.ec.fa").read() == open(cwd + "/o.ec").read()
+
+
+def _batch_download(sa, L, bt):
+    import ctypes as C
+    from siga_amd import _lib
+    from siga_amd.overlap import BLOCK_DTYPE, EDGE_DTYPE
+    res = _lib.Result()
+    assert L.sigax_batch_download(bt, C.byref(res)) == 0, _lib.last_error()
+    try:
+        n = res.n_reads
+        offs = np.ctypeslib.as_array(res.block_offs, shape=(n + 1,)).copy()
+        blocks = np.frombuffer(C.string_at(res.blocks, int(offs[-1]) * BLOCK_DTYPE.itemsize), dtype=BLOCK_DTYPE).copy()
+        sub = np.ctypeslib.as_array(res.substring, shape=(max(n, 1),))[:n].copy()
+        eds = np.frombuffer(C.string_at(res.edges, int(res.n_edges) * EDGE_DTYPE.itemsize), dtype=EDGE_DTYPE).copy()
+    finally:
+        L.sigax_result_free(C.byref(res))
+    return offs, blocks, sub, eds
+
+
+def test_batches_in_flight_on_one_index(sa):
+    """Three batch objects of one index run at once, each from its own stream (the library queues their launches on
+    the index's shared finder / filter streams): every result equals the one-shot call's."""
+    import ctypes as C
+    from siga_amd import _lib
+    from siga_amd.overlap import pack_reads, name_ranks
+    fx = fixture("toy")
+    pair = _pair(sa, fx)
+    reads = sa.overlap.read_sequences(fx.fa)
+    seqs = [r[2] for r in reads]
+    pair.set_reads(np.array([len(s) for s in seqs], dtype=np.uint32), name_ranks([r[0] for r in reads]))
+    n = len(seqs)
+    cuts = [0, n // 3, n // 2, n]
+    builder = sa.OverlapBuilder(pair, fx.prefix)
+    want = [builder.overlap(seqs[cuts[i]:cuts[i + 1]], 45, read_base=cuts[i], edges=True) for i in range(3)]
+    L = _lib.lib()
+    flags = _lib.SIGAX_IRREDUCIBLE | _lib.SIGAX_RC | _lib.SIGAX_EDGES
+    for rounds in range(2):  # second round: the batch objects are reused
+        bts, streams = [], []
+        for i in range(3):
+            part = seqs[cuts[i]:cuts[i + 1]]
+            buf, offs = pack_reads(part)
+            bt = C.c_void_p()
+            assert L.sigax_batch_create(pair.handle, len(part), len(buf), max(map(len, part)), C.byref(bt)) == 0
+            sp = C.c_void_p()
+            assert L.sigax_stream_create(0, C.byref(sp)) == 0, _lib.last_error()
+            assert L.sigax_batch_upload(bt, buf, offs.ctypes.data, len(part), sp) == 0, _lib.last_error()
+            assert L.sigax_batch_set_subbatches(bt, 1 + i) == 0
+            bts.append(bt)
+            streams.append(sp)
+        for rep in range(2):
+            for i in range(3):
+                assert L.sigax_batch_run(bts[i], cuts[i], 45, flags, streams[i]) == 0, _lib.last_error()
+            for i in (2, 0, 1):  # finished in another order than submitted
+                stats = _lib.Stats()
+                assert L.sigax_batch_finish(bts[i], streams[i], C.byref(stats)) == 0, _lib.last_error()
+                offs, blocks, sub, eds = _batch_download(sa, L, bts[i])
+                assert np.array_equal(offs, want[i]["block_offs"])
+                assert blocks.tobytes() == want[i]["blocks"].tobytes()
+                assert np.array_equal(sub, want[i]["substring"])
+                assert eds.tobytes() == want[i]["edges"].tobytes()
+        for bt, sp in zip(bts, streams):
+            L.sigax_batch_destroy(bt)
+            L.sigax_stream_destroy(0, sp)
