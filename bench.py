@@ -45,8 +45,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU restatement (0 = skip)")
     ap.add_argument("--workdir", default=None)
-    ap.add_argument("--subbatches", type=int, default=0,
-                    help="sub-batches per step (0 = library default: 4 at this size; their find and filter/extract kernels overlap)")
+    ap.add_argument("--subbatches", type=int, default=2,
+                    help="sub-batches per step (0 = library default for one batch at a time: 4 at this size); sub-batch i's "
+                         "filter/extract kernels run beside sub-batch i+1's finder")
     ap.add_argument("--depth", type=int, default=2,
                     help="batches in flight on the index (2 = batch k+1's finder starts beside batch k's filter/extract tail)")
     ap.add_argument("--isolated", action="store_true",

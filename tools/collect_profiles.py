@@ -19,7 +19,12 @@ for tag, d in (('default', 'q_kt'), ('sub1', 'q_kt1')):
     print(tag, 'rocprof k_find calls', kf['Calls'], 'avg ms', float(kf['AverageNs']) / 1e6, '| bench avg_launch_ms',
           b['roofline']['avg_launch_ms'], 'value', b['value'], 'frac', b['roofline']['frac'])
 res = {}
-for tag, names in (('default_4_launches_per_step', ['q_fetch', 'q_write', 'q_tcc']), ('subbatches_1', ['q_fetch1', 'q_write1', 'q_tcc1'])):
+launches = {}
+for tag, names in (('default', ['q_fetch', 'q_write', 'q_tcc']), ('subbatches_1', ['q_fetch1', 'q_write1', 'q_tcc1'])):
+    try:
+        launches[tag] = last_json('gpurun_out/%s.json' % names[0])['launches_per_step']
+    except Exception:
+        launches[tag] = None
     o = {}
     for name in names:
         f = latest('gpurun_out/%s/*/*_counter_collection.csv' % name)
@@ -39,7 +44,8 @@ def hb(o):
     return (k['FETCH_SIZE']['mean_per_launch'] + k['WRITE_SIZE']['mean_per_launch']) * 1024
 src = "profiles/" + R + "_pmc_per_launch.json %s: (FETCH_SIZE + WRITE_SIZE) KB x 1024; 64-byte sector requests, no x2 correction (DESIGN.md 4)"
 tr = {}
-for key, tag in (("k_find/1000000/5000000/150/4", 'default_4_launches_per_step'), ("k_find/1000000/5000000/150/1", 'subbatches_1')):
+for tag in ('default', 'subbatches_1'):
+    key = "k_find/1000000/5000000/150/%s" % launches.get(tag)
     try:
         tr[key] = {"hbm_bytes_per_launch": hb(res[tag]), "source": src % tag}
     except KeyError:
