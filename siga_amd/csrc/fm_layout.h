@@ -35,8 +35,21 @@
 #define SIGAX_AF_CHAIN2 3u
 #define SIGAX_AF_CHAIN3 6u
 
+/* Two-step table (u32-position indexes below 2^31 symbols; built on the device at open time from the granules above):
+ * one 128-byte granule per 64 BWT rows j, holding for each row its BWT symbol c1(j) and, for c1 in ACGT, the symbol
+ * c2(j) = BWT[LF(j)] that precedes it in the text (the "second" backward step):
+ *   words 0..3    number of A, C, G, T among c1 of rows [0, 64 g)
+ *   words 4..19   [c = A..T][x = A..T] number of rows in [0, 64 g) with c1 = c and c2 = x
+ *   words 20..31  bit planes y1 z1 w1 y2 z2 w2 (64 bits each, low word first) of the codes of c1 and c2
+ * With R2(x,c,p) = rows j < p with c1 = c, c2 = x:  Occ(e, C[c] + Occ(c, p)) = Occ(e, C[c]) + R2(e, c, p), because LF
+ * keeps the rows with c1 = c in order -- so two consecutive backward steps (c, then e) need only the two positions
+ * of the first one.  A 128-byte line costs the memory system what a 64-byte one does (profiles/r01_gather_probe3.txt). */
+#define SIGAX_GRAN2_SYMS 64
+#define SIGAX_GRAN2_WORDS 32
+
 struct FmStrand {
   const uint32_t* granules;  /* n_granules x 16 u32 */
+  const uint32_t* gran2;     /* (n / 64 + 1) x 32 u32, or NULL */
   const unsigned long long* super;    /* [n_super][4] absolute A,C,G,T counts at each superblock start (wide mode) */
   unsigned long long n;             /* symbols */
   unsigned long long C[5];           /* FMIndex::_pred (src/fmindex.cpp:156-160) */

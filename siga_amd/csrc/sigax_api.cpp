@@ -72,6 +72,7 @@ struct sigax_index {
   bool wide;
   FmStrand st[2];  // 0 forward (.bwt), 1 reverse (.rbwt); pointers are device pointers
   void* d_gran[2];
+  void* d_gran2[2];  // two-step tables (fm_layout.h) or NULL
   void* d_super[2];
   uint32_t* d_sai[2];
   u64 n_sai;
@@ -198,6 +199,7 @@ extern "C" void sigax_index_close(sigax_index* ix) {
   hipSetDevice(ix->device);
   for (int s = 0; s < 2; ++s) {
     if (ix->d_gran[s]) hipFree(ix->d_gran[s]);
+    if (ix->d_gran2[s]) hipFree(ix->d_gran2[s]);
     if (ix->d_super[s]) hipFree(ix->d_super[s]);
     if (ix->d_sai[s]) hipFree(ix->d_sai[s]);
   }
@@ -266,6 +268,37 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
     if (ix->st[0].total[k] != ix->st[1].total[k]) {
       sigax_index_close(ix);
       return fail(SIGAX_E_IO, "forward and reverse BWT hold different symbol counts: not a .bwt/.rbwt pair");
+    }
+  }
+  // Two-step tables for the block finder: u32-position indexes whose table (2 bytes per symbol) stays below 4 GiB
+  // (SIGAX_TWO_STEP=0 turns them off).  Built on the device from the granules just uploaded.
+  {
+    const char* env2 = getenv("SIGAX_TWO_STEP");
+    const bool want2 = !ix->wide && n_symbols < (1ull << 31) && !(env2 && env2[0] == '0');
+    if (want2) {
+      const u64 ng2 = n_symbols / SIGAX_GRAN2_SYMS + 1;
+      void *cnt = nullptr, *offs = nullptr, *partial = nullptr, *total = nullptr;
+      hipError_t e = hipMalloc(&cnt, 20 * ng2 * 4);
+      if (e == hipSuccess) e = hipMalloc(&offs, (ng2 + 2) * 8);
+      if (e == hipSuccess) e = hipMalloc(&partial, scan_partials_needed(ng2) * 8);
+      if (e == hipSuccess) e = hipMalloc(&total, 8);
+      for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+        e = hipMalloc(&ix->d_gran2[s], ng2 * SIGAX_GRAN2_WORDS * 4);
+        if (e != hipSuccess) break;
+        ix->device_bytes += ng2 * SIGAX_GRAN2_WORDS * 4;
+        launch_build2(ix->st[s], (uint32_t*)ix->d_gran2[s], (uint32_t*)cnt, (u64*)offs, (u64*)partial, (u64*)total, nullptr);
+        e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipGetLastError();
+        ix->st[s].gran2 = (const uint32_t*)ix->d_gran2[s];
+      }
+      if (cnt) hipFree(cnt);
+      if (offs) hipFree(offs);
+      if (partial) hipFree(partial);
+      if (total) hipFree(total);
+      if (e != hipSuccess) {
+        sigax_index_close(ix);
+        return fail(SIGAX_E_DEVICE, "building the two-step table: %s", hipGetErrorString(e));
+      }
     }
   }
   if (sai && rsai) {
@@ -658,6 +691,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.read_begin = rb;
     fa.read_end = re;
     fa.stage_bytes = 0;  // set by launch_find
+    fa.two_step = (ix->st[0].gran2 && ix->st[1].gran2) ? 1u : 0u;
     fa.arena = b->arena.p;
     fa.chain_cnt = (uint32_t*)b->chain_cnt.p;
     fa.dstat = dstat;

@@ -39,6 +39,7 @@ struct FindArgs {
   uint32_t n_reads, minov, chain_mask, cap;  // chain_mask bit o = find o runs; cap = slots per chain, last = containment
   uint32_t read_begin, read_end;     // this launch's sub-batch
   uint32_t stage_bytes;              // dynamic LDS per workgroup that may hold the workgroup's reads (set by launch_find)
+  uint32_t two_step;                 // both strands carry the two-step table (u32 positions only)
   void* arena;                       // [n_reads][4][cap] candidate records of cand_bytes(wide) each
   uint32_t* chain_cnt;               // [n_reads][4]
   unsigned long long* dstat;
@@ -122,6 +123,10 @@ unsigned long long fast_pool_entries_per_wave();
 void launch_scan(const uint32_t* cnt, unsigned long long n, unsigned long long* partial, unsigned long long* offs,
                  unsigned long long* total_out, hipStream_t st);
 unsigned long long scan_partials_needed(unsigned long long n);
+// Two-step table of one strand (fm_layout.h): gran2 = (n/64+1) x 32 u32; cnt = 20 x (n/64+1) u32, offs = (n/64+2) u64,
+// partial = scan_partials_needed(n/64+1) u64, total = 1 u64 of scratch.
+void launch_build2(const FmStrand& s, uint32_t* gran2, uint32_t* cnt, unsigned long long* offs, unsigned long long* partial,
+                   unsigned long long* total, hipStream_t st);
 void launch_order_scatter(const OrderArgs& a, hipStream_t st);
 unsigned long long fast_fin_chunk();
 unsigned long long cand_bytes(bool wide);

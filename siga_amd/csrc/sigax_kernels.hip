@@ -364,6 +364,110 @@ __device__ __forceinline__ void store_block(sigax_block* dst, u64 c0lo, u64 c0hi
   d[4] = make_ulonglong2((u64)len | ((u64)af << 32), 0ull);
 }
 
+// ---- two-step table (fm_layout.h) -------------------------------------------------------------------------------
+// built on the device from the one-step granules: one wave per 64 rows
+__global__ __launch_bounds__(256) void k_build2_a(FmStrand s, u32* gran2, u32* cnt, u64 ng2) {
+  const FmRef F = fm_ref(s, 0);
+  const u32 lane = threadIdx.x & 63u;
+  const u64 wave = ((u64)blockIdx.x * 256 + threadIdx.x) >> 6, nw = (u64)gridDim.x * 4;
+  for (u64 g = wave; g < ng2; g += nw) {
+    const u64 p = g * 64 + lane;
+    u32 c1 = 0, c2 = 0;
+    if (p < s.n) {
+      c1 = fm_char(F, p);
+      if (c1 >= 1 && c1 <= 4) {
+        const Cnt4 k = fm_rank<false>(F, p);
+        const u64 rk = c1 == 1 ? k.a : c1 == 2 ? k.c : c1 == 3 ? k.g : k.t;
+        c2 = fm_char(F, s.C[c1] + rk);  // BWT[LF(p)]
+      } else {
+        c1 = c1 > 4 ? 0 : c1;
+      }
+    }
+    const u64 y1 = __ballot((c1 & 1u) != 0), z1 = __ballot((c1 & 2u) != 0), w1 = __ballot((c1 & 4u) != 0);
+    const u64 y2 = __ballot((c2 & 1u) != 0), z2 = __ballot((c2 & 2u) != 0), w2 = __ballot((c2 & 4u) != 0);
+    u32 mine = 0;  // lane t < 20 ends up with the granule's count for header word t
+    for (u32 b = 1; b <= 4; ++b) {
+      const u32 v = (u32)__popcll(__ballot(c1 == b));
+      if (lane == b - 1) mine = v;
+    }
+    for (u32 c = 1; c <= 4; ++c)
+      for (u32 x = 1; x <= 4; ++x) {
+        const u32 v = (u32)__popcll(__ballot(c1 == c && c2 == x));
+        if (lane == 4 + (c - 1) * 4 + (x - 1)) mine = v;
+      }
+    if (lane < 20) cnt[(u64)lane * ng2 + g] = mine;
+    if (lane == 0) {
+      u32* q = gran2 + g * SIGAX_GRAN2_WORDS + 20;
+      q[0] = (u32)y1; q[1] = (u32)(y1 >> 32); q[2] = (u32)z1; q[3] = (u32)(z1 >> 32); q[4] = (u32)w1; q[5] = (u32)(w1 >> 32);
+      q[6] = (u32)y2; q[7] = (u32)(y2 >> 32); q[8] = (u32)z2; q[9] = (u32)(z2 >> 32); q[10] = (u32)w2; q[11] = (u32)(w2 >> 32);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_build2_b(const u64* offs, u32* gran2, u32 col, u64 ng2) {
+  const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (g < ng2) gran2[g * SIGAX_GRAN2_WORDS + col] = (u32)offs[g];
+}
+
+struct Gran2 {  // the five 16-byte pieces of a two-step granule one step needs
+  v4u s, pc, p5, p6, p7;  // one-symbol counts; pair counts [first symbol c][x = A..T]; planes
+};
+// both positions of a double step: ten loads back to back, one wait (u32 offsets from a scalar base: table < 4 GiB)
+__device__ __forceinline__ void find_step2_loads(const void* base, u32 offa, u32 offa_c, u32 offb, u32 offb_c, Gran2& a, Gran2& b) {
+  asm volatile(
+      "global_load_dwordx4 %0, %10, %14\n\t"
+      "global_load_dwordx4 %5, %12, %14\n\t"
+      "global_load_dwordx4 %1, %11, %14\n\t"
+      "global_load_dwordx4 %2, %10, %14 offset:80\n\t"
+      "global_load_dwordx4 %3, %10, %14 offset:96\n\t"
+      "global_load_dwordx4 %4, %10, %14 offset:112\n\t"
+      "global_load_dwordx4 %6, %13, %14\n\t"
+      "global_load_dwordx4 %7, %12, %14 offset:80\n\t"
+      "global_load_dwordx4 %8, %12, %14 offset:96\n\t"
+      "global_load_dwordx4 %9, %12, %14 offset:112\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a.s), "=&v"(a.pc), "=&v"(a.p5), "=&v"(a.p6), "=&v"(a.p7), "=&v"(b.s), "=&v"(b.pc), "=&v"(b.p5), "=&v"(b.p6),
+        "=&v"(b.p7)
+      : "v"(offa), "v"(offa_c), "v"(offb), "v"(offb_c), "s"(base)
+      : "memory");
+}
+struct Rank2 {
+  u32 a, c, g, t;      // rows j < p with c1(j) = A, C, G, T
+  u32 pa, pc, pg, pt;  // rows j < p with c1(j) = c and c2(j) = A, C, G, T
+};
+__device__ __forceinline__ Rank2 rank2_from(const Gran2& q, u32 r, u32 c) {  // r = p & 63, c in 1..4
+  const u32 m0 = r >= 32 ? 0xFFFFFFFFu : ((1u << r) - 1u);
+  const u32 m1 = r > 32 ? ((1u << (r - 32)) - 1u) : 0u;
+  const bool cb0 = ((c - 1u) & 1u) != 0, cb1 = ((c - 1u) & 2u) != 0;
+  Rank2 o;
+  o.a = q.s.x; o.c = q.s.y; o.g = q.s.z; o.t = q.s.w;
+  o.pa = q.pc.x; o.pc = q.pc.y; o.pg = q.pc.z; o.pt = q.pc.w;
+  auto word = [&](u32 y, u32 z, u32 w, u32 y2, u32 z2, u32 w2, u32 m) {
+    const u32 A = y & ~z, C = z & ~y, G = y & z, T = w;
+    o.a += __popc(A & m); o.c += __popc(C & m); o.g += __popc(G & m); o.t += __popc(T & m);
+    const u32 E = (cb1 ? (cb0 ? T : G) : (cb0 ? C : A)) & m;  // rows whose first symbol is c
+    o.pa += __popc(y2 & ~z2 & E); o.pc += __popc(z2 & ~y2 & E); o.pg += __popc(y2 & z2 & E); o.pt += __popc(w2 & E);
+  };
+  word(q.p5.x, q.p5.z, q.p6.x, q.p6.z, q.p7.x, q.p7.z, m0);
+  word(q.p5.y, q.p5.w, q.p6.y, q.p6.w, q.p7.y, q.p7.w, m1);
+  return o;
+}
+// constants of a double step, per strand: Cc[c][e] = Occ(e, C[c]); Cd[c] = Occ('$', C[c])
+struct Find2Tables {
+  u32 Cc[2][4][4];
+  u32 Cd[2][4];
+};
+__device__ __forceinline__ void find2_tables_load(Find2Tables& t, const FmStrand& fwd, const FmStrand& rev) {
+  if (threadIdx.x < 8) {
+    const u32 which = threadIdx.x >> 2, c = (threadIdx.x & 3u) + 1u;
+    const FmStrand& st = which ? rev : fwd;
+    const FmRef F = fm_ref(st, which);
+    const u64 pos = st.C[c];
+    const Cnt4 k = fm_rank<false>(F, pos);
+    t.Cc[which][c - 1][0] = (u32)k.a; t.Cc[which][c - 1][1] = (u32)k.c; t.Cc[which][c - 1][2] = (u32)k.g; t.Cc[which][c - 1][3] = (u32)k.t;
+    t.Cd[which][c - 1] = (u32)(pos - (k.a + k.c + k.g + k.t));
+  }
+}
+
 // Candidate records leave the finder as full 64-byte lines.  A lane that produced a record parks it in its LDS row
 // (two 32-byte records per row with u32 positions, one 64-byte record with u64); once the row is full the FOUR lanes
 // of the lane's quad (all lanes of a wave stay in the loop until its last chain is done) each take a 16-byte piece of
@@ -396,8 +500,9 @@ __device__ __forceinline__ void find_flush(FindStage& sg, bool want, u32 tid) {
 
 // STAGED: the workgroup's 64 reads (one contiguous byte range of the batch) are in LDS at `rd`, first byte = the
 // 4-byte-aligned address at or below the first read's first base; rd_base = that address's offset in A.seqs.
-template <bool WIDE, bool STAGED>
-__device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindStage& sg, const unsigned char* rd, u64 rd_base) {
+template <bool WIDE, bool STAGED, bool TWO>
+__device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindStage& sg, const Find2Tables& t2,
+                                          const unsigned char* rd, u64 rd_base) {
   // A workgroup = 64 reads; wave o of it walks chain o of each, so everything that depends on the chain (which index
   // is primary, complementing, the direction the read is consumed in) is wave-uniform and lives in scalar registers.
   const u32 tid = threadIdx.x;
@@ -420,6 +525,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
   const FmRef OI = fm_pick(pf, R, F);
   const u64* CP = tb.C[PI.which];
   const u64* CO = tb.C[OI.which];
+  const void* PI2 = pf ? (const void*)A.fwd.gran2 : (const void*)A.rev.gran2;  // two-step table of the primary index
   const bool comp = (o & 1u) != 0;            // chains 1 (revcomp) and 3 (complement)
   const bool fromStart = (o == 1 || o == 2);  // reversed strings are consumed from the read's first base
   const u32 af = o == 0 ? SIGAX_AF_CHAIN0 : o == 1 ? SIGAX_AF_CHAIN1 : o == 2 ? SIGAX_AF_CHAIN2 : SIGAX_AF_CHAIN3;
@@ -446,9 +552,85 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
   // the quad-cooperative record stores need every lane of a quad present.
   u32 s = 1;                  // this chain's current match length
   bool full = !live;          // the arena slots of this chain ran out ("cannot happen": cap comes from the longest read)
+  // probe = ranges; probe.updateL('$') (overlap_builder.cpp:861-865) is valid <=> d > 0: park the candidate block in
+  // this lane's row; returns whether the row is now full (to be written by the quad)
+  auto emit = [&](P c0lo, P d, P c1lo, P r0lo, P szv, u32 len) -> bool {
+    bool fl = false;
+    if (nb < A.cap - 1 && !full) {
+      if (WIDE) {
+        cand_store(reinterpret_cast<Cand<WIDE>*>(&sg.row[tid][0]), c0lo, d, c1lo, r0lo, c1lo, szv, len, af);
+        sg.tag[tid] = slot_addr(nb) | 3u;
+        fl = true;
+      } else {
+        cand_store(reinterpret_cast<Cand<WIDE>*>(&sg.row[tid][(nb & 1u) * 2]), c0lo, d, c1lo, r0lo, c1lo, szv, len, af);
+        if (nb & 1u) {
+          sg.tag[tid] = slot_addr(nb - 1) | 3u;
+          fl = true;
+        }
+      }
+    } else {
+      flagbits |= 1u;
+      full = true;
+    }
+    ++nb;
+    return fl;
+  };
   for (;;) {
     const bool on = live && sz != 0 && s < L;  // an empty range stays empty, nothing more can be emitted
     if (__ballot(on) == 0) break;
+    if (TWO) {
+      // Double step: when every running chain of the wave has two more ACGT bases to consume, both backward steps
+      // are taken from ONE pair of positions of the two-step table (fm_layout.h): half the memory lines per base.
+      u32 c = 0, e = 0;
+      const bool want2 = on && s + 1 < L;
+      if (want2) {
+        c = base_rank(rd[rdo + (fromStart ? s : L - 1 - s)]);
+        e = base_rank(rd[rdo + (fromStart ? s + 1 : L - 2 - s)]);
+        if (comp) { c = comp_rank(c); e = comp_rank(e); }
+      }
+      const bool ok2 = want2 && c != 0 && e != 0;
+      if (__ballot(on && !ok2) == 0) {
+        bool fl1 = false, fl2 = false;
+        P lo1n = 0, lo0n = 0, szn = 0, ldn = 0, dd2 = 0, nlo1 = 0, nlo0 = 0, nsz = 0;
+        if (on) {
+          const u32 pl = (u32)lo0, pu = (u32)(lo0 + sz);
+          Gran2 ga, gb;
+          const u32 oa = (pl >> 6) * 128u, ob = (pu >> 6) * 128u;
+          find_step2_loads(PI2, oa, oa + 16u * c, ob, ob + 16u * c, ga, gb);
+          const Rank2 l = rank2_from(ga, pl & 63u, c), u = rank2_from(gb, pu & 63u, c);
+          const u32 da = u.a - l.a, dc = u.c - l.c, dg = u.g - l.g, dt = u.t - l.t;
+          const u32 dd = (u32)sz - (da + dc + dg + dt);  // '$' extensions of the current string
+          const u32 ld = (u32)lo0 - (l.a + l.c + l.g + l.t);
+          if (s >= A.minov && dd > 0) fl1 = emit((P)ld, (P)dd, lo1, lo0, sz, s);
+          // first step, symbol c (overlap_builder.cpp:112-122)
+          const u32 acc1 = sel5<u32>(c, 0u, dd, dd + da, dd + da + dc, dd + da + dc + dg);
+          const u32 lc = sel5<u32>(c, ld, l.a, l.c, l.g, l.t);
+          const u32 dcc = sel5<u32>(c, dd, da, dc, dg, dt);
+          lo1n = lo1 + (P)acc1;
+          lo0n = (P)CP[c] + (P)lc;
+          szn = (P)dcc;
+          // second step, symbol e, from the pair counts: Occ(e, lo0n) = Cc[c][e] + R2(e, c, lower), same for upper
+          const u32 d2a = u.pa - l.pa, d2c = u.pc - l.pc, d2g = u.pg - l.pg, d2t = u.pt - l.pt;
+          const u32 l2d = lc - (l.pa + l.pc + l.pg + l.pt);  // rows below with first symbol c and '$' before it
+          dd2 = (P)(dcc - (d2a + d2c + d2g + d2t));
+          ldn = (P)(t2.Cd[PI.which][c - 1] + l2d);               // Occ('$', lo0n)
+          const u32 acc2 = sel5<u32>(e, 0u, (u32)dd2, (u32)dd2 + d2a, (u32)dd2 + d2a + d2c, (u32)dd2 + d2a + d2c + d2g);
+          const u32 l2e = sel5<u32>(e, 0u, l.pa, l.pc, l.pg, l.pt);
+          const u32 d2e = sel5<u32>(e, 0u, d2a, d2c, d2g, d2t);
+          nlo1 = lo1n + (P)acc2;
+          nlo0 = (P)CP[e] + (P)(t2.Cc[PI.which][c - 1][e - 1] + l2e);
+          nsz = (P)d2e;
+        }
+        find_flush(sg, fl1, tid);
+        if (on) {
+          if (s + 1 >= A.minov && dd2 > 0) fl2 = emit(ldn, dd2, lo1n, lo0n, szn, s + 1);
+          lo1 = nlo1; lo0 = nlo0; sz = nsz;
+          s += szn != 0 ? 2u : 1u;  // an empty range after the first step: the second is not taken (and sz is 0)
+        }
+        find_flush(sg, fl2, tid);
+        continue;
+      }
+    }
     bool flush = false;
     if (on) {
       const u64 pl = (u64)lo0 > PI.n ? PI.n : (u64)lo0;  // never leave the table, whatever an invalid interval holds
@@ -472,26 +654,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
       P da = u.a - l.a, dc = u.c - l.c, dg = u.g - l.g, dt = u.t - l.t;
       P dd = sz - (da + dc + dg + dt);  // '$' extensions
       const P ld = lo0 - (l.a + l.c + l.g + l.t);
-      if (s >= A.minov && dd > 0) {
-        // probe = ranges; probe.updateL('$') (overlap_builder.cpp:861-865): valid <=> dd > 0
-        if (nb < A.cap - 1 && !full) {
-          if (WIDE) {
-            cand_store(reinterpret_cast<Cand<WIDE>*>(&sg.row[tid][0]), ld, dd, lo1, lo0, lo1, sz, s, af);
-            sg.tag[tid] = slot_addr(nb) | 3u;
-            flush = true;
-          } else {
-            cand_store(reinterpret_cast<Cand<WIDE>*>(&sg.row[tid][(nb & 1u) * 2]), ld, dd, lo1, lo0, lo1, sz, s, af);
-            if (nb & 1u) {
-              sg.tag[tid] = slot_addr(nb - 1) | 3u;
-              flush = true;
-            }
-          }
-        } else {
-          flagbits |= 1u;
-          full = true;
-        }
-        ++nb;
-      }
+      if (s >= A.minov && dd > 0) flush = emit(ld, dd, lo1, lo0, sz, s);
       // ranges.updateL(c) (overlap_builder.cpp:112-122), branch-free: acc = extensions by smaller symbols
       const P p1 = dd, p2 = dd + da, p3 = p2 + dc, p4 = p3 + dg;
       const P acc = sel5<P>(r, (P)0, p1, p2, p3, p4);
@@ -580,20 +743,34 @@ __device__ __forceinline__ bool find_stage_reads(const FindArgs& A, u64* rd_base
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_find_n(FindArgs A) {
   __shared__ FmTables tb;
   __shared__ FindStage sg;
+  __shared__ Find2Tables t2;  // unused here
   u64 rd_base = 0;
   const bool staged = find_stage_reads(A, &rd_base);
   fm_tables_load(tb, A.fwd, A.rev);  // ends with the workgroup barrier that also publishes the staged reads
-  if (staged) find_body<false, true>(A, tb, sg, find_dyn_lds, rd_base);
-  else find_body<false, false>(A, tb, sg, find_dyn_lds, rd_base);
+  if (staged) find_body<false, true, false>(A, tb, sg, t2, find_dyn_lds, rd_base);
+  else find_body<false, false, false>(A, tb, sg, t2, find_dyn_lds, rd_base);
+}
+// u32 positions with the two-step table (index below 2^31 symbols, reads staged in LDS)
+__global__ __launch_bounds__(256) void k_find_n2(FindArgs A) {
+  __shared__ FmTables tb;
+  __shared__ FindStage sg;
+  __shared__ Find2Tables t2;
+  u64 rd_base = 0;
+  const bool staged = find_stage_reads(A, &rd_base);
+  find2_tables_load(t2, A.fwd, A.rev);
+  fm_tables_load(tb, A.fwd, A.rev);
+  if (staged) find_body<false, true, true>(A, tb, sg, t2, find_dyn_lds, rd_base);
+  else find_body<false, false, false>(A, tb, sg, t2, find_dyn_lds, rd_base);
 }
 __global__ __launch_bounds__(256) void k_find_w(FindArgs A) {
   __shared__ FmTables tb;
   __shared__ FindStage sg;
+  __shared__ Find2Tables t2;  // unused here
   u64 rd_base = 0;
   const bool staged = find_stage_reads(A, &rd_base);
   fm_tables_load(tb, A.fwd, A.rev);
-  if (staged) find_body<true, true>(A, tb, sg, find_dyn_lds, rd_base);
-  else find_body<true, false>(A, tb, sg, find_dyn_lds, rd_base);
+  if (staged) find_body<true, true, false>(A, tb, sg, t2, find_dyn_lds, rd_base);
+  else find_body<true, false, false>(A, tb, sg, t2, find_dyn_lds, rd_base);
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -2066,6 +2243,7 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
   FindArgs b = a;
   b.stage_bytes = lds;  // the residency cap doubles as the staging buffer for the workgroup's reads
   if (wide) hipLaunchKernelGGL(k_find_w, dim3(g), dim3(bs), lds, st, b);
+  else if (a.two_step && a.fwd.gran2 && a.rev.gran2) hipLaunchKernelGGL(k_find_n2, dim3(g), dim3(bs), lds, st, b);
   else hipLaunchKernelGGL(k_find_n, dim3(g), dim3(bs), lds, st, b);
 }
 
@@ -2096,6 +2274,15 @@ void launch_scan(const u32* cnt, u64 n, u64* partial, u64* offs, u64* total_out,
   hipLaunchKernelGGL(k_scan_partials, dim3(g), dim3(256), 0, st, cnt, n, partial);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, st, partial, (u64)g, total_out);
   hipLaunchKernelGGL(k_scan_apply, dim3(g), dim3(256), 0, st, cnt, n, (const u64*)partial, offs);
+}
+
+void launch_build2(const FmStrand& s, u32* gran2, u32* cnt, u64* offs, u64* partial, u64* total, hipStream_t st) {
+  const u64 ng2 = s.n / SIGAX_GRAN2_SYMS + 1;
+  hipLaunchKernelGGL(k_build2_a, dim3((unsigned)std::min<u64>(nblk(ng2, 4), 65536)), dim3(256), 0, st, s, gran2, cnt, ng2);
+  for (u32 col = 0; col < 20; ++col) {
+    launch_scan(cnt + (u64)col * ng2, ng2, partial, offs, total, st);
+    hipLaunchKernelGGL(k_build2_b, dim3(nblk(ng2, 256)), dim3(256), 0, st, (const u64*)offs, gran2, col, ng2);
+  }
 }
 
 u64 scan_partials_needed(u64 n) { return (n + 1 + SCAN_ITEMS - 1) / SCAN_ITEMS + 1; }
