@@ -270,11 +270,17 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
       return fail(SIGAX_E_IO, "forward and reverse BWT hold different symbol counts: not a .bwt/.rbwt pair");
     }
   }
-  // Two-step tables for the block finder: u32-position indexes whose table (2 bytes per symbol) stays below 4 GiB
-  // (SIGAX_TWO_STEP=0 turns them off).  Built on the device from the granules just uploaded.
+  // Two-step tables for the block finder (2 bytes per symbol and strand), built on the device from the granules just
+  // uploaded.  Only up to 2^30 symbols: measured on MI355X, the finder takes 7.1 instead of 10.6 ms per 1 M reads with a
+  // 0.3 GB table, 9.1 instead of 11.5 ms with 1.2 GB, but 17.4 instead of 13.6 ms with 2.4 GB per strand (one lane per
+  // 128-byte granule then runs into address translation, as tools/gather_probe.hip shows for 8 GB tables).
+  // SIGAX_TWO_STEP=0 turns them off, SIGAX_TWO_STEP_MAX_SYMBOLS moves the limit (never beyond 2^31: u32 byte offsets).
   {
     const char* env2 = getenv("SIGAX_TWO_STEP");
-    const bool want2 = !ix->wide && n_symbols < (1ull << 31) && !(env2 && env2[0] == '0');
+    const char* envm = getenv("SIGAX_TWO_STEP_MAX_SYMBOLS");
+    u64 max2 = envm ? strtoull(envm, nullptr, 10) : (1ull << 30);
+    if (max2 > (1ull << 31)) max2 = 1ull << 31;
+    const bool want2 = !ix->wide && n_symbols < max2 && !(env2 && env2[0] == '0');
     if (want2) {
       const u64 ng2 = n_symbols / SIGAX_GRAN2_SYMS + 1;
       void *cnt = nullptr, *offs = nullptr, *partial = nullptr, *total = nullptr;
