@@ -1,7 +1,7 @@
 """Turn the rocprofv3 outputs tools/run_profiles.sh left under gpurun_out/ into the committed summaries under profiles/."""
 import collections, csv, glob, json, os, shutil, sys
 R = sys.argv[1] if len(sys.argv) > 1 else 'r01'
-FIND = 'k_find_n'
+FIND = 'k_find_n2'
 def latest(pat):
     fs = sorted(glob.glob(pat), key=os.path.getmtime)
     return fs[-1] if fs else None
