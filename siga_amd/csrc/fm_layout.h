@@ -12,8 +12,8 @@
 //     codes: $=0 A=1 C=2 G=3 T=4 (src/alphabet.h:14) so  A = p0&~p1, C = p1&~p0, G = p0&p1, T = p2.
 //   Occ('$') follows from the position: Occ($, p) = p - (A + C + G + T).
 //
-// Each chunk is self-contained (its own 32 symbols + one of the four counters), so a granule can be
-// consumed by one lane (4 x global_load_dwordx4) or by a quad of lanes (one dwordx4 each + DPP reduce).
+// Each chunk holds its own 32 symbols + one of the four counters, so a granule can be consumed by one lane
+// (4 x global_load_dwordx4, what the kernels do) or by a quad of lanes (one dwordx4 each + a quad reduction).
 // Two adjacent granules form one 128-byte line with counters at symbol 0 and symbol 128.
 // 4 bits per symbol: C2 (1.51e8 symbols) = 75.5 MB per strand, C5 (1.255e10) = 6.3 GB per strand.
 #ifndef SIGA_AMD_FM_LAYOUT_H_

@@ -710,6 +710,8 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     xa.fwd = ix->st[0];
     xa.rev = ix->st[1];
     xa.offs = b->d_offs;
+    static const bool fx_one_step = getenv("SIGAX_FX_ONE_STEP") != nullptr;  // A/B aid: extractor without the two-step table
+    if (fx_one_step) xa.fwd.gran2 = xa.rev.gran2 = nullptr;
     xa.n_reads = n;
     xa.cap = b->cap;
     xa.irreducible = (b->flags & SIGAX_IRREDUCIBLE) ? 1u : 0u;

@@ -1317,8 +1317,10 @@ struct GFx {
   bool xerror;
   u64 fin_cur, fin_end;  // this wave's chunk of the unordered final-block arena (wave-uniform)
 
-  __device__ GFx(const FxArgs& a, const FmTables& t, SideSh<WIDE>& s, Ent* wp)
-      : A(a), tb(t), sh(s), F(fm_ref(a.fwd, 0)), R(fm_ref(a.rev, 1)), wpool(wp), lane(threadIdx.x & 63u),
+  const Find2Tables* t2;  // constants of the two-step table, or NULL when the index has none
+
+  __device__ GFx(const FxArgs& a, const FmTables& t, SideSh<WIDE>& s, Ent* wp, const Find2Tables* tt)
+      : A(a), tb(t), sh(s), F(fm_ref(a.fwd, 0)), R(fm_ref(a.rev, 1)), wpool(wp), t2(tt), lane(threadIdx.x & 63u),
         gb(W == 64 ? 0u : (threadIdx.x & 32u)), gl(W == 64 ? (threadIdx.x & 63u) : (threadIdx.x & 31u)),
         glt((1ull << (W == 64 ? (threadIdx.x & 63u) : (threadIdx.x & 31u))) - 1ull), slots(nullptr), nout(0), nocc(0),
         xerror(false), fin_cur(0), fin_end(0), nslot(1), ni(0), gAlive(0), gD(0), gI(0) {}
@@ -1469,11 +1471,73 @@ struct GFx {
   // blocks, IntervalPair::updateR(b) collapses: every extension of a block is b, so diff[k < b] = 0 and diff[b] = the
   // range size, i.e. capped[0] does not move and capped[1] = C[b] + Occ(b, lower - 1) keeps its size: one symbol's rank
   // at one position.  Anything else (range across granules, a branch, '$' as the single symbol) goes to round().
-  __device__ int round_fast(E& e, u64 alive, u64* newAlive) {
+  __device__ int round_fast(E& e, u64 alive, u64* newAlive, bool allow2) {
     const u32 OUTCAP = W == 64 ? FX_OUTCAP : FX_OUTCAP / 2;
     const bool mine = (alive >> gl) & 1ull;
     const FmRef ix = ext_index(e.src);
     const u64 p0 = (u64)e.c1lo, p1 = (u64)e.c1hi + 1ull;  // [p0, p1) in the extension index
+    // With the two-step table (fm_layout.h) and a single group: TWO rounds at once when every alive block's range lies
+    // in one 64-row granule and holds one (first, second) symbol pair, the same pair (after complementing) for all
+    // blocks and neither of them '$': both rounds are then "usual" rounds (no top-level end, no branch), capped[0] and
+    // the range size do not move, and capped[1].lower = C[e] + Occ(e, C[c]) + R2(e, c, lower).  If only the first
+    // symbol is common, ONE round from the same line.  Anything else goes on to the one-step forms below.
+    if (!WIDE && allow2 && t2 != nullptr) {
+      const u32 q0 = (u32)p0, q1 = (u32)p1;
+      const bool in2 = mine && q1 > q0 && ((q1 - 1u) >> 6) == (q0 >> 6) && p1 <= ix.n;
+      if (gballot(mine && !in2) == 0) {
+        const u32* gq = (find_of(e.src) < 2 ? A.rev.gran2 : A.fwd.gran2) + (u64)(q0 >> 6) * SIGAX_GRAN2_WORDS;
+        uint4 a5 = make_uint4(0, 0, 0, 0), a6 = a5, a7 = a5;
+        if (mine) {
+          const uint4* pq = reinterpret_cast<const uint4*>(gq + 20);
+          a5 = pq[0]; a6 = pq[1]; a7 = pq[2];
+        }
+        const u32 r0 = q0 & 63u, r1 = r0 + (q1 - q0);  // 0 <= r0 < r1 <= 64
+        const u32 lo0 = r0 < 32u ? r0 : 32u, hi0 = r1 < 32u ? r1 : 32u;           // the range inside the low word
+        const u32 lo1 = r0 > 32u ? r0 - 32u : 0u, hi1 = r1 > 32u ? r1 - 32u : 0u;  // ... inside the high word
+        const u32 w0 = hi0 - lo0, w1 = hi1 - lo1;
+        const u32 rm0 = w0 == 32u ? 0xFFFFFFFFu : (((1u << (w0 & 31u)) - 1u) << (lo0 & 31u));
+        const u32 rm1 = w1 == 32u ? 0xFFFFFFFFu : (((1u << (w1 & 31u)) - 1u) << (lo1 & 31u));
+        const u32 bl0 = lo0 == 32u ? 0xFFFFFFFFu : ((1u << lo0) - 1u);
+        const u32 bl1 = (1u << lo1) - 1u;  // lo1 <= 31
+        const bool hiw = r0 >= 32u;
+        const u32 bit = r0 & 31u;
+        // planes: a5 = y1lo y1hi z1lo z1hi, a6 = w1lo w1hi y2lo y2hi, a7 = z2lo z2hi w2lo w2hi
+        const u32 fy = 0u - (((hiw ? a5.y : a5.x) >> bit) & 1u), fz = 0u - (((hiw ? a5.w : a5.z) >> bit) & 1u);
+        const u32 fw = 0u - (((hiw ? a6.y : a6.x) >> bit) & 1u);
+        const u32 gy = 0u - (((hiw ? a6.w : a6.z) >> bit) & 1u), gz = 0u - (((hiw ? a7.y : a7.x) >> bit) & 1u);
+        const u32 gw = 0u - (((hiw ? a7.w : a7.z) >> bit) & 1u);
+        const u32 d10 = (a5.x ^ fy) | (a5.z ^ fz) | (a6.x ^ fw), d11 = (a5.y ^ fy) | (a5.w ^ fz) | (a6.y ^ fw);
+        const u32 d20 = (a6.z ^ gy) | (a7.x ^ gz) | (a7.z ^ gw), d21 = (a6.w ^ gy) | (a7.y ^ gz) | (a7.w ^ gw);
+        const bool qcomp2 = (af_of(e.src) & 4u) != 0;
+        const u32 c = fw ? 4u : ((fy & 1u) | (fz & 2u));
+        const u32 x = gw ? 4u : ((gy & 1u) | (gz & 2u));
+        const u32 cq = (qcomp2 && c) ? 5u - c : c, xq = (qcomp2 && x) ? 5u - x : x;
+        const u32 first2 = ffs0(alive);
+        const u32 cfirst = gshfl(cq, first2);
+        const bool diff1 = ((d10 & rm0) | (d11 & rm1)) != 0;
+        if (cfirst != 0 && gballot(mine && (diff1 || cq != cfirst)) == 0) {
+          const u32 xfirst = gshfl(xq, first2);
+          const bool diff2 = ((d20 & rm0) | (d21 & rm1)) != 0;
+          const bool two = xfirst != 0 && gballot(mine && (diff2 || xq != xfirst)) == 0;
+          if (mine) {
+            const P size = e.c1hi - e.c1lo;
+            if (two) {
+              const u32 hdr = gq[4 + (c - 1u) * 4 + (x - 1u)];
+              const u32 below = __popc(~(d10 | d20) & bl0) + __popc(~(d11 | d21) & bl1);
+              e.c1lo = (P)tb.C[ix.which][x] + (P)(t2->Cc[ix.which][c - 1][x - 1] + hdr + below);
+            } else {
+              const u32 hdr = gq[c - 1u];
+              const u32 below = __popc(~d10 & bl0) + __popc(~d11 & bl1);
+              e.c1lo = (P)tb.C[ix.which][c] + (P)(hdr + below);
+            }
+            e.c1hi = e.c1lo + size;
+          }
+          nocc += (two ? 4u : 2u) * pop(alive);
+          *newAlive = alive;
+          return RD_UPDATED;
+        }
+      }
+    }
     const u64 g0 = p0 >> 7;
     const bool inside = mine && p1 > p0 && ((p1 - 1) >> 7) == g0 && p1 <= ix.n;
     if (gballot(mine && !inside)) return round(e, alive, newAlive);
@@ -1626,7 +1690,7 @@ struct GFx {
       u32 guard = 0;
       while (alive) {
         u64 na = 0;
-        int st = round_fast(e, alive, &na);
+        int st = round_fast(e, alive, &na, true);
         if (st == RD_BAIL) return false;
         if (st == RD_XERROR) return true;
         if (st != RD_UPDATED) break;
@@ -1660,7 +1724,7 @@ struct GFx {
         bool eraseGroup = true;
         if (alive) {
           u64 na = 0;
-          int st = round_fast(e, alive, &na);
+          int st = round_fast(e, alive, &na, false);
           if (st == RD_BAIL) return false;
           if (st == RD_XERROR) return true;
           if (st == RD_UPDATED) {
@@ -1862,11 +1926,14 @@ struct GFx {
 template <bool WIDE, int W>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 1 : 4))) void k_filter_extract_fast(FxArgs A) {
   __shared__ FmTables tb;
+  __shared__ Find2Tables t2;
   __shared__ SideSh<WIDE> shm[4];
+  const bool have2 = !WIDE && A.fwd.gran2 != nullptr && A.rev.gran2 != nullptr;
+  if (have2) find2_tables_load(t2, A.fwd, A.rev);
   fm_tables_load(tb, A.fwd, A.rev);
   const u32 wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const u64 wave = (u64)blockIdx.x * 4 + wid, nwaves = (u64)gridDim.x * 4;
-  GFx<WIDE, W> fx(A, tb, shm[wid], A.wpool + wave * FX_WPOOL);
+  GFx<WIDE, W> fx(A, tb, shm[wid], A.wpool + wave * FX_WPOOL, have2 ? &t2 : nullptr);
   u64 nocc_total = 0, nerr = 0, nsub = 0;
   if (W == 32) {
     const u64 first = 2ull * A.read_begin, last = 2ull * A.read_end;
