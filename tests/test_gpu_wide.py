@@ -28,3 +28,16 @@ def test_wide_kernels_with_many_superblocks():
     from siga_amd import build as sbuild
     lib = sbuild.build_libsigax(out=os.path.join(ROOT, "build", "libsigax_super12.so"), defines=("SIGAX_SUPER_SHIFT=12",))
     _run_parity({"SIGAX_FORCE_WIDE": "1", "SIGAX_LIB": lib}, "occ or toy or rep or dup or tiny or kmer")
+
+
+def test_one_step_finder_and_extractor_bit_exact():
+    """Indexes of 2^30 symbols and more carry no two-step table: the one-step finder (k_find_n) and the extractor without
+    double rounds are what they run.  SIGAX_TWO_STEP=0 selects that path on the small fixtures."""
+    _run_parity({"SIGAX_TWO_STEP": "0"}, "hits_and_asqg or non_acgt or duplicate or in_flight")
+
+
+def test_two_step_table_limit_env():
+    """SIGAX_TWO_STEP_MAX_SYMBOLS below the fixture size must fall back to the one-step path, above it use the table:
+    both give the same answers."""
+    _run_parity({"SIGAX_TWO_STEP_MAX_SYMBOLS": "1000"}, "toy or tiny")
+    _run_parity({"SIGAX_TWO_STEP_MAX_SYMBOLS": "100000000"}, "toy or tiny")
