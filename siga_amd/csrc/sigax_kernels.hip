@@ -1307,6 +1307,7 @@ struct GFx {
   SideSh<WIDE>& sh;
   FmRef F, R;
   Ent* wpool;  // FX_NSLOT group slots of 64 entries (branch copies only), shared by the wave's lane groups
+  const Find2Tables* t2;  // constants of the two-step table, or NULL when the index has none
   u32 lane;    // lane in the wave
   u32 gb;      // first lane of this lane's group (0, or 32 for the second group when W == 32)
   u32 gl;      // lane inside the group
@@ -1316,8 +1317,6 @@ struct GFx {
   u32 nocc;
   bool xerror;
   u64 fin_cur, fin_end;  // this wave's chunk of the unordered final-block arena (wave-uniform)
-
-  const Find2Tables* t2;  // constants of the two-step table, or NULL when the index has none
 
   __device__ GFx(const FxArgs& a, const FmTables& t, SideSh<WIDE>& s, Ent* wp, const Find2Tables* tt)
       : A(a), tb(t), sh(s), F(fm_ref(a.fwd, 0)), R(fm_ref(a.rev, 1)), wpool(wp), t2(tt), lane(threadIdx.x & 63u),
