@@ -160,7 +160,8 @@ int  sigax_batch_device_outputs(sigax_batch*, const sigax_block** d_blocks, cons
 int  sigax_batch_download(sigax_batch*, sigax_result* out);
 /* Device time of the kernels of the last finished run, measured with HIP events on the streams they were launched on,
  * summed over the run's sub-batch launches: ms[0] find, ms[1] filter/extract (32- and 64-lane launches),
- * ms[2] filter/extract (general), ms[3] order, ms[4] edges.  *n_sub = launches per kernel (sub-batches). */
+ * ms[2] filter/extract (general), ms[3] order, ms[4] edges.  *n_sub = finder launches of the run (sub-batches, times
+ * two when the finder runs once per strand's two-step table); the other kernels run once per sub-batch. */
 int  sigax_batch_kernel_ms(sigax_batch*, float ms[5], uint32_t* n_sub);
 
 #ifdef __cplusplus

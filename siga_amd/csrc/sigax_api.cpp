@@ -86,6 +86,7 @@ struct sigax_index {
   hipStream_t s_find, s_fx, s_tail;
   std::mutex* enqueue_mu;
   int n_cu;  // compute units of the device
+  bool split_strands;  // two-step tables too large to gather from both at once: one finder launch per strand
 };
 
 // RL units (src/rlstring.h:10-63) -> 64-byte rank granules (fm_layout.h)
@@ -271,14 +272,16 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
     }
   }
   // Two-step tables for the block finder (2 bytes per symbol and strand), built on the device from the granules just
-  // uploaded.  Only up to 2^30 symbols: measured on MI355X, the finder takes 7.1 instead of 10.6 ms per 1 M reads with a
-  // 0.3 GB table, 9.1 instead of 11.5 ms with 1.2 GB, but 17.4 instead of 13.6 ms with 2.4 GB per strand (one lane per
-  // 128-byte granule then runs into address translation, as tools/gather_probe.hip shows for 8 GB tables).
-  // SIGAX_TWO_STEP=0 turns them off, SIGAX_TWO_STEP_MAX_SYMBOLS moves the limit (never beyond 2^31: u32 byte offsets).
+  // uploaded.  The finder then runs one launch per strand (chains 0,1 / 2,3): gathering from one table at a time keeps
+  // the randomly accessed footprint small -- measured on MI355X per 1 M reads, index of 0.15 / 0.6 / 1.2 G symbols:
+  // one-step finder 10.6 / 11.5 / 13.9 ms, two-step with both tables in one launch 7.3 / 9.1 / 17.4 ms (one lane per
+  // 128-byte granule runs into address translation once more than ~4 GB are gathered from: tools/gather_probe3.hip),
+  // two-step with one launch per strand 6.8 / 8.5 / 9.2 ms.  Up to 1.6 G symbols (u32 byte offsets into the table).
+  // SIGAX_TWO_STEP=0 turns the tables off, SIGAX_TWO_STEP_MAX_SYMBOLS moves the limit (never beyond 2^31).
   {
     const char* env2 = getenv("SIGAX_TWO_STEP");
     const char* envm = getenv("SIGAX_TWO_STEP_MAX_SYMBOLS");
-    u64 max2 = envm ? strtoull(envm, nullptr, 10) : (1ull << 30);
+    u64 max2 = envm ? strtoull(envm, nullptr, 10) : ((1ull << 30) + (1ull << 29));
     if (max2 > (1ull << 31)) max2 = 1ull << 31;
     const bool want2 = !ix->wide && n_symbols < max2 && !(env2 && env2[0] == '0');
     if (want2) {
@@ -297,6 +300,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
         if (e == hipSuccess) e = hipGetLastError();
         ix->st[s].gran2 = (const uint32_t*)ix->d_gran2[s];
       }
+      ix->split_strands = true;
       if (cnt) hipFree(cnt);
       if (offs) hipFree(offs);
       if (partial) hipFree(partial);
@@ -505,6 +509,7 @@ struct sigax_batch {
   hipEvent_t sev[SIGAX_MAX_SUB][SV_COUNT];
   unsigned nsub;
   unsigned nsub_req;  // 0 = automatic
+  unsigned find_per_sub;  // finder launches per sub-batch (2 = one per strand's two-step table)
   sigax_stats last;
   u64 last_total_blocks, last_total_edges;
   bool finished;
@@ -555,6 +560,7 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
     for (int j = 0; j < SV_COUNT; ++j) b->sev[i][j] = nullptr;
   b->nsub = 1;
   b->nsub_req = 0;
+  b->find_per_sub = 1;
   {
     hipError_t e = hipSuccess;
     for (int i = 0; i < EV_COUNT && e == hipSuccess; ++i) e = hipEventCreate(&b->ev[i]);
@@ -702,6 +708,17 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.chain_cnt = (uint32_t*)b->chain_cnt.p;
     fa.dstat = dstat;
     HIP_TRY(hipEventRecord(b->sev[i][SV_F0], ix->s_find));
+    fa.chain_base = 0;
+    fa.chains_per_wg = 4;
+    static const char* env_split = getenv("SIGAX_SPLIT_STRANDS");
+    const bool split = fa.two_step && (env_split ? env_split[0] != '0' : ix->split_strands);
+    b->find_per_sub = split ? 2u : 1u;
+    if (split) {
+      // one launch per strand's two-step table (chains 0,1 gather from the forward index, 2,3 from the reverse one)
+      fa.chains_per_wg = 2;
+      launch_find(fa, ix->wide, ix->s_find);
+      fa.chain_base = 2;
+    }
     launch_find(fa, ix->wide, ix->s_find);
     HIP_TRY(hipEventRecord(b->sev[i][SV_F1], ix->s_find));
     HIP_TRY(hipStreamWaitEvent(ix->s_fx, b->sev[i][SV_F1], 0));
@@ -928,7 +945,7 @@ extern "C" int sigax_batch_set_subbatches(sigax_batch* b, uint32_t n) {
 extern "C" int sigax_batch_kernel_ms(sigax_batch* b, float ms[5], uint32_t* n_sub) {
   if (!b || !ms) return fail(SIGAX_E_ARG, "NULL argument");
   if (!b->finished) return fail(SIGAX_E_STATE, "batch not finished");
-  if (n_sub) *n_sub = b->nsub;
+  if (n_sub) *n_sub = b->nsub * b->find_per_sub;
   for (int i = 0; i < 5; ++i) ms[i] = 0.f;
   for (unsigned i = 0; i < b->nsub; ++i) {  // sums over the sub-batch launches (which overlap across the two streams)
     float t = 0.f;

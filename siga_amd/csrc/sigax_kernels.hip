@@ -505,9 +505,11 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
                                           const unsigned char* rd, u64 rd_base) {
   // A workgroup = 64 reads; wave o of it walks chain o of each, so everything that depends on the chain (which index
   // is primary, complementing, the direction the read is consumed in) is wave-uniform and lives in scalar registers.
+  // (With chains_per_wg == 2 a workgroup is 128 reads and two chains: the launch gathers from one strand's tables.)
   const u32 tid = threadIdx.x;
-  const u32 o = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const u32 read = A.read_begin + blockIdx.x * 64u + (tid & 63u);
+  const u32 wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const u32 o = A.chain_base + (wv & (A.chains_per_wg - 1u));
+  const u32 read = A.read_begin + blockIdx.x * (256u / A.chains_per_wg) + (A.chains_per_wg == 4u ? 0u : (wv >> 1) * 64u) + (tid & 63u);
   typedef typename PosOf<WIDE>::type P;
   u32 nocc = 0;
   u32 nb = 0, flagbits = 0;
@@ -724,8 +726,9 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
 // the last base belong to the same allocation as the bases); returns whether it did.
 extern __shared__ __attribute__((aligned(16))) unsigned char find_dyn_lds[];
 __device__ __forceinline__ bool find_stage_reads(const FindArgs& A, u64* rd_base) {
-  const u32 r0 = A.read_begin + blockIdx.x * 64u;
-  const u32 r1 = r0 + 64u < A.read_end ? r0 + 64u : A.read_end;
+  const u32 per = 256u / A.chains_per_wg;
+  const u32 r0 = A.read_begin + blockIdx.x * per;
+  const u32 r1 = r0 + per < A.read_end ? r0 + per : A.read_end;
   const u64 lo = A.offs[r0], hi = A.offs[r1];
   const u64 alo = (reinterpret_cast<u64>(A.seqs) + lo) & ~3ull;
   const u64 nbytes = reinterpret_cast<u64>(A.seqs) + hi - alo;
@@ -2298,7 +2301,7 @@ void launch_correct(const CorrectArgs& a, bool wide, hipStream_t st) {
 void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
   if (a.read_end <= a.read_begin) return;
   const unsigned bs = 256u;
-  unsigned g = nblk((u64)(a.read_end - a.read_begin), 64u);  // 64 reads x 4 chains per workgroup
+  unsigned g = nblk((u64)(a.read_end - a.read_begin), 256u / a.chains_per_wg);  // 64 reads x 4 chains (or 128 x 2) per workgroup
   // Unused dynamic LDS caps the finder's residency (it saturates the memory request rate with few waves), leaving
   // wave slots and registers for the filter/extract kernel that runs beside it on the other stream.
   // Measured on MI355X at C2: 28 resident waves/CU 15.7 ms, 12 waves 14.5 ms, 8 waves 13.4 ms, 4 waves 14.9 ms.
