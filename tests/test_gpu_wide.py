@@ -31,7 +31,7 @@ def test_wide_kernels_with_many_superblocks():
 
 
 def test_one_step_finder_and_extractor_bit_exact():
-    """Indexes of 2^30 symbols and more carry no two-step table: the one-step finder (k_find_n) and the extractor without
+    """Indexes of 1.6 G symbols and more carry no two-step table: the one-step finder (k_find_n) and the extractor without
     double rounds are what they run.  SIGAX_TWO_STEP=0 selects that path on the small fixtures."""
     _run_parity({"SIGAX_TWO_STEP": "0"}, "hits_and_asqg or non_acgt or duplicate or in_flight")
 
