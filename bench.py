@@ -36,8 +36,8 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads-per-gpu", type=int, default=1000000)
     ap.add_argument("--genome-per-gpu", type=int, default=5000000)
     ap.add_argument("--read-len", type=int, default=150)
