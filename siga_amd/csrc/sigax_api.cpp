@@ -792,6 +792,9 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   oa.offs2 = (const u64*)b->offs2.p;
   oa.out = (sigax_block*)b->outb.p;
   oa.out_cap = b->fin_cap;
+  oa.arena = b->arena.p;
+  oa.cap = b->cap;
+  oa.wide = ix->wide ? 1u : 0u;
   launch_order_scatter(oa, ts);
   HIP_TRY(hipEventRecord(b->ev[EV_ORDER], ts));
 

@@ -83,6 +83,8 @@ struct OrderArgs {
   const unsigned long long* offs2;      // [n_items+1] per-(read, side) offsets in the ordered output
   sigax_block* out;
   unsigned long long out_cap;
+  const void* arena;   // candidate records: a block whose `reserved` has bit 63 set carries (chain, slot) there instead
+  uint32_t cap, wide;  // of its raw intervals, length and flags, which the scatter then takes from the candidate record
 };
 
 struct EdgeArgs {

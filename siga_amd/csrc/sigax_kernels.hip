@@ -1891,14 +1891,13 @@ struct GFx {
     if (has && done) {
       if (gl == 0) A.item_base[2ull * r + sd] = base;
       if (gl < nout && base + gl < A.fin_cap) {
+        // capped pair + where the candidate record is: the ordered scatter (a streaming kernel) fetches the raw pair,
+        // length and flags from it, which keeps that memory round trip off this item's dependent chain
         const u32 src = sh.osrc[lane];
-        const Cand<WIDE> b = cand_load<WIDE>(slots + slot_of(src));
         ulonglong2* d = reinterpret_cast<ulonglong2*>(A.fin + base + gl);
         d[0] = make_ulonglong2(widen(sh.o0[lane]), widen(sh.o1[lane]));
         d[1] = make_ulonglong2(widen(sh.o2[lane]), widen(sh.o3[lane]));
-        d[2] = make_ulonglong2((u64)b.r0lo, (u64)b.r0lo + b.sz - 1);
-        d[3] = make_ulonglong2((u64)b.r1lo, (u64)b.r1lo + b.sz - 1);
-        d[4] = make_ulonglong2((u64)b.len | ((u64)b.af << 32), 0ull);
+        d[4] = make_ulonglong2(0ull, 0x8000000000000000ull | (u64)src);
       }
     }
     return done;
@@ -2210,7 +2209,16 @@ __global__ __launch_bounds__(256) void k_pick_read_offsets(const u64* offs2, u64
   if (i <= n_reads) block_offs[i] = offs2[2 * i];
 }
 
-// one lane per (read, side) item: copy its blocks from the unordered arena to their place in the ordered output
+// one lane per (read, side) item: copy its blocks from the unordered arena to their place in the ordered output; blocks
+// written by the lane-group kernels get their raw pair, length and flags from the candidate record here
+template <bool WIDE>
+__device__ __forceinline__ void order_fill_from_cand(const OrderArgs& A, u64 item, u32 src, ulonglong2& v2, ulonglong2& v3, ulonglong2& v4) {
+  const Cand<WIDE>* rec = reinterpret_cast<const Cand<WIDE>*>(A.arena) + (item >> 1) * 4 * A.cap + (src & 0x3FFFFFFFu);
+  const Cand<WIDE> b = cand_load<WIDE>(rec);
+  v2 = make_ulonglong2((u64)b.r0lo, (u64)b.r0lo + b.sz - 1);
+  v3 = make_ulonglong2((u64)b.r1lo, (u64)b.r1lo + b.sz - 1);
+  v4 = make_ulonglong2((u64)b.len | ((u64)b.af << 32), 0ull);
+}
 __global__ __launch_bounds__(256) void k_order_scatter(OrderArgs A) {
   u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
   if (w >= A.n_items) return;
@@ -2221,7 +2229,14 @@ __global__ __launch_bounds__(256) void k_order_scatter(OrderArgs A) {
     if (srcb + i >= A.fin_cap || dstb + i >= A.out_cap) return;  // only after an overflow, whose results the host discards
     const ulonglong2* s = reinterpret_cast<const ulonglong2*>(A.fin + srcb + i);
     ulonglong2* d = reinterpret_cast<ulonglong2*>(A.out + dstb + i);
-    ulonglong2 v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3], v4 = s[4];
+    ulonglong2 v0 = s[0], v1 = s[1], v4 = s[4];
+    ulonglong2 v2, v3;
+    if (v4.y >> 63) {
+      if (A.wide) order_fill_from_cand<true>(A, w, (u32)v4.y, v2, v3, v4);
+      else order_fill_from_cand<false>(A, w, (u32)v4.y, v2, v3, v4);
+    } else {
+      v2 = s[2]; v3 = s[3];
+    }
     d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3; d[4] = v4;
   }
 }
