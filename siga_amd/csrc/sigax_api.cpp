@@ -711,7 +711,9 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.chain_base = 0;
     fa.chains_per_wg = 4;
     static const char* env_split = getenv("SIGAX_SPLIT_STRANDS");
-    const bool split = fa.two_step && (env_split ? env_split[0] != '0' : ix->split_strands);
+    // (only while the 128 reads of such a workgroup still fit the LDS staging buffer: the double step needs them there)
+    const bool split = fa.two_step && (env_split ? env_split[0] != '0' : ix->split_strands) &&
+                       128ull * b->cur_max_len + 8 <= find_stage_capacity();
     b->find_per_sub = split ? 2u : 1u;
     if (split) {
       // one launch per strand's two-step table (chains 0,1 gather from the forward index, 2,3 from the reverse one)

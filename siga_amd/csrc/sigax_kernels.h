@@ -121,6 +121,7 @@ void launch_occ_batch(const FmStrand& s, bool wide, const unsigned long long* po
 void launch_kmer_count(const FmStrand& s, bool wide, const unsigned char* kmers, uint32_t k, unsigned long long n,
                        unsigned long long* out, hipStream_t st);
 void launch_find(const FindArgs& a, bool wide, hipStream_t st);
+unsigned long long find_stage_capacity();  // bytes of reads a finder workgroup can stage in LDS
 void launch_filter_extract(const FxArgs& a, bool wide, unsigned grid, hipStream_t st);
 void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid32, unsigned grid64, hipStream_t st);
 unsigned long long fast_pool_entries_per_wave();

@@ -595,7 +595,8 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
         bool fl1 = false, fl2 = false;
         P lo1n = 0, lo0n = 0, szn = 0, ldn = 0, dd2 = 0, nlo1 = 0, nlo0 = 0, nsz = 0;
         if (on) {
-          const u32 pl = (u32)lo0, pu = (u32)(lo0 + sz);
+          const u32 nn = (u32)PI.n;  // never leave the table, whatever an invalid interval holds
+          const u32 pl = (u32)lo0 > nn ? nn : (u32)lo0, pu = (u32)(lo0 + sz) > nn ? nn : (u32)(lo0 + sz);
           Gran2 ga, gb;
           const u32 oa = (pl >> 6) * 128u, ob = (pu >> 6) * 128u;
           find_step2_loads(PI2, oa, oa + 16u * c, ob, ob + 16u * c, ga, gb);
@@ -2313,6 +2314,16 @@ void launch_correct(const CorrectArgs& a, bool wide, hipStream_t st) {
   else hipLaunchKernelGGL(k_correct<false>, dim3(g), dim3(256), 0, st, a);
 }
 
+static unsigned find_lds_budget() {
+  static const char* env = getenv("SIGAX_FIND_LDS");
+  return env ? (unsigned)atoi(env) : 60000u;
+}
+// bytes of a workgroup's reads that can be staged in LDS (see launch_find)
+unsigned long long find_stage_capacity() {
+  const unsigned lds = find_lds_budget();
+  return lds > (unsigned)sizeof(FindStage) ? lds - (unsigned)sizeof(FindStage) : 0u;
+}
+
 void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
   if (a.read_end <= a.read_begin) return;
   const unsigned bs = 256u;
@@ -2321,9 +2332,7 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
   // wave slots and registers for the filter/extract kernel that runs beside it on the other stream.
   // Measured on MI355X at C2: 28 resident waves/CU 15.7 ms, 12 waves 14.5 ms, 8 waves 13.4 ms, 4 waves 14.9 ms.
   // 60 KB per workgroup = two workgroups (8 waves) per CU and 40 KB of LDS left for filter/extract workgroups.
-  static const char* env = getenv("SIGAX_FIND_LDS");
-  unsigned lds = env ? (unsigned)atoi(env) : 60000u;
-  lds = lds > (unsigned)sizeof(FindStage) ? lds - (unsigned)sizeof(FindStage) : 0u;  // the record staging rows are part of the budget
+  unsigned lds = (unsigned)find_stage_capacity();  // the record staging rows are part of the budget
   FindArgs b = a;
   b.stage_bytes = lds;  // the residency cap doubles as the staging buffer for the workgroup's reads
   if (wide) hipLaunchKernelGGL(k_find_w, dim3(g), dim3(bs), lds, st, b);

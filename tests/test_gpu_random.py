@@ -77,3 +77,40 @@ def test_random_case_bit_exact(seed, tmp_path):
     host.rmdup_file(fa, prefix, d + "/g.rm.fa", d + "/g.rm.dups.fa")
     assert open(d + "/g.rm.fa").read() == open(d + "/o.rm.fa").read()
     assert open(d + "/g.rm.dups.fa").read() == open(d + "/o.rm.dups.fa").read()
+
+
+@pytest.mark.parametrize("L", [250, 400, 700])
+def test_long_reads_bit_exact(L, tmp_path):
+    """Read lengths at which the finder changes form: 128 reads of a workgroup staged in LDS (one launch per strand),
+    64 reads staged (both strands in one launch), reads too long to stage (one-step finder)."""
+    import siga_amd
+    from siga_amd import host
+    from siga_amd.overlap import format_hits
+    rnd = random.Random(1000 + L)
+    G = 12 * L
+    genome = "".join(rnd.choice("ACGT") for _ in range(G))
+    reads = []
+    for i in range(G * 12 // L):
+        l = L if i % 5 else rnd.randrange(L // 2, L)
+        p = rnd.randrange(0, G - l + 1)
+        s = genome[p:p + l]
+        if rnd.random() < 0.5:
+            s = revcomp(s)
+        s = "".join((rnd.choice([c for c in "ACGT" if c != b]) if rnd.random() < 0.003 else b) for b in s)
+        reads.append(("q%d" % i, s))
+    d = str(tmp_path)
+    fa = d + "/r.fa"
+    with open(fa, "w") as f:
+        for n, s in reads:
+            f.write(">%s\n%s\n" % (n, s))
+    prefix = d + "/r"
+    host.index_file(fa, prefix, threads=2)
+    fwd = po.Index.load(prefix + ".bwt", prefix + ".sai")
+    rev = po.Index.load(prefix + ".rbwt", prefix + ".rsai")
+    st = po.build_asqg(fwd, rev, fa, 40, d + "/o.asqg", d + "/o.hits", True, True)
+    pair = siga_amd.FMIndexPair.load(prefix)
+    text, res = siga_amd.OverlapBuilder(pair, prefix).build(fa, 40)
+    assert format_hits(res) == open(d + "/o.hits").read()
+    assert text == open(d + "/o.asqg").read()
+    s = res["stats"]
+    assert s["n_occ_find"] + s["n_occ_extract"] == st["n_occ_min"]
