@@ -1479,19 +1479,21 @@ struct GFx {
     const bool mine = (alive >> gl) & 1ull;
     const FmRef ix = ext_index(e.src);
     const u64 p0 = (u64)e.c1lo, p1 = (u64)e.c1hi + 1ull;  // [p0, p1) in the extension index
-    // With the two-step table (fm_layout.h) and a single group: TWO rounds at once when every alive block's range lies
-    // in one 64-row granule and holds one (first, second) symbol pair, the same pair (after complementing) for all
+    // With the two-step table (fm_layout.h), when every alive block's range lies in one 64-row granule, one 128-byte line
+    // per block serves: the end of the top-level block ('$' follows it); with a single group, TWO rounds at once when
+    // every range holds one (first, second) symbol pair, the same pair (after complementing) for all
     // blocks and neither of them '$': both rounds are then "usual" rounds (no top-level end, no branch), capped[0] and
     // the range size do not move, and capped[1].lower = C[e] + Occ(e, C[c]) + R2(e, c, lower).  If only the first
     // symbol is common, ONE round from the same line.  Anything else goes on to the one-step forms below.
-    if (!WIDE && allow2 && t2 != nullptr) {
+    if (!WIDE && t2 != nullptr) {
       const u32 q0 = (u32)p0, q1 = (u32)p1;
       const bool in2 = mine && q1 > q0 && ((q1 - 1u) >> 6) == (q0 >> 6) && p1 <= ix.n;
       if (gballot(mine && !in2) == 0) {
         const u32* gq = (find_of(e.src) < 2 ? A.rev.gran2 : A.fwd.gran2) + (u64)(q0 >> 6) * SIGAX_GRAN2_WORDS;
-        uint4 a5 = make_uint4(0, 0, 0, 0), a6 = a5, a7 = a5;
+        uint4 a4 = make_uint4(0, 0, 0, 0), a5 = a4, a6 = a4, a7 = a4;
         if (mine) {
           const uint4* pq = reinterpret_cast<const uint4*>(gq + 20);
+          a4 = *reinterpret_cast<const uint4*>(gq);  // A, C, G, T before the granule
           a5 = pq[0]; a6 = pq[1]; a7 = pq[2];
         }
         const u32 r0 = q0 & 63u, r1 = r0 + (q1 - q0);  // 0 <= r0 < r1 <= 64
@@ -1511,17 +1513,50 @@ struct GFx {
         const u32 gw = 0u - (((hiw ? a7.w : a7.z) >> bit) & 1u);
         const u32 d10 = (a5.x ^ fy) | (a5.z ^ fz) | (a6.x ^ fw), d11 = (a5.y ^ fy) | (a5.w ^ fz) | (a6.y ^ fw);
         const u32 d20 = (a6.z ^ gy) | (a7.x ^ gz) | (a7.z ^ gw), d21 = (a6.w ^ gy) | (a7.y ^ gz) | (a7.w ^ gw);
+        const u32 first2 = ffs0(alive);
+        {
+          // the top-level block has ended (:747-766), from the same line: capped.updateR('$') needs Occ('$') at both
+          // ends of the range = position minus the A,C,G,T before it
+          const u32 ds0 = ~(a5.x | a5.z | a6.x), ds1 = ~(a5.y | a5.w | a6.y);  // rows whose symbol is '$'
+          const bool x0 = mine && (((ds0 & rm0) | (ds1 & rm1)) != 0);
+          const u32 topLen = gshfl(e.len, first2);
+          const bool isTop = mine && e.len == topLen;
+          if (gballot(isTop && x0)) {
+            const u64 topMask = gballot(isTop);
+            const u64 bad = gballot(isTop && !x0);
+            u64 emitMask = topMask;
+            if (bad) emitMask &= (1ull << ffs0(bad)) - 1ull;
+            nocc += 2u * pop(topMask);
+            const u32 ne = pop(emitMask);
+            if (nout + ne > OUTCAP) return RD_BAIL;
+            if ((emitMask >> gl) & 1ull) {
+              const u32 acgt = a4.x + a4.y + a4.z + a4.w + __popc(~ds0 & bl0) + __popc(~ds1 & bl1);
+              const u32 nd = __popc(ds0 & rm0) + __popc(ds1 & rm1);
+              const P ld = (P)(q0 - acgt);  // Occ('$', lower - 1); C['$'] = 0
+              E br = e;
+              br.c0hi = br.c0lo + (P)nd - 1;
+              br.c1lo = ld;
+              br.c1hi = ld + (P)nd - 1;
+              out_put(nout + pop(emitMask & glt), br);
+            }
+            nout += ne;
+            if (bad) {
+              xerror = true;
+              return RD_XERROR;
+            }
+            return RD_ENDED;
+          }
+        }
         const bool qcomp2 = (af_of(e.src) & 4u) != 0;
         const u32 c = fw ? 4u : ((fy & 1u) | (fz & 2u));
         const u32 x = gw ? 4u : ((gy & 1u) | (gz & 2u));
         const u32 cq = (qcomp2 && c) ? 5u - c : c, xq = (qcomp2 && x) ? 5u - x : x;
-        const u32 first2 = ffs0(alive);
         const u32 cfirst = gshfl(cq, first2);
         const bool diff1 = ((d10 & rm0) | (d11 & rm1)) != 0;
         if (cfirst != 0 && gballot(mine && (diff1 || cq != cfirst)) == 0) {
           const u32 xfirst = gshfl(xq, first2);
           const bool diff2 = ((d20 & rm0) | (d21 & rm1)) != 0;
-          const bool two = xfirst != 0 && gballot(mine && (diff2 || xq != xfirst)) == 0;
+          const bool two = allow2 && xfirst != 0 && gballot(mine && (diff2 || xq != xfirst)) == 0;
           if (mine) {
             const P size = e.c1hi - e.c1lo;
             if (two) {
