@@ -113,6 +113,17 @@ int  sigax_index_info_get(const sigax_index*, sigax_index_info* out);
  * the dedup rule of src/overlap_builder.cpp:358,365 needs only equality and order of names. */
 int  sigax_index_set_reads(sigax_index*, const uint32_t* lengths, const uint32_t* name_rank, uint64_t n);
 
+/* `siga index` for one strand on the GPU: SuffixArrayBuilder "sais2" + BWT(sa, reads) + the .sai rows
+ * (src/indexer.cpp:80-104, src/suffix_array_builder.cpp:472-674, src/bwt.cpp:7-32, src/suffix_array.cpp:17-44).
+ * seqs/offs as in sigax_overlap_batch; reverse != 0 indexes the reversed reads (src/indexer.cpp:60-64: the .rbwt/.rsai
+ * pair).  On success *runs holds *n_runs RL units exactly as the .bwt payload stores them (31-cap of src/bwt.cpp:17),
+ * *sai the n_reads read ids of the full-read suffixes in suffix order, *n_symbols = sum(len + 1).  Both arrays are
+ * malloc'd; release with sigax_free.  SIGAX_E_CAPACITY = input too repetitive for the device sort (the host falls
+ * back to its own SA-IS). */
+int  sigax_build_strand(const char* seqs, const uint64_t* offs, uint64_t n_reads, int reverse, int device,
+                        uint8_t** runs, uint64_t* n_runs, uint32_t** sai, uint64_t* n_symbols);
+void sigax_free(void* p);
+
 /* FMIndex::getOcc(i) for many positions (src/fmindex.cpp:320-323): which = 0 forward, 1 reverse index;
  * counts5[5*k..] = Occ($,A,C,G,T) inclusive of positions[k]; position 2^64-1 gives zeros. Host buffers. */
 int  sigax_occ_batch(sigax_index*, int which, const uint64_t* positions, uint64_t n, uint64_t* counts5);

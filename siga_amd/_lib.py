@@ -45,7 +45,7 @@ SYMBOLS = [
     "sigax_index_info_get", "sigax_index_set_reads", "sigax_occ_batch", "sigax_kmer_count_batch",
     "sigax_correct_batch", "sigax_overlap_batch", "sigax_result_free", "sigax_batch_create", "sigax_batch_destroy", "sigax_batch_upload",
     "sigax_batch_set_device_reads", "sigax_batch_set_subbatches", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
-    "sigax_batch_download", "sigax_batch_kernel_ms",
+    "sigax_batch_download", "sigax_batch_kernel_ms", "sigax_build_strand", "sigax_free",
 ]
 
 _lib = None
@@ -91,6 +91,9 @@ def lib():
     L.sigax_batch_download.argtypes = [vp, C.POINTER(Result)]
     L.sigax_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 5), C.POINTER(C.c_uint32)]
     L.sigax_batch_set_subbatches.argtypes = [vp, u32]
+    L.sigax_build_strand.argtypes = [vp, vp, u64, ci, ci, pvp, C.POINTER(u64), pvp, C.POINTER(u64)]
+    L.sigax_free.argtypes = [vp]
+    L.sigax_free.restype = None
     _lib = L
     return L
 

@@ -28,6 +28,14 @@ static int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+// the same for the library's other translation units (sigax_index_build.hip)
+int sigax_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
 
 #define HIP_TRY(expr)                                                                                  \
   do {                                                                                                 \
@@ -89,48 +97,24 @@ struct sigax_index {
   bool split_strands;  // two-step tables too large to gather from both at once: one finder launch per strand
 };
 
-// RL units (src/rlstring.h:10-63) -> 64-byte rank granules (fm_layout.h)
-static int encode_strand(const uint8_t* runs, u64 nruns, u64 nsym, bool wide, std::vector<uint32_t>* gran,
-                         std::vector<u64>* super, u64 C[5], u64 total[5]) {
-  u64 ngran = nsym / SIGAX_GRANULE_SYMS + 1;
-  gran->assign(ngran * 16, 0u);
-  super->clear();
-  u64 cnt[5] = {0, 0, 0, 0, 0};
-  u64 sbase[4] = {0, 0, 0, 0};
-  uint32_t* g = gran->data();
-  auto header = [&](u64 gi) {
-    if ((gi * SIGAX_GRANULE_SYMS) % (1ull << SIGAX_SUPER_SHIFT) == 0) {
-      for (int j = 0; j < 4; ++j) {
-        sbase[j] = wide ? cnt[1 + j] : 0;
-        super->push_back(sbase[j]);
-      }
-    }
-    for (int j = 0; j < 4; ++j) g[gi * 16 + j * 4] = (uint32_t)(cnt[1 + j] - sbase[j]);
-  };
-  header(0);
-  u64 pos = 0;
-  for (u64 i = 0; i < nruns; ++i) {
-    uint32_t sym = runs[i] >> 5, c = runs[i] & 31u;
-    if (sym > 4) return fail(SIGAX_E_IO, "invalid RL unit 0x%02x at run %llu", runs[i], i);
-    if (pos + c > nsym) return fail(SIGAX_E_IO, "run lengths exceed the symbol count in the header");
-    for (uint32_t k = 0; k < c; ++k) {
-      u64 gi = pos >> 7;
-      uint32_t r = (uint32_t)pos & 127u, j = r >> 5, b = r & 31u;
-      uint32_t* ch = g + gi * 16 + j * 4;
-      ch[1] |= (sym & 1u) << b;
-      ch[2] |= ((sym >> 1) & 1u) << b;
-      ch[3] |= ((sym >> 2) & 1u) << b;
-      ++cnt[sym];
-      ++pos;
-      if ((pos & 127u) == 0) header(pos >> 7);
-    }
+// RL units (src/rlstring.h:10-63) -> 64-byte rank granules (fm_layout.h), decoded on the device (sigax_index_build.hip)
+int sigax_decode_strand(const uint8_t* runs, u64 n_runs, u64 nsym, bool wide, void** d_gran, u64* gran_bytes, void** d_super,
+                        u64* super_bytes, u64 C[5], u64 total[5]);
+
+// frees device buffers on every exit path of the one-shot calls below
+struct DevGuard {
+  std::vector<void*> ptrs;
+  ~DevGuard() {
+    for (void* p : ptrs)
+      if (p) hipFree(p);
   }
-  if (pos != nsym) return fail(SIGAX_E_IO, "run lengths (%llu) do not add up to the symbol count (%llu)", pos, nsym);
-  for (int k = 0; k < 5; ++k) total[k] = cnt[k];
-  C[0] = 0;
-  for (int k = 1; k < 5; ++k) C[k] = C[k - 1] + cnt[k - 1];  // src/fmindex.cpp:156-160
-  return SIGAX_OK;
-}
+  hipError_t alloc(void** out, size_t bytes) {
+    *out = nullptr;
+    hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+    if (e == hipSuccess) ptrs.push_back(*out);
+    return e;
+  }
+};
 
 static int read_file(const char* path, std::vector<uint8_t>* out) {
   FILE* f = fopen(path, "rb");
@@ -181,6 +165,7 @@ static int parse_sai(const std::vector<uint8_t>& buf, const char* path, std::vec
   for (u64 i = 0; i < elems; ++i) {
     u64 a, b;
     if (!next(&a) || !next(&b)) return fail(SIGAX_E_IO, "%s: truncated .sai body", path);
+    if (a >= strings) return fail(SIGAX_E_IO, "%s: read id %llu at row %llu, the table declares %llu strings", path, a, i, strings);
     (*out)[i] = (uint32_t)a;
   }
   return SIGAX_OK;
@@ -247,16 +232,13 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
   const uint8_t* rr[2] = {runs, rruns};
   u64 nr[2] = {n_runs, n_rruns};
   for (int s = 0; s < 2; ++s) {
-    std::vector<uint32_t> gran;
-    std::vector<u64> super;
-    u64 C[5], total[5];
-    int rc = encode_strand(rr[s], nr[s], n_symbols, ix->wide, &gran, &super, C, total);
-    if (rc == SIGAX_OK) rc = upload(gran.data(), gran.size() * 4, &ix->d_gran[s], &ix->device_bytes);
-    if (rc == SIGAX_OK) rc = upload(super.data(), super.size() * 8, &ix->d_super[s], &ix->device_bytes);
+    u64 C[5], total[5], gb = 0, sb = 0;
+    int rc = sigax_decode_strand(rr[s], nr[s], n_symbols, ix->wide, &ix->d_gran[s], &gb, &ix->d_super[s], &sb, C, total);
     if (rc != SIGAX_OK) {
       sigax_index_close(ix);
       return rc;
     }
+    ix->device_bytes += gb + sb;
     ix->st[s].granules = (const uint32_t*)ix->d_gran[s];
     ix->st[s].super = (const u64*)ix->d_super[s];
     ix->st[s].n = n_symbols;
@@ -306,13 +288,30 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
       if (partial) hipFree(partial);
       if (total) hipFree(total);
       if (e != hipSuccess) {
-        sigax_index_close(ix);
-        return fail(SIGAX_E_DEVICE, "building the two-step table: %s", hipGetErrorString(e));
+        // the tables are an accelerator, not a requirement: without them the one-step finder runs
+        (void)hipGetLastError();
+        for (int s = 0; s < 2; ++s) {
+          if (ix->d_gran2[s]) {
+            hipFree(ix->d_gran2[s]);
+            ix->device_bytes -= ng2 * SIGAX_GRAN2_WORDS * 4;
+          }
+          ix->d_gran2[s] = nullptr;
+          ix->st[s].gran2 = nullptr;
+        }
+        ix->split_strands = false;
+        if (getenv("SIGAX_VERBOSE")) fprintf(stderr, "[sigax] two-step tables not built (%s): one-step finder\n", hipGetErrorString(e));
       }
     }
   }
   if (sai && rsai) {
     const uint32_t* ss[2] = {sai, rsai};
+    for (int s = 0; s < 2; ++s)  // k_edges indexes the read tables with these ids
+      for (u64 i = 0; i < n_strings; ++i)
+        if (ss[s][i] >= n_strings) {
+          sigax_index_close(ix);
+          return fail(SIGAX_E_IO, "%s table: read id %u at row %llu, the index holds %llu strings", s ? ".rsai" : ".sai", ss[s][i], i,
+                      (u64)n_strings);
+        }
     for (int s = 0; s < 2; ++s) {
       int rc = upload(ss[s], n_strings * 4, (void**)&ix->d_sai[s], &ix->device_bytes);
       if (rc != SIGAX_OK) {
@@ -381,14 +380,13 @@ extern "C" int sigax_occ_batch(sigax_index* ix, int which, const uint64_t* posit
   HIP_TRY(hipSetDevice(ix->device));
   if (n == 0) return SIGAX_OK;
   u64 *d_pos = nullptr, *d_out = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_pos, n * 8));
-  HIP_TRY(hipMalloc((void**)&d_out, n * 40));
+  DevGuard g;
+  HIP_TRY(g.alloc((void**)&d_pos, n * 8));
+  HIP_TRY(g.alloc((void**)&d_out, n * 40));
   HIP_TRY(hipMemcpy(d_pos, positions, n * 8, hipMemcpyHostToDevice));
   launch_occ_batch(ix->st[which], ix->wide, d_pos, n, d_out, 0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(counts5, d_out, n * 40, hipMemcpyDeviceToHost));
-  hipFree(d_pos);
-  hipFree(d_out);
   return SIGAX_OK;
 }
 
@@ -398,14 +396,13 @@ extern "C" int sigax_kmer_count_batch(sigax_index* ix, const char* kmers, uint32
   if (n == 0) return SIGAX_OK;
   unsigned char* d_k = nullptr;
   u64* d_out = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_k, n * k));
-  HIP_TRY(hipMalloc((void**)&d_out, n * 8));
+  DevGuard g;
+  HIP_TRY(g.alloc((void**)&d_k, n * k));
+  HIP_TRY(g.alloc((void**)&d_out, n * 8));
   HIP_TRY(hipMemcpy(d_k, kmers, n * k, hipMemcpyHostToDevice));
   launch_kmer_count(ix->st[0], ix->wide, d_k, k, n, d_out, 0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(counts, d_out, n * 8, hipMemcpyDeviceToHost));
-  hipFree(d_k);
-  hipFree(d_out);
   return SIGAX_OK;
 }
 
@@ -418,16 +415,17 @@ extern "C" int sigax_correct_batch(sigax_index* ix, const char* seqs, const char
   const u64 nb = offs[n_reads];
   unsigned char *d_seqs = nullptr, *d_quals = nullptr, *d_out = nullptr, *d_valid = nullptr;
   u64 *d_offs = nullptr, *d_stat = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_seqs, nb + 16));
-  HIP_TRY(hipMalloc((void**)&d_out, nb + 16));
-  HIP_TRY(hipMalloc((void**)&d_offs, ((size_t)n_reads + 1) * 8));
-  HIP_TRY(hipMalloc((void**)&d_valid, (size_t)n_reads + 16));
-  HIP_TRY(hipMalloc((void**)&d_stat, 64));
+  DevGuard g;
+  HIP_TRY(g.alloc((void**)&d_seqs, nb + 16));
+  HIP_TRY(g.alloc((void**)&d_out, nb + 16));
+  HIP_TRY(g.alloc((void**)&d_offs, ((size_t)n_reads + 1) * 8));
+  HIP_TRY(g.alloc((void**)&d_valid, (size_t)n_reads + 16));
+  HIP_TRY(g.alloc((void**)&d_stat, 64));
   HIP_TRY(hipMemset(d_stat, 0, 64));
   HIP_TRY(hipMemcpy(d_seqs, seqs, nb, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_offs, offs, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
   if (quals) {
-    HIP_TRY(hipMalloc((void**)&d_quals, nb + 16));
+    HIP_TRY(g.alloc((void**)&d_quals, nb + 16));
     HIP_TRY(hipMemcpy(d_quals, quals, nb, hipMemcpyHostToDevice));
   }
   CorrectArgs ca;
@@ -452,8 +450,6 @@ extern "C" int sigax_correct_batch(sigax_index* ix, const char* seqs, const char
   HIP_TRY(hipMemcpy(&toolong, d_stat, 8, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(out_seqs, d_out, nb, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(valid, d_valid, n_reads, hipMemcpyDeviceToHost));
-  hipFree(d_seqs); hipFree(d_out); hipFree(d_offs); hipFree(d_valid); hipFree(d_stat);
-  if (d_quals) hipFree(d_quals);
   if (toolong) return fail(SIGAX_E_ARG, "%llu reads are longer than the 1024 bases the correction kernel supports", toolong);
   return SIGAX_OK;
 }
@@ -654,13 +650,18 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   // general filter/extract kernel (reads the fast kernel queued): persistent lanes with a private pool each
   unsigned want_grid = (unsigned)std::min<u64>(128, ((u64)n + 255) / 256);
   if (want_grid == 0) want_grid = 1;
-  uint32_t want_pool = std::max<uint32_t>(b->pool_cap, 4u * (b->cap + 2u) + 128u);
+  // SIGAX_TEST_{POOL,FIN,EDGE}_CAP: tiny first sizes, so that tests reach the grow-and-rerun loop of sigax_batch_finish
+  const char* t_pool = getenv("SIGAX_TEST_POOL_CAP");
+  const char* t_fin = getenv("SIGAX_TEST_FIN_CAP");
+  const char* t_edge = getenv("SIGAX_TEST_EDGE_CAP");
+  uint32_t want_pool = std::max<uint32_t>(b->pool_cap, t_pool ? (uint32_t)atoi(t_pool) : 4u * (b->cap + 2u) + 128u);
   b->fx_grid = want_grid;
   b->pool_cap = want_pool;
   if ((rc = ensure(&b->pool, (size_t)want_grid * 256 * want_pool * SIGAX_ENT_BYTES)) != SIGAX_OK) return rc;
   // the unordered arena is handed out in chunks (one atomic per chunk): leave room for every wave's / lane's tail
   u64 chunk_slack = (u64)fast_grid * 4 * fast_fin_chunk() + (u64)want_grid * 256 * 64 + 1024;
   u64 want_fin = ((b->flags & SIGAX_IRREDUCIBLE) ? (u64)n * 8 : (u64)n * 64) + chunk_slack;
+  if (t_fin) want_fin = std::max<u64>(strtoull(t_fin, nullptr, 10), 1);
   b->fin_cap = std::max<u64>(b->fin_cap, want_fin);
   if ((rc = ensure(&b->fin, b->fin_cap * sizeof(sigax_block))) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->outb, b->fin_cap * sizeof(sigax_block))) != SIGAX_OK) return rc;
@@ -668,7 +669,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   u64 scan_n = std::max<u64>(2 * (u64)n, b->fin_cap);
   if ((rc = ensure(&b->partial, scan_partials_needed(scan_n) * 8)) != SIGAX_OK) return rc;
   if (edges) {
-    if (b->edge_cap == 0) b->edge_cap = b->fin_cap * 2 + 1024;
+    if (b->edge_cap == 0) b->edge_cap = t_edge ? std::max<u64>(strtoull(t_edge, nullptr, 10), 1) : b->fin_cap * 2 + 1024;
     if ((rc = ensure(&b->edge_cnt, (b->fin_cap + 1) * 4)) != SIGAX_OK) return rc;
     if ((rc = ensure(&b->edge_offs, (b->fin_cap + 2) * 8)) != SIGAX_OK) return rc;
     if ((rc = ensure(&b->edges, b->edge_cap * sizeof(sigax_edge))) != SIGAX_OK) return rc;

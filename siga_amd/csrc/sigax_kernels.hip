@@ -2292,6 +2292,9 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void k_edges(EdgeArgs A) {
   u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
   u64 nblocks = A.block_offs[A.n_reads];
+  // after an overflow of the final-block arena the scanned total exceeds what `blocks`, `edge_cnt` and `edge_offs` hold
+  // (the host discards that run and repeats it with larger arenas): stay inside them
+  if (nblocks > A.cnt_cap) nblocks = A.cnt_cap;
   if (i >= nblocks) {
     if (!FILL && i < A.cnt_cap) A.edge_cnt[i] = 0;
     return;

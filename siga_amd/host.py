@@ -17,6 +17,9 @@ def lib():
             raise ImportError("siga_amd host library missing: %s (python -m siga_amd.build)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         L.sigah_index_build.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_int, C.c_char_p, C.c_uint64]
+        L.sigah_index_build_dev.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_char_p, C.c_uint64]
+        L.sigah_index_file_dev.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_uint64]
         L.sigah_index_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_uint64]
         L.sigah_overlap_file.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_int, C.c_int, C.c_uint64,
                                          C.c_uint64, C.c_int, C.c_char_p, C.c_uint64]
@@ -35,6 +38,25 @@ def index_build(seq_bytes, offs, prefix, threads=2):
     err = C.create_string_buffer(512)
     buf = seq_bytes if isinstance(seq_bytes, (bytes, bytearray)) else np.ascontiguousarray(seq_bytes).tobytes()
     if lib().sigah_index_build(buf, offs.ctypes.data, len(offs) - 1, prefix.encode(), threads, err, 512) != 0:
+        raise RuntimeError("siga index failed: " + err.value.decode())
+
+
+def index_build_gpu(seq_bytes, offs, prefix, device=0, threads=2):
+    """`siga index` for in-memory reads on the GPU (sigax_build_strand): writes <prefix>.{bwt,sai,rbwt,rsai}."""
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    err = C.create_string_buffer(512)
+    if isinstance(seq_bytes, np.ndarray):
+        arr = np.ascontiguousarray(seq_bytes)
+        ptr = C.c_char_p(arr.ctypes.data)  # no copy: BASELINE-sized sets are gigabytes
+    else:
+        ptr = seq_bytes
+    if lib().sigah_index_build_dev(ptr, offs.ctypes.data, len(offs) - 1, prefix.encode(), device, threads, 1, 1, err, 512) != 0:
+        raise RuntimeError("siga index failed: " + err.value.decode())
+
+
+def index_file_gpu(reads_path, prefix, device=0, threads=2):
+    err = C.create_string_buffer(512)
+    if lib().sigah_index_file_dev(reads_path.encode(), prefix.encode(), device, threads, 1, 1, err, 512) != 0:
         raise RuntimeError("siga index failed: " + err.value.decode())
 
 

@@ -376,6 +376,28 @@ bool BuildStrandIndex(const char* seqs, const uint64_t* offs, uint64_t nReads, b
   }
 }
 
+// The same on the GPU (libsigax: sigax_build_strand).  *rc receives the library's code: SIGAX_E_CAPACITY means the input
+// is too repetitive for the device sort and the caller should use BuildStrandIndex.
+bool BuildStrandIndexGPU(const char* seqs, const uint64_t* offs, uint64_t nReads, bool reverse, int device, StrandIndex* out,
+                         std::string* error, int* rc_out) {
+  uint8_t* runs = nullptr;
+  uint32_t* sai = nullptr;
+  uint64_t nruns = 0, nsym = 0;
+  int rc = sigax_build_strand(seqs, offs, nReads, reverse ? 1 : 0, device, &runs, &nruns, &sai, &nsym);
+  if (rc_out) *rc_out = rc;
+  if (rc != SIGAX_OK) {
+    if (error) *error = sigax_last_error();
+    return false;
+  }
+  out->runs.assign(runs, runs + nruns);
+  out->sai.assign(sai, sai + nReads);
+  out->nStrings = nReads;
+  out->nSymbols = nsym;
+  sigax_free(runs);
+  sigax_free(sai);
+  return true;
+}
+
 bool StrandIndex::writeBWT(const std::string& path) const {
   FILE* f = fopen(path.c_str(), "wb");
   if (!f) return false;
@@ -928,6 +950,52 @@ int sigah_index_build(const char* seqs, const uint64_t* offs, uint64_t n_reads, 
     return -1;
   }
   return 0;
+}
+
+// `siga index` on the GPU: both strands through sigax_build_strand; an input too repetitive for the device sort is
+// built by the host SA-IS instead (said on stderr).  device < 0: host builder only.
+int sigah_index_build_dev(const char* seqs, const uint64_t* offs, uint64_t n_reads, const char* prefix, int device, int threads,
+                          int do_fwd, int do_rev, char* err, uint64_t errcap) {
+  if (device < 0) {
+    if (do_fwd && do_rev) return sigah_index_build(seqs, offs, n_reads, prefix, threads, err, errcap);
+  }
+  std::string p(prefix), e;
+  for (int rev = 0; rev < 2; ++rev) {
+    if ((rev == 0 && !do_fwd) || (rev == 1 && !do_rev)) continue;
+    sigah::StrandIndex ix;
+    int rc = 0;
+    bool ok = device >= 0 && sigah::BuildStrandIndexGPU(seqs, offs, n_reads, rev != 0, device, &ix, &e, &rc);
+    if (!ok && (device < 0 || rc == SIGAX_E_CAPACITY)) {
+      if (device >= 0) fprintf(stderr, "siga index: %s; using the host suffix sorter\n", e.c_str());
+      ok = sigah::BuildStrandIndex(seqs, offs, n_reads, rev != 0, &ix, &e, (unsigned)std::max(threads, 1));
+    }
+    if (ok) {
+      ok = ix.writeSAI(p + (rev ? ".rsai" : ".sai")) && ix.writeBWT(p + (rev ? ".rbwt" : ".bwt"));
+      if (!ok) e = "cannot write index files with prefix " + p;
+    }
+    if (!ok) {
+      if (err && errcap) snprintf(err, errcap, "%s", e.c_str());
+      return -1;
+    }
+  }
+  return 0;
+}
+
+// `siga index READS` with the device builder (device < 0: host builder)
+int sigah_index_file_dev(const char* reads_path, const char* prefix, int device, int threads, int do_fwd, int do_rev, char* err,
+                         uint64_t errcap) {
+  sigah::DNASeqList reads;
+  if (!sigah::ReadDNASequences(reads_path, reads, 0)) {
+    if (err && errcap) snprintf(err, errcap, "Failed to open input file %s", reads_path);
+    return -1;
+  }
+  std::string seqs;
+  std::vector<uint64_t> offs(1, 0);
+  for (auto& r : reads) {
+    seqs += r.seq;
+    offs.push_back(seqs.size());
+  }
+  return sigah_index_build_dev(seqs.data(), offs.data(), reads.size(), prefix, device, threads, do_fwd, do_rev, err, errcap);
 }
 
 // `siga index READS`

@@ -60,6 +60,10 @@ struct StrandIndex {
 bool BuildStrandIndex(const char* seqs, const uint64_t* offs, uint64_t nReads, bool reverse, StrandIndex* out,
                       std::string* error, unsigned threads = 1);
 
+// the same on the GPU (sigax_build_strand); *rc = the library's code (SIGAX_E_CAPACITY: use BuildStrandIndex)
+bool BuildStrandIndexGPU(const char* seqs, const uint64_t* offs, uint64_t nReads, bool reverse, int device, StrandIndex* out,
+                         std::string* error, int* rc = nullptr);
+
 // FMIndex pair resident on a GPU (FMIndex::load x2, src/overlap.cpp:41-42)
 class FMIndex {
  public:

@@ -10,7 +10,7 @@
 
 #include "siga_host.hpp"
 
-extern "C" int sigah_index_file(const char*, const char*, int, char*, uint64_t);
+extern "C" int sigah_index_file_dev(const char*, const char*, int, int, int, int, char*, uint64_t);
 
 static int usage() {
   printf("siga [index|correct|overlap|rmdup] [OPTION] ... READSFILE\n"
@@ -30,6 +30,8 @@ static int index_help() {
          "      -p, --prefix=PREFIX              write index to file using PREFIX instead of prefix of READSFILE\n"
          "          --no-reverse                 suppress construction of the reverse BWT\n"
          "          --no-forward                 suppress construction of the forward BWT\n"
+         "          --device=NUM                 GPU that sorts the suffixes (default: 0)\n"
+         "          --cpu                        sort on the host (-t threads) instead; also taken when no GPU is visible\n"
          "\n");
   return 256;
 }
@@ -53,14 +55,16 @@ static int overlap_help() {
 }
 
 static int run_index(int argc, char** argv) {
-  enum { OPT_NO_REVERSE = 1, OPT_NO_FORWARD };
-  static const option longopts[] = {{"prefix", required_argument, nullptr, 'p'},   {"algorithm", required_argument, nullptr, 'a'},
+  enum { OPT_NO_REVERSE = 1, OPT_NO_FORWARD, OPT_DEVICE, OPT_CPU };
+  static const option longopts[] = {{"log4cxx", required_argument, nullptr, 'c'},  {"ini", required_argument, nullptr, 's'},
+                                    {"prefix", required_argument, nullptr, 'p'},   {"algorithm", required_argument, nullptr, 'a'},
                                     {"threads", required_argument, nullptr, 't'},  {"no-reverse", no_argument, nullptr, OPT_NO_REVERSE},
-                                    {"no-forward", no_argument, nullptr, OPT_NO_FORWARD}, {"help", no_argument, nullptr, 'h'},
+                                    {"no-forward", no_argument, nullptr, OPT_NO_FORWARD}, {"device", required_argument, nullptr, OPT_DEVICE},
+                                    {"cpu", no_argument, nullptr, OPT_CPU},        {"help", no_argument, nullptr, 'h'},
                                     {nullptr, 0, nullptr, 0}};
   std::string prefix, algorithm = "sais2";
-  int threads = 1, c;
-  bool help = false, nofwd = false, norev = false;
+  int threads = 1, c, device = 0;
+  bool help = false, nofwd = false, norev = false, cpu = false;
   while ((c = getopt_long(argc, argv, "c:s:a:t:p:h", longopts, nullptr)) != -1) {
     switch (c) {
       case 'p': prefix = optarg; break;
@@ -68,6 +72,8 @@ static int run_index(int argc, char** argv) {
       case 't': threads = atoi(optarg); break;
       case OPT_NO_REVERSE: norev = true; break;
       case OPT_NO_FORWARD: nofwd = true; break;
+      case OPT_DEVICE: device = atoi(optarg); break;
+      case OPT_CPU: cpu = true; break;
       case 'h': help = true; break;
       default: break;
     }
@@ -79,29 +85,12 @@ static int run_index(int argc, char** argv) {
     fprintf(stderr, "Failed to create suffix array builder algorithm %s\n", algorithm.c_str());
     return -1;
   }
-  if (nofwd || norev) {
-    sigah::DNASeqList reads;
-    if (!sigah::ReadDNASequences(input, reads, 0)) {
-      fprintf(stderr, "Failed to open input file %s\n", input.c_str());
-      return -1;
-    }
-    std::string seqs;
-    std::vector<uint64_t> offs(1, 0);
-    for (auto& r : reads) { seqs += r.seq; offs.push_back(seqs.size()); }
-    std::string err;
-    sigah::StrandIndex ix;
-    if (!nofwd) {
-      if (!sigah::BuildStrandIndex(seqs.data(), offs.data(), reads.size(), false, &ix, &err) || !ix.writeSAI(prefix + ".sai") ||
-          !ix.writeBWT(prefix + ".bwt")) return -1;
-    }
-    if (!norev) {
-      if (!sigah::BuildStrandIndex(seqs.data(), offs.data(), reads.size(), true, &ix, &err) || !ix.writeSAI(prefix + ".rsai") ||
-          !ix.writeBWT(prefix + ".rbwt")) return -1;
-    }
-    return 0;
+  if (!cpu) {
+    int ndev = 0;
+    if (sigax_device_count(&ndev) != SIGAX_OK || ndev <= 0) cpu = true;  // `siga index` also runs on a host without a GPU
   }
   char err[512] = "";
-  if (sigah_index_file(input.c_str(), prefix.c_str(), threads, err, sizeof(err)) != 0) {
+  if (sigah_index_file_dev(input.c_str(), prefix.c_str(), cpu ? -1 : device, threads, nofwd ? 0 : 1, norev ? 0 : 1, err, sizeof(err)) != 0) {
     fprintf(stderr, "%s\n", err);
     return -1;
   }

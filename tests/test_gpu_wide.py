@@ -41,3 +41,11 @@ def test_two_step_table_limit_env():
     both give the same answers."""
     _run_parity({"SIGAX_TWO_STEP_MAX_SYMBOLS": "1000"}, "toy or tiny")
     _run_parity({"SIGAX_TWO_STEP_MAX_SYMBOLS": "100000000"}, "toy or tiny")
+
+
+def test_arena_regrow_and_rerun():
+    """Tiny first sizes for the final-block arena, the edge buffer and the general kernel's pool: sigax_batch_finish
+    must grow each and repeat the run, and the repeated run must give the oracle's bytes (k_edges stays inside its
+    buffers on the overflowing run)."""
+    _run_parity({"SIGAX_TEST_FIN_CAP": "64", "SIGAX_TEST_EDGE_CAP": "16"}, "hits_and_asqg and (toy or dup or rep)")
+    _run_parity({"SIGAX_TEST_POOL_CAP": "24", "SIGAX_GENERAL_ONLY": "1", "SIGAX_TEST_FIN_CAP": "100"}, "hits_and_asqg and (toy or rep or corner)")
