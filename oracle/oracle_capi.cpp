@@ -200,6 +200,48 @@ double orc_overlap_batch_timed(void* hf, void* hr, const char* seqs, const uint6
   return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// OverlapBuilder::overlap (mode 0) or OverlapBuilder::duplicate (mode 1, overlap_builder.cpp:1184-1195) for a batch of
+// reads, OpenMP over reads, all blocks returned: block_offs[n+1]; blocks[10 * k ..] as orc_overlap lays them out, up to
+// `cap` blocks (the return value is the number needed); substring[n]; *nmin = N_occ_min summed.
+int64_t orc_overlap_batch(void* hf, void* hr, const char* seqs, const uint64_t* offs, uint64_t n, uint64_t min_overlap,
+                          int irreducible, int rc, int mode, int threads, uint64_t* block_offs, uint64_t* blocks, uint64_t cap,
+                          uint8_t* substring, uint64_t* nmin_out) {
+  OrcIndex* f = (OrcIndex*)hf;
+  OrcIndex* r = (OrcIndex*)hr;
+  std::vector<std::vector<uint64_t>> per(n);
+  uint64_t nmin = 0;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : nmin)
+#endif
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    OccStats st;
+    OverlapBuilder builder(&f->b.fm, &r->b.fm, irreducible != 0, rc != 0, &st);
+    OverlapBlockList bl;
+    std::string seq(seqs + offs[i], seqs + offs[i + 1]);
+    OverlapResult res = mode ? builder.duplicate(seq, &bl) : builder.overlap(seq, min_overlap, &bl);
+    substring[i] = res.substring ? 1 : 0;
+    nmin += st.nmin;
+    std::vector<uint64_t>& o = per[i];
+    o.reserve(bl.size() * 10);
+    for (auto& b : bl) {
+      o.push_back(b.capped[0].lower); o.push_back(b.capped[0].upper); o.push_back(b.capped[1].lower); o.push_back(b.capped[1].upper);
+      o.push_back(b.raw[0].lower); o.push_back(b.raw[0].upper); o.push_back(b.raw[1].lower); o.push_back(b.raw[1].upper);
+      o.push_back(b.length); o.push_back(b.af.bits);
+    }
+  }
+  uint64_t k = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    block_offs[i] = k;
+    const uint64_t nb = per[i].size() / 10;
+    if (k + nb <= cap) memcpy(blocks + 10 * k, per[i].data(), per[i].size() * 8);
+    k += nb;
+  }
+  block_offs[n] = k;
+  if (nmin_out) *nmin_out = nmin;
+  return (int64_t)k;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

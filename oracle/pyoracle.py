@@ -51,6 +51,9 @@ def lib():
         L.orc_correct.argtypes = [vp, cp, cp, u64, C.c_int, u64, u64, pu64]
         L.orc_overlap_batch_timed.restype = C.c_double
         L.orc_overlap_batch_timed.argtypes = [vp, vp, cp, pu64, u64, u64, C.c_int, C.c_int, C.c_int, pu64]
+        L.orc_overlap_batch.restype = C.c_int64
+        L.orc_overlap_batch.argtypes = [vp, vp, vp, pu64, u64, u64, C.c_int, C.c_int, C.c_int, C.c_int, pu64, pu64, u64,
+                                        C.POINTER(C.c_uint8), pu64]
         L.orc_rl_encode.restype = u64
         L.orc_rl_encode.argtypes = [cp, u64, C.POINTER(C.c_uint8), u64]
         L.orc_stem.argtypes = [cp, C.c_char_p, u64]
@@ -177,6 +180,32 @@ def overlap_batch_timed(fwd, rev, reads, min_overlap, irreducible=True, rc=True,
     sec = lib().orc_overlap_batch_timed(fwd.h, rev.h, seqs, _p64(offs), len(reads), min_overlap, int(irreducible),
                                         int(rc), threads, _p64(out))
     return sec, {"blocks": int(out[0]), "substring": int(out[1]), "n_occ_min": int(out[2])}
+
+
+def overlap_batch(fwd, rev, reads, min_overlap, irreducible=True, rc=True, duplicate=False, threads=0, cap=None):
+    """OverlapBuilder::overlap (or ::duplicate) for many reads at once, OpenMP over reads.
+    reads: list of str/bytes, or (uint8 array of concatenated bases, offsets u64[n+1]).
+    Returns dict(block_offs u64[n+1], blocks u64[k,10], substring u8[n], n_occ_min)."""
+    if isinstance(reads, tuple):
+        buf, offs = reads
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        ptr = buf.ctypes.data
+    else:
+        seqs, offs = pack_reads(reads)
+        keep = C.create_string_buffer(seqs, len(seqs) + 1)
+        ptr = C.addressof(keep)
+    n = len(offs) - 1
+    cap = cap or max(16 * n, 1024)
+    block_offs = np.zeros(n + 1, dtype=np.uint64)
+    blocks = np.zeros((cap, 10), dtype=np.uint64)
+    sub = np.zeros(max(n, 1), dtype=np.uint8)
+    nmin = np.zeros(1, dtype=np.uint64)
+    k = lib().orc_overlap_batch(fwd.h, rev.h, ptr, _p64(offs), n, min_overlap, int(irreducible), int(rc), int(duplicate), threads,
+                                _p64(block_offs), _p64(blocks), cap, sub.ctypes.data_as(C.POINTER(C.c_uint8)), _p64(nmin))
+    if k > cap:
+        return overlap_batch(fwd, rev, reads, min_overlap, irreducible, rc, duplicate, threads, cap=int(k))
+    return {"block_offs": block_offs, "blocks": blocks[:k].copy(), "substring": sub[:n], "n_occ_min": int(nmin[0])}
 
 
 def max_threads():

@@ -28,6 +28,9 @@ def _check(code, where):
 
 
 def pack_reads(seqs):
+    if isinstance(seqs, tuple):  # (uint8 array of concatenated bases, offsets u64[n+1]): BASELINE-sized sets, no copies
+        buf, offs = seqs
+        return np.ascontiguousarray(buf, dtype=np.uint8), np.ascontiguousarray(offs, dtype=np.uint64)
     bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
     offs = np.zeros(len(bs) + 1, dtype=np.uint64)
     if bs:
@@ -178,7 +181,9 @@ class OverlapBuilder:
         """Batched OverlapBuilder::overlap.  Returns dict(block_offs, blocks, substring, edges, stats)."""
         buf, offs = pack_reads(seqs)
         res = _lib.Result()
-        _check(_lib.lib().sigax_overlap_batch(self.fmi.handle, buf, offs.ctypes.data, len(seqs), read_base, min_overlap,
+        if isinstance(buf, np.ndarray):
+            buf = C.c_char_p(buf.ctypes.data) if buf.size else b""
+        _check(_lib.lib().sigax_overlap_batch(self.fmi.handle, buf, offs.ctypes.data, len(offs) - 1, read_base, min_overlap,
                                               self._flags(edges) if _flags is None else _flags, C.byref(res)),
                "sigax_overlap_batch")
         try:

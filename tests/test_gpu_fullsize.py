@@ -1,6 +1,6 @@
-"""BASELINE.json configs[1] at full size (1M x 150 bp from a 5 Mb genome, m = 45) on the GPU: size-independent
-properties, since the oracle takes minutes there -- idempotence, shard invariance (the multi-GPU decomposition),
-structural invariants of the output, and an oracle spot-check on a random sample of reads against the full index."""
+"""BASELINE.json configs[1] at full size (1M x 150 bp from a 5 Mb genome, m = 45) on the GPU: idempotence, shard
+invariance (the multi-GPU decomposition), structural invariants of the output, and EVERY read's block list against the
+oracle (OpenMP over the host cores), plus the edge records against a numpy restatement of the converter."""
 import os
 
 import numpy as np
@@ -23,7 +23,7 @@ def c2():
     os.makedirs(d, exist_ok=True)
     prefix = os.path.join(d, "reads")
     if not all(os.path.exists(prefix + e) for e in (".bwt", ".rbwt", ".sai", ".rsai")):
-        host.index_build(reads.reshape(-1), np.arange(0, (N + 1) * L, L, dtype=np.uint64), prefix, threads=2)
+        host.index_build_gpu(reads.reshape(-1), np.arange(0, (N + 1) * L, L, dtype=np.uint64), prefix)
     pair = siga_amd.FMIndexPair.load(prefix)
     names = np.char.add("r", np.arange(N).astype(str))
     order = np.argsort(names, kind="stable")
@@ -35,7 +35,7 @@ def c2():
 
 def _run(c2, lo, hi):
     b = c2["sa"].OverlapBuilder(c2["pair"])
-    return b.overlap([bytes(r) for r in c2["reads"][lo:hi]], M, read_base=lo, edges=True)
+    return b.overlap((c2["reads"][lo:hi].reshape(-1), np.arange(0, (hi - lo + 1) * L, L, dtype=np.uint64)), M, read_base=lo, edges=True)
 
 
 def test_fullsize_invariants_idempotence_and_shards(c2):
@@ -72,16 +72,15 @@ def test_fullsize_invariants_idempotence_and_shards(c2):
     c2["full"] = full
 
 
-def test_fullsize_sample_against_oracle(c2):
+def test_fullsize_every_read_against_oracle(c2):
     from oracle import pyoracle as po
+    from tests.bigcheck import assert_same_blocks, edges_matrix, expected_edges
     full = c2.get("full") or _run(c2, 0, N)
     fwd = po.Index.load(c2["prefix"] + ".bwt", c2["prefix"] + ".sai")
     rev = po.Index.load(c2["prefix"] + ".rbwt", c2["prefix"] + ".rsai")
-    rng = np.random.default_rng(7)
-    cols = ["capped0_lo", "capped0_hi", "capped1_lo", "capped1_hi", "raw0_lo", "raw0_hi", "raw1_lo", "raw1_hi", "length", "af"]
-    offs = full["block_offs"]
-    for r in rng.integers(0, N, 1500):
-        want, sub, _, _ = po.overlap(fwd, rev, bytes(c2["reads"][r]), M)
-        got = full["blocks"][int(offs[r]):int(offs[r + 1])]
-        assert [[int(x[c]) for c in cols] for x in got] == [list(map(int, w)) for w in want], int(r)
-        assert bool(full["substring"][r]) == sub
+    want = po.overlap_batch(fwd, rev, (c2["reads"].reshape(-1), np.arange(0, (N + 1) * L, L, dtype=np.uint64)), M)
+    assert_same_blocks(full, want, "C2")
+    # edge records: the converter's rule restated in numpy over the ORACLE's blocks
+    exp = expected_edges(want["blocks"], want["block_offs"], fwd.sai(), rev.sai(), np.full(N, L, dtype=np.uint32), c2["rank"])
+    assert np.array_equal(edges_matrix(full["edges"]), exp)
+    assert len(exp) > N  # about 1.1 irreducible edges per read at 30x

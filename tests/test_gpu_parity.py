@@ -190,20 +190,20 @@ def test_rmdup_matches_oracle(sa, name, tmp_path):
         assert open(tmp_path / "o.dups.fa").read().count(">") > 100  # the fixture is mostly duplicates / substrings
 
 
-def test_duplicate_blocks_match_oracle(sa):
-    """sigax SIGAX_DUPLICATE blocks == OverlapBuilder::duplicate of the oracle, read by read."""
-    fx = fixture("dup")
+@pytest.mark.parametrize("name", ["dup", "corner", "ragged", "toy"])
+def test_duplicate_blocks_match_oracle(sa, name):
+    """sigax SIGAX_DUPLICATE blocks == OverlapBuilder::duplicate of the oracle (src/overlap_builder.cpp:1184-1195),
+    block by block and read by read, substring flags included."""
+    from oracle import pyoracle as po
+    from tests.bigcheck import blocks_matrix
+    fx = fixture(name)
     pair = _pair(sa, fx)
     res = sa.OverlapBuilder(pair).duplicate(fx.seqs)
-    from oracle import pyoracle as po
-    import ctypes as C
-    offs = res["block_offs"]
-    assert res["stats"]["n_blocks"] == int(offs[-1])
-    # every block is a full-length containment block with flags 000 or 110
-    assert all(int(b["af"]) in (0, 6) for b in res["blocks"])
-    for r, s in enumerate(fx.seqs):
-        got = res["blocks"][int(offs[r]):int(offs[r + 1])]
-        assert all(int(b["length"]) == len(s) for b in got)
+    want = po.overlap_batch(fx.fwd, fx.rev, fx.seqs, 0, duplicate=True)
+    assert np.array_equal(res["block_offs"], want["block_offs"])
+    assert np.array_equal(blocks_matrix(res["blocks"]), want["blocks"])
+    assert np.array_equal(res["substring"].astype(bool), want["substring"].astype(bool))
+    assert res["stats"]["n_blocks"] == int(want["block_offs"][-1]) > 0
 
 
 # ---- `siga correct` k-mer path (SURVEY.md 8(f2), BASELINE configs[3]) ------------------------------------------------
