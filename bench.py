@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- reads/s overlapped by the MI355X-native `siga overlap` path (BASELINE.json metric).
 
-A "step" is one pass of the whole hot path (block finder -> sub-maximal filter / irreducible extraction ->
-ordered compaction -> edge records) over this rank's shard of reads, inputs already resident in HBM, followed (for
-N > 1) by the RCCL gather of the edge records to rank 0.  Workload at N = 1: BASELINE configs[1], synthetic
-1M x 150 bp reads from a 5 Mb genome, min-overlap 45, irreducible, both strands.  For N > 1 the per-GPU share is
-kept (weak scaling): N x 1M reads from an N x 5 Mb genome, index replicated on every GPU, reads sharded.
+A "step" is one pass of the whole hot path (block finder -> sub-maximal filter / irreducible extraction -> ordered
+compaction -> edge records) over this rank's shard of reads, inputs already resident in HBM, ending with the edge
+records in pinned host memory on rank 0 (for N > 1 after the RCCL gather to rank 0).  Workload at N = 1: BASELINE
+configs[1], synthetic 1M x 150 bp reads from a 5 Mb genome, min-overlap 45, irreducible, both strands.  For N > 1 the
+per-GPU share is kept (weak scaling): N x 1M reads from an N x 5 Mb genome, index replicated on every GPU, reads sharded.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]         (N > 1: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --workload correct                          (BASELINE configs[3]: `siga correct` k-mer path)
 
 Prints ONE JSON line on rank 0.
 """
@@ -16,6 +17,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -25,7 +28,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+GATHER_CEILING_GLINES = 55.0  # dependency-free random line reads this chip sustains (profiles/r01_gather_probe*.txt): 55-57 G lines/s
 KERNELS = ["k_find", "k_filter_extract_fast", "k_filter_extract", "k_order", "k_edges"]
 
 
@@ -33,11 +37,12 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="overlap", choices=["overlap", "correct"])
     ap.add_argument("--reads-per-gpu", type=int, default=1000000)
     ap.add_argument("--genome-per-gpu", type=int, default=5000000)
     ap.add_argument("--read-len", type=int, default=150)
@@ -57,8 +62,39 @@ def main():
                          "in this single process, to see what one GPU of that job achieves")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow on fewer GPUs than ranks (edge records gathered via host)")
-    args = ap.parse_args()
+    ap.add_argument("--kmer", type=int, default=31, help="--workload correct: k-mer size (31 = code default, 41 = example script)")
+    ap.add_argument("--error-rate", type=float, default=0.01, help="--workload correct: substitutions per base")
+    return ap.parse_args()
 
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as fresh child processes (torchrun, one
+    per GPU) BEFORE anything in this process touches the GPU, and leave with their exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("starting %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    return subprocess.call(cmd)
+
+
+def rank_of_r_names(n):
+    from tests.golden.make_reads import rank_of_r_names as f
+    return f(n)
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    if args.workload == "correct":
+        return bench_correct(args)
+    return bench_overlap(args)
+
+
+def bench_overlap(args):
     import torch
     import torch.distributed as dist
 
@@ -94,7 +130,7 @@ def main():
     workdir = args.workdir or os.path.join(tempfile.gettempdir(), "siga_bench_%d_%d_%d_%d" % (n_total, G, L, args.seed))
     prefix = os.path.join(workdir, "reads")
 
-    # ---- synthetic reads (every rank draws the same set) and the index (rank 0 builds, everyone loads) ----
+    # ---- synthetic reads (every rank draws the same set) and the index (rank 0 builds on its GPU, everyone loads) ----
     t0 = time.time()
     reads, _ = fast_reads(G, L, n_total, args.seed)  # uint8 [n_total, L]
     if rank == 0:
@@ -102,18 +138,14 @@ def main():
         os.makedirs(workdir, exist_ok=True)
         if not all(os.path.exists(prefix + e) for e in (".bwt", ".rbwt", ".sai", ".rsai")):
             offs_all = np.arange(0, (n_total + 1) * L, L, dtype=np.uint64)
-            host.index_build(reads.reshape(-1), offs_all, prefix, threads=max(2, min(os.cpu_count() or 2, 96)))
+            host.index_build_gpu(reads.reshape(-1), offs_all, prefix, device=dev_index)
         log("reads + index ready in %.1f s (%d reads, %d symbols per strand)" % (time.time() - t0, n_total, n_total * (L + 1)))
     if world > 1:
         dist.barrier()
     pair = FMIndexPair.load(prefix, device=dev_index)
     info = pair.info()
     # ReadInfo{name,length}: names r<i>; rank of a name under std::string operator<
-    names = np.char.add("r", np.arange(n_total).astype(str))
-    order = np.argsort(names, kind="stable")
-    name_rank = np.empty(n_total, dtype=np.uint32)
-    name_rank[order] = np.arange(n_total, dtype=np.uint32)
-    pair.set_reads(np.full(n_total, L, dtype=np.uint32), name_rank)
+    pair.set_reads(np.full(n_total, L, dtype=np.uint32), rank_of_r_names(n_total))
     log("index on GPU: %.1f MB, wide=%d (%.1f s since start)" % (info["device_bytes"] / 1e6, info["wide"], time.time() - t0))
 
     lo, hi = shard_range(n_total, rank, job_world)
@@ -140,7 +172,7 @@ def main():
     batch = batches[0]
     torch.cuda.synchronize(dev)
 
-    class _EdgeView:  # zero-copy view of the library's device edge buffer for torch.distributed
+    class _EdgeView:  # zero-copy view of the library's device edge buffer for torch
         def __init__(self, ptr, n):
             self.__cuda_array_interface__ = {"shape": (n, 4), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
@@ -151,16 +183,32 @@ def main():
     inflight = [False] * depth
     pending = []  # edge gathers in flight: step k's gather runs beside step k+1's kernels
     last_edges = [0]
+    host_edges = [None] * depth   # pinned host buffers: where a step's edge records end up (rank 0)
+    host_cap = [0]
+
+    def host_buf(i, need):
+        if host_edges[i] is None or host_edges[i].shape[0] < need:
+            host_cap[0] = max(host_cap[0], int(need * 1.25) + 1024)
+            host_edges[i] = torch.empty((host_cap[0], 4), dtype=torch.int32).pin_memory()
+        return host_edges[i]
+
+    def land(i, t):
+        """rank 0: the gathered records of one step -> pinned host memory (asynchronous copy on the batch's stream)"""
+        if t is not None and t.shape[0]:
+            host_buf(i, t.shape[0])[: t.shape[0]].copy_(t, non_blocking=True)
 
     def drain():
         tot = None
         while pending:
-            _, counts = pending.pop(0).wait()
+            i, pg = pending.pop(0)
+            t, counts = pg.wait()
+            with torch.cuda.stream(streams[i]):
+                land(i, t if (t is None or t.is_cuda) else None)
             tot = sum(counts)
         return tot
 
     def complete(i):
-        """finish batch i's run: stats, kernel times, and (N > 1) start the gather of its edge records"""
+        """finish batch i's run: stats, kernel times, and send its edge records on their way (N > 1: gather to rank 0)"""
         if not inflight[i]:
             return
         inflight[i] = False
@@ -171,18 +219,25 @@ def main():
         lib.sigax_batch_kernel_ms(batches[i], C.byref(kms), C.byref(nsub))  # HIP events on the streams the kernels run on
         ksum[:] += np.array(list(kms))
         last_edges[0] = int(stats.n_edges)
-        if world > 1:
-            d_edges = C.c_void_p()
-            lib.sigax_batch_device_outputs(batches[i], None, None, None, C.byref(d_edges))
-            ne = int(stats.n_edges)
-            with torch.cuda.stream(streams[i]):
+        d_edges = C.c_void_p()
+        lib.sigax_batch_device_outputs(batches[i], None, None, None, C.byref(d_edges))
+        ne = int(stats.n_edges)
+        with torch.cuda.stream(streams[i]):
+            if world == 1:
+                # the records leave the device here, inside the timed region; the copy runs beside the next step's kernels
+                # and is waited for when this batch object is finished the next time (or by the final synchronize)
+                if ne:
+                    land(i, torch.as_tensor(_EdgeView(d_edges.value, ne), device=dev))
+            else:
                 # copy out of the batch's buffer (its next run overwrites it), then gather asynchronously
                 local = torch.as_tensor(_EdgeView(d_edges.value, ne), device=dev).clone() if ne else torch.zeros((0, 4), dtype=torch.int32, device=dev)
                 if args.backend == "gloo":
                     local = local.cpu()
-                if len(pending) >= 2:
-                    pending.pop(0).wait()
-                pending.append(gather_edges_async(local))
+                while len(pending) >= 2:
+                    j, pg = pending.pop(0)
+                    t, _ = pg.wait()
+                    land(j, t if (t is None or t.is_cuda) else None)
+                pending.append((i, gather_edges_async(local)))
 
     def submit(k):
         i = k % depth
@@ -212,7 +267,7 @@ def main():
     total_edges = last_edges[0]
     if world > 1:
         total_edges = drain()  # every step's edge records have reached rank 0 before the clock stops
-    torch.cuda.synchronize(dev)
+    torch.cuda.synchronize(dev)  # ... and its pinned host buffer
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
@@ -223,6 +278,10 @@ def main():
     kavg = ksum / max(args.steps, 1)  # per step, summed over the step's sub-batch launches
     st = stats.as_dict()
     launches = int(nsub.value)
+    # finder launches per sub-batch: two (one per strand's table) when the two-step finder runs, see sigax_api.cpp
+    split = (info["n_symbols"] < (1 << 30) + (1 << 29)) and not info["wide"] and os.environ.get("SIGAX_TWO_STEP", "1") != "0" \
+        and 128 * L + 8 <= 41568
+    nsub_step = max(1, launches // (2 if split else 1))
 
     # the same kernels with sub-batching off (no overlap between find and filter/extract): untimed extra steps
     iso = None
@@ -238,46 +297,72 @@ def main():
     out = None
     if rank == 0:
         reads_per_s = (n_total if job_world == world else n_local) * args.steps / elapsed
-        # algorithmic bytes: 64 B per distinct Occ evaluation + L per read + 64 B per block out
-        n_occ = st["n_occ_find"] + st["n_occ_extract"]
-        bytes_find = 64 * st["n_occ_find"] + n_local * L + 64 * st["n_candidate_blocks"]
-        bytes_read = (64 * n_occ + n_local * L + 64 * st["n_blocks"]) / max(n_local, 1)
+        step_s = elapsed / args.steps
+        two_step = 1 if (info["n_symbols"] < (1 << 30) + (1 << 29) and not info["wide"] and os.environ.get("SIGAX_TWO_STEP", "1") != "0") else 0
+        cand_rec = 64 if info["wide"] else 32
+        # Algorithmic bytes of THIS formulation: the distinct 64-byte sectors of the rank tables each step /
+        # round asks for, counted by the kernels themselves (a 128-byte line of the two-step table = 2 sectors), plus
+        # the reads, the candidate records and the final records as they are written and read once.
+        sec_f, sec_x = st["n_sectors_find"], st["n_sectors_extract"]
+        bytes_find = 64 * sec_f + n_local * L + cand_rec * st["n_candidate_blocks"] + 16 * n_local
+        bytes_fx = 64 * sec_x + cand_rec * st["n_candidate_blocks"] + 16 * n_local + 48 * st["n_blocks"] + 16 * 2 * n_local
+        bytes_order = (48 + cand_rec + 80) * st["n_blocks"] + 20 * 2 * n_local
+        bytes_edges = 2 * (80 * st["n_blocks"] + 4 * st["n_edges"] + 12 * st["n_blocks"]) + 16 * st["n_edges"]
+        bytes_step = bytes_find + bytes_fx + bytes_order + bytes_edges
         find_ms = float(kavg[0]) / launches          # average duration of one k_find launch in the timed region
-        bytes_launch = bytes_find / launches
-        achieved = bytes_launch / (find_ms * 1e-3) / 1e9 if find_ms > 0 else 0.0
-        traffic = None
+        fx_ms = float(kavg[1]) / nsub_step           # ... of one sub-batch's 32-lane + 64-lane launch pair
+        ach_find = bytes_find / launches / (find_ms * 1e-3) / 1e9 if find_ms > 0 else 0.0
+        ach_fx = bytes_fx / nsub_step / (fx_ms * 1e-3) / 1e9 if fx_ms > 0 else 0.0
+        lines_find = sec_f / 2 if two_step else sec_f  # memory requests: 128-byte lines / 64-byte granules
+        glines = lines_find / launches / (find_ms * 1e-3) / 1e9 if find_ms > 0 else 0.0
+        traffic = fx_traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = "k_find/%d/%d/%d/%d" % (args.reads_per_gpu, args.genome_per_gpu, L, launches)
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                key = "%d/%d/%d/%d" % (args.reads_per_gpu, args.genome_per_gpu, L, launches)
+                traffic = tj.get("k_find/" + key, {}).get("hbm_bytes_per_launch")
+                fx_traffic = tj.get("k_filter_extract_fast/" + key, {}).get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic = fx_traffic = None
         out = {
             "metric": "reads/sec overlapped (ASQG bit-exact)", "value": reads_per_s, "unit": "reads/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "synthetic %dx%d bp reads from %d bp genome, min-overlap %d, irreducible, both strands; "
-                                   "FM-index (both strands) resident in HBM, reads sharded over %d GPU(s)" % (
+                                   "FM-index (both strands) resident in HBM, reads sharded over %d GPU(s), edge records to "
+                                   "pinned host memory on rank 0 inside the timed region" % (
                                        n_total, L, G, args.min_overlap, world),
                        "reads_per_gpu": n_local, "edges": total_edges, "blocks_per_read": st["n_blocks"] / max(n_local, 1),
-                       "n_occ_min_per_read": n_occ / max(n_local, 1), "algorithmic_bytes_per_read": bytes_read,
-                       "slow_path_reads": st["n_slow_reads"], "batches_in_flight": depth},
+                       "n_occ_min_per_read": (st["n_occ_find"] + st["n_occ_extract"]) / max(n_local, 1),
+                       "sectors_per_read": {"find": sec_f / max(n_local, 1), "extract": sec_x / max(n_local, 1)},
+                       "algorithmic_bytes_per_read": bytes_step / max(n_local, 1),
+                       "reference_formulation_bytes_per_read": (64 * (st["n_occ_find"] + st["n_occ_extract"]) + n_local * L + 64 * st["n_blocks"]) / max(n_local, 1),
+                       "slow_path_reads": st["n_slow_reads"], "batches_in_flight": depth, "two_step_table": two_step},
             "kernel_ms_per_step": {k: float(v) for k, v in zip(KERNELS, kavg)},
             "launches_per_step": launches,
-            "roofline": {"bound": "hbm", "kernel": "k_find", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": find_ms,
+            "roofline": {"bound": "hbm", "kernel": "k_find", "achieved": ach_find, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_find / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_find / launches, "avg_launch_ms": find_ms,
+                         "request_rate": {"achieved": glines, "ceiling": GATHER_CEILING_GLINES, "unit": "G lines/s",
+                                          "frac": glines / GATHER_CEILING_GLINES,
+                                          "note": "random line requests per second against what dependency-free random "
+                                                  "reads sustain on this chip (tools/gather_probe*.hip)"},
                          "note": "launch durations in the timed region, where sub-batch i+1's k_find runs beside "
-                                 "sub-batch i's filter/extract kernels" if launches > 1 else "kernels run back to back",
-                         "whole_path_achieved": bytes_read * n_local / (elapsed / args.steps) / 1e9},
+                                 "sub-batch i's filter/extract kernels" if launches > 1 else "kernels run back to back"},
+            "roofline_filter_extract": {"bound": "hbm", "kernel": "k_filter_extract_fast<32> + <64>", "achieved": ach_fx,
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_fx / HBM_PEAK_GBS, "traffic": fx_traffic,
+                                        "algorithmic_bytes_per_launch": bytes_fx / nsub_step, "avg_launch_ms": fx_ms,
+                                        "note": "latency-bound: a chain of dependent rank lookups per (read, side)"},
+            "whole_path": {"achieved": bytes_step / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": bytes_step / step_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": bytes_step},
         }
         if iso is not None:
             ims = float(iso[0])
             out["roofline"]["isolated"] = {
                 "what": "same kernels, sub-batching off (one launch per step, nothing beside it), 2 untimed steps",
                 "k_find_ms": ims, "achieved": bytes_find / (ims * 1e-3) / 1e9, "frac": bytes_find / (ims * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "request_rate_glines": lines_find / (ims * 1e-3) / 1e9,
                 "kernel_ms_per_step": {k: float(v) for k, v in zip(KERNELS, iso)}}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(prefix, reads, min(args.cpu_sample, n_total), args.min_overlap, st, lib, batch)
@@ -311,6 +396,99 @@ def cpu_baseline(prefix, reads, sample, min_overlap, st, lib, batch):
                       "OpenMP over reads" % sample,
             "seconds": sec, "single_thread_reads_per_s": max(sample // 20, 1) / sec1,
             "blocks_per_read": o["blocks"] / sample, "n_occ_min_per_read": o["n_occ_min"] / sample}
+
+
+def bench_correct(args):
+    """BASELINE configs[3]: the `siga correct` k-mer path (KmerCorrector::process, src/correct_processor.cpp:72-229) on
+    configs[1]-shaped reads with substitution errors, one GPU.  A step = k_correct over all reads, everything resident."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the correction path has no CPU fallback")
+    from siga_amd import _lib, host
+    from siga_amd import build as sbuild
+    from siga_amd.overlap import FMIndexPair
+    from tests.golden.make_reads import fast_reads, substitute
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    N, G, L, k = args.reads_per_gpu, args.genome_per_gpu, args.read_len, args.kmer
+    t0 = time.time()
+    clean, _ = fast_reads(G, L, N, args.seed)
+    reads = substitute(clean, args.error_rate, args.seed + 100)
+    workdir = args.workdir or os.path.join(tempfile.gettempdir(), "siga_bench_correct_%d_%d_%d_%d" % (N, G, L, args.seed))
+    os.makedirs(workdir, exist_ok=True)
+    prefix = os.path.join(workdir, "reads")
+    sbuild.build_all()
+    offs = np.arange(0, (N + 1) * L, L, dtype=np.uint64)
+    if not all(os.path.exists(prefix + e) for e in (".bwt", ".rbwt", ".sai", ".rsai")):
+        host.index_build_gpu(reads.reshape(-1), offs, prefix)
+    pair = FMIndexPair.load(prefix, device=0, with_sai=False)
+    log("reads + index ready in %.1f s" % (time.time() - t0))
+    lib = _lib.lib()
+    d_seqs = torch.from_numpy(reads.reshape(-1).copy()).to(dev)
+    d_offs = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_out = torch.empty_like(d_seqs)
+    d_valid = torch.empty(N + 16, dtype=torch.uint8, device=dev)
+    d_stat = torch.zeros(4, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        rc = lib.sigax_correct_device(pair.handle, d_seqs.data_ptr(), None, d_offs.data_ptr(), N, k, 3, 10, 1, d_out.data_ptr(),
+                                      d_valid.data_ptr(), d_stat.data_ptr(), C.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise SystemExit("sigax_correct_device: " + _lib.last_error())
+
+    steps, warm = args.steps, args.warmup
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_start = time.perf_counter()
+    e0.record(stream)
+    for _ in range(steps):
+        step()
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t_start
+    kernel_ms = e0.elapsed_time(e1) / steps  # memset + kernel on the stream the kernel is launched on
+    stat = d_stat.cpu().numpy()
+    valid = d_valid[:N].cpu().numpy()
+    fixed = d_out.cpu().numpy().reshape(N, L)
+    n_valid = int((valid == 1).sum())
+    restored = int(((fixed == clean).all(axis=1) & (valid == 1)).sum())
+    bytes_step = 64 * int(stat[1]) + 2 * N * L + N
+    out = {
+        "metric": "reads/sec corrected (siga correct k-mer path, output bit-exact)", "value": N * steps / elapsed, "unit": "reads/s",
+        "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "siga correct -k %d -x 3 -i 10 -O 1 on synthetic %dx%d bp reads from %d bp genome with %.2g "
+                               "substitutions per base; FM-index of those reads resident in HBM" % (k, N, L, G, args.error_rate),
+                   "reads_written": n_valid, "reads_equal_to_truth": restored, "kmer_lookups_per_read": int(stat[2]) / N,
+                   "sectors_per_read": int(stat[1]) / N, "algorithmic_bytes_per_read": bytes_step / N},
+        "roofline": {"bound": "hbm", "kernel": "k_correct", "achieved": bytes_step / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": bytes_step / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": bytes_step, "avg_launch_ms": kernel_ms,
+                     "request_rate": {"achieved": int(stat[1]) / (kernel_ms * 1e-3) / 1e9, "ceiling": GATHER_CEILING_GLINES,
+                                      "unit": "G lines/s", "frac": int(stat[1]) / (kernel_ms * 1e-3) / 1e9 / GATHER_CEILING_GLINES}},
+    }
+    if args.cpu_sample > 0:
+        from oracle import pyoracle as po
+        po.build()
+        sample = min(args.cpu_sample, N)
+        fa = os.path.join(workdir, "sample.fa")
+        with open(fa, "wb") as f:
+            f.write(b"".join(b">r%d\n%s\n" % (i, bytes(r)) for i, r in enumerate(reads[:sample])))
+        fwd = po.Index.load(prefix + ".bwt", "")
+        t1 = time.time()
+        st = po.correct(fwd, fa, os.path.join(workdir, "sample.out.fa"), k, 3, 10, 1)
+        sec = time.time() - t1
+        want = open(os.path.join(workdir, "sample.out.fa"), "rb").read()
+        got = b"".join(b">r%d\n%s\n" % (i, bytes(fixed[i])) for i in range(sample) if valid[i] == 1)
+        out["cpu_baseline"] = {"value": sample / sec, "unit": "reads/s", "cores": 1, "kind": "port",
+                               "sample": "first %d reads through the oracle's CorrectProcessor (file in, file out, one thread) "
+                                         "against the full index" % sample,
+                               "seconds": sec, "reads_written": st["written"], "gpu_output_identical": got == want}
+    pair.close()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

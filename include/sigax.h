@@ -69,6 +69,9 @@ typedef struct sigax_stats {
   uint64_t n_substring;        /* reads flagged substring (SS:i:1) */
   uint64_t n_slow_reads;       /* reads that needed the general (serial) filter/extract kernel */
   uint64_t n_extract_errors;   /* reads where extract() hit "substring read found" (src/overlap_builder.cpp:754-757) */
+  uint64_t n_sectors_find;     /* distinct 64-byte sectors of the rank tables the finder's formulation touches: per step one
+                                  or two granules (one-step) or both halves of one or two 128-byte lines (two-step table) */
+  uint64_t n_sectors_extract;  /* the same for sub-maximal filter + irreducible extraction, per round and block */
 } sigax_stats;
 
 typedef struct sigax_result {
@@ -138,6 +141,13 @@ int  sigax_kmer_count_batch(sigax_index*, const char* kmers, uint32_t k, uint64_
 int  sigax_correct_batch(sigax_index*, const char* seqs, const char* quals, const uint64_t* offs, uint32_t n_reads,
                          uint32_t kmer_size, int32_t kmer_threshold, uint32_t kmer_rounds, uint32_t count_offset,
                          char* out_seqs, uint8_t* valid);
+
+/* The same with every buffer in device memory, asynchronous on `stream` (a hipStream_t or NULL): d_offs u64[n_reads+1],
+ * d_quals may be NULL, d_stat4 = 4 u64 of device scratch that receive {reads longer than the kernel supports (their
+ * valid[] is 2), rank-table sectors asked for, k-mer lookups made, reserved}.  What a batching runtime and bench.py use. */
+int  sigax_correct_device(sigax_index*, const void* d_seqs, const void* d_quals, const void* d_offs, uint64_t n_reads,
+                          uint32_t kmer_size, int32_t kmer_threshold, uint32_t kmer_rounds, uint32_t count_offset,
+                          void* d_out_seqs, void* d_valid, void* d_stat4, void* stream);
 
 /* OverlapBuilder::overlap for a batch (host buffers in, host buffers out).  seqs = concatenated read bytes,
  * offs[n_reads+1]; read r of the batch is read `read_base + r` of the indexed set (only used for edges).

@@ -23,7 +23,7 @@ assert BLOCK_DTYPE.itemsize == 80 and EDGE_DTYPE.itemsize == 16
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "n_reads", "n_candidate_blocks", "n_blocks", "n_edges", "n_occ_find", "n_occ_extract", "n_substring",
-        "n_slow_reads", "n_extract_errors")]
+        "n_slow_reads", "n_extract_errors", "n_sectors_find", "n_sectors_extract")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -43,7 +43,7 @@ class IndexInfo(C.Structure):
 SYMBOLS = [
     "sigax_last_error", "sigax_device_count", "sigax_stream_create", "sigax_stream_destroy", "sigax_index_open", "sigax_index_open_mem", "sigax_index_close",
     "sigax_index_info_get", "sigax_index_set_reads", "sigax_occ_batch", "sigax_kmer_count_batch",
-    "sigax_correct_batch", "sigax_overlap_batch", "sigax_result_free", "sigax_batch_create", "sigax_batch_destroy", "sigax_batch_upload",
+    "sigax_correct_batch", "sigax_correct_device", "sigax_overlap_batch", "sigax_result_free", "sigax_batch_create", "sigax_batch_destroy", "sigax_batch_upload",
     "sigax_batch_set_device_reads", "sigax_batch_set_subbatches", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
     "sigax_batch_download", "sigax_batch_kernel_ms", "sigax_build_strand", "sigax_free",
 ]
@@ -77,6 +77,7 @@ def lib():
     L.sigax_occ_batch.argtypes = [vp, ci, vp, u64, vp]
     L.sigax_kmer_count_batch.argtypes = [vp, cp, u32, u64, vp]
     L.sigax_correct_batch.argtypes = [vp, cp, cp, vp, u32, u32, C.c_int32, u32, u32, vp, vp]
+    L.sigax_correct_device.argtypes = [vp, vp, vp, vp, u64, u32, C.c_int32, u32, u32, vp, vp, vp, vp]
     L.sigax_overlap_batch.argtypes = [vp, cp, vp, u32, u32, u32, u32, C.POINTER(Result)]
     L.sigax_result_free.argtypes = [C.POINTER(Result)]
     L.sigax_result_free.restype = None

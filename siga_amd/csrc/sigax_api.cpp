@@ -406,6 +406,42 @@ extern "C" int sigax_kmer_count_batch(sigax_index* ix, const char* kmers, uint32
   return SIGAX_OK;
 }
 
+static CorrectArgs correct_args(sigax_index* ix, const unsigned char* d_seqs, const unsigned char* d_quals, const u64* d_offs, u64 n_reads,
+                                uint32_t kmer_size, int32_t kmer_threshold, uint32_t kmer_rounds, uint32_t count_offset,
+                                unsigned char* d_out, unsigned char* d_valid, u64* d_stat) {
+  CorrectArgs ca;
+  ca.fwd = ix->st[0];
+  ca.seqs = d_seqs;
+  ca.quals = d_quals;
+  ca.offs = d_offs;
+  ca.n_reads = n_reads;
+  ca.k = kmer_size;
+  ca.low = (uint32_t)std::max(kmer_threshold, 0);       // CorrectThreshold::minSupport (src/correct_processor.cpp:28-31)
+  ca.high = (uint32_t)std::max(kmer_threshold + 1, 0);
+  ca.cutoff = 20;
+  ca.rounds = kmer_rounds;
+  ca.offset = count_offset;
+  ca.out = d_out;
+  ca.valid = d_valid;
+  ca.dstat = d_stat;
+  return ca;
+}
+
+extern "C" int sigax_correct_device(sigax_index* ix, const void* d_seqs, const void* d_quals, const void* d_offs, uint64_t n_reads,
+                                    uint32_t kmer_size, int32_t kmer_threshold, uint32_t kmer_rounds, uint32_t count_offset,
+                                    void* d_out_seqs, void* d_valid, void* d_stat4, void* stream) {
+  if (!ix || kmer_size == 0 || (n_reads && (!d_seqs || !d_offs || !d_out_seqs || !d_valid || !d_stat4))) return fail(SIGAX_E_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(ix->device));
+  if (n_reads == 0) return SIGAX_OK;
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(d_stat4, 0, 32, st));
+  CorrectArgs ca = correct_args(ix, (const unsigned char*)d_seqs, (const unsigned char*)d_quals, (const u64*)d_offs, n_reads, kmer_size,
+                                kmer_threshold, kmer_rounds, count_offset, (unsigned char*)d_out_seqs, (unsigned char*)d_valid, (u64*)d_stat4);
+  launch_correct(ca, ix->wide, st);
+  HIP_TRY(hipGetLastError());
+  return SIGAX_OK;
+}
+
 extern "C" int sigax_correct_batch(sigax_index* ix, const char* seqs, const char* quals, const uint64_t* offs, uint32_t n_reads,
                                    uint32_t kmer_size, int32_t kmer_threshold, uint32_t kmer_rounds, uint32_t count_offset,
                                    char* out_seqs, uint8_t* valid) {
@@ -428,21 +464,8 @@ extern "C" int sigax_correct_batch(sigax_index* ix, const char* seqs, const char
     HIP_TRY(g.alloc((void**)&d_quals, nb + 16));
     HIP_TRY(hipMemcpy(d_quals, quals, nb, hipMemcpyHostToDevice));
   }
-  CorrectArgs ca;
-  ca.fwd = ix->st[0];
-  ca.seqs = d_seqs;
-  ca.quals = d_quals;
-  ca.offs = d_offs;
-  ca.n_reads = n_reads;
-  ca.k = kmer_size;
-  ca.low = (uint32_t)std::max(kmer_threshold, 0);       // CorrectThreshold::minSupport (src/correct_processor.cpp:28-31)
-  ca.high = (uint32_t)std::max(kmer_threshold + 1, 0);
-  ca.cutoff = 20;
-  ca.rounds = kmer_rounds;
-  ca.offset = count_offset;
-  ca.out = d_out;
-  ca.valid = d_valid;
-  ca.dstat = d_stat;
+  CorrectArgs ca = correct_args(ix, d_seqs, d_quals, d_offs, n_reads, kmer_size, kmer_threshold, kmer_rounds, count_offset, d_out,
+                                d_valid, d_stat);
   launch_correct(ca, ix->wide, 0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
@@ -887,6 +910,8 @@ extern "C" int sigax_batch_finish(sigax_batch* b, void* stream, sigax_stats* sta
     b->last.n_slow_reads = 0;
     for (int i = 0; i < SIGAX_MAX_SUB; ++i) b->last.n_slow_reads += ds[DS_SLOW_BASE + i];
     b->last.n_extract_errors = ds[DS_EXTRACT_ERRORS];
+    b->last.n_sectors_find = ds[DS_SEC_FIND];
+    b->last.n_sectors_extract = ds[DS_SEC_EXTRACT];
     b->last_total_blocks = ds[DS_TOTAL_BLOCKS];
     b->last_total_edges = b->last.n_edges;
     b->finished = true;

@@ -25,6 +25,8 @@ enum {
   DS_TOTAL_EDGES,  // written by the edge scan
   DS_SLOW_BASE,    // [DS_SLOW_BASE + i]: reads sub-batch i queued for the general kernel (i < SIGAX_MAX_SUB)
   DS_W64_BASE = DS_SLOW_BASE + 8,  // [DS_W64_BASE + i]: (read, side) items sub-batch i queued for the 64-lane launch
+  DS_SEC_FIND = DS_W64_BASE + 8,   // distinct 64-byte sectors of the rank tables the finder asked for, step by step
+  DS_SEC_EXTRACT,                  // ... filter/extract, round by round
   DS_COUNT = 48
 };
 #define SIGAX_MAX_SUB 8
@@ -112,7 +114,7 @@ struct CorrectArgs {
   uint32_t k, low, high, cutoff, rounds, offset;  // CorrectThreshold: required support low / high (phred >= cutoff)
   unsigned char* out;    // corrected sequences, same layout as seqs
   unsigned char* valid;  // CorrectResult::validQC; 2 = read longer than the kernel supports
-  unsigned long long* dstat;  // [0] reads too long
+  unsigned long long* dstat;  // [0] reads too long, [1] rank-table sectors asked for, [2] k-mer lookups (4 x u64)
 };
 void launch_correct(const CorrectArgs& a, bool wide, hipStream_t st);
 

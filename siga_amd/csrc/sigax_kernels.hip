@@ -512,6 +512,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
   const u32 read = A.read_begin + blockIdx.x * (256u / A.chains_per_wg) + (A.chains_per_wg == 4u ? 0u : (wv >> 1) * 64u) + (tid & 63u);
   typedef typename PosOf<WIDE>::type P;
   u32 nocc = 0;
+  u32 nsec = 0;  // wave total (scalar): distinct 64-byte sectors of the rank tables asked for (a two-step line is two)
   u32 nb = 0, flagbits = 0;
   bool live = read < A.read_end && ((A.chain_mask >> o) & 1u);  // overlap: 0xF, or 0x5 without the opposite strand; duplicate: 0x9
   u64 b0 = 0;
@@ -592,13 +593,14 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
       }
       const bool ok2 = want2 && c != 0 && e != 0;
       if (__ballot(on && !ok2) == 0) {
-        bool fl1 = false, fl2 = false;
+        bool fl1 = false, fl2 = false, two_lines = false;
         P lo1n = 0, lo0n = 0, szn = 0, ldn = 0, dd2 = 0, nlo1 = 0, nlo0 = 0, nsz = 0;
         if (on) {
           const u32 nn = (u32)PI.n;  // never leave the table, whatever an invalid interval holds
           const u32 pl = (u32)lo0 > nn ? nn : (u32)lo0, pu = (u32)(lo0 + sz) > nn ? nn : (u32)(lo0 + sz);
           Gran2 ga, gb;
           const u32 oa = (pl >> 6) * 128u, ob = (pu >> 6) * 128u;
+          two_lines = oa != ob;
           find_step2_loads(PI2, oa, oa + 16u * c, ob, ob + 16u * c, ga, gb);
           const Rank2 l = rank2_from(ga, pl & 63u, c), u = rank2_from(gb, pu & 63u, c);
           const u32 da = u.a - l.a, dc = u.c - l.c, dg = u.g - l.g, dt = u.t - l.t;
@@ -624,6 +626,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
           nlo0 = (P)CP[e] + (P)(t2.Cc[PI.which][c - 1][e - 1] + l2e);
           nsz = (P)d2e;
         }
+        nsec += 2u * (u32)(__popcll(__ballot(on)) + __popcll(__ballot(two_lines)));
         find_flush(sg, fl1, tid);
         if (on) {
           if (s + 1 >= A.minov && dd2 > 0) fl2 = emit(ldn, dd2, lo1n, lo0n, szn, s + 1);
@@ -634,13 +637,14 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
         continue;
       }
     }
-    bool flush = false;
+    bool flush = false, two_gran = false;
     if (on) {
       const u64 pl = (u64)lo0 > PI.n ? PI.n : (u64)lo0;  // never leave the table, whatever an invalid interval holds
       const u64 pu0 = (u64)(P)(lo0 + sz);
       const u64 pu = pu0 > PI.n ? PI.n : pu0;
       Gran gl, gu;
       u32 ch;
+      two_gran = (pl >> 7) != (pu >> 7);
       if (STAGED) {
         ch = rd[rdo + (fromStart ? s : L - 1 - s)];
         if (WIDE) find_step_loads8(PI.g + (pl >> 7) * 4, PI.g + (pu >> 7) * 4, gl, gu);
@@ -668,6 +672,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
       sz = dcur;
       ++s;
     }
+    nsec += (u32)(__popcll(__ballot(on)) + __popcll(__ballot(two_gran)));
     find_flush(sg, flush, tid);
   }
   // a single record left in the row (u32 positions, odd count): 32 bytes = two pieces
@@ -677,6 +682,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
     find_flush(sg, tail, tid);
   }
   bool contain = false;
+  u32 tail_sec = 0;
   nocc = live ? 2u * (s - 1u) : 0u;  // two rank positions per step taken
   if (live && sz != 0 && s >= L) {
     // full-length interval: substring test and containment block (overlap_builder.cpp:889-904)
@@ -686,6 +692,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
     const u64 ql = clampn((u64)lo1, OI.n), qu = clampn((u64)(P)(lo1 + sz), OI.n);
     Gran ga, gb;
     u32 ignored;
+    tail_sec = ((pl >> 7) != (pu >> 7) ? 2u : 1u) + ((ql >> 7) != (qu >> 7) ? 2u : 1u);
     find_step_loads(PI.g + (pl >> 7) * 4, PI.g + (pu >> 7) * 4, sq, ga, gb, ignored);
     const Cnt4P<P> l = fm_rank4p_from<WIDE>(PI, pl, ga);
     const Cnt4P<P> u = fm_rank4p_from<WIDE>(PI, pu, gb);
@@ -716,7 +723,9 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
   u64 tot_occ = wave_sum((u64)nocc);
   u64 tot_blk = wave_sum((u64)nb + ((flagbits & SIGAX_CC_CONTAIN) ? 1u : 0u));
   u64 tot_err = wave_sum((u64)(flagbits & 1u));
+  u64 tot_sec = (u64)nsec + wave_sum((u64)tail_sec);
   if ((threadIdx.x & 63) == 0) {
+    if (tot_sec) atomicAdd(&A.dstat[DS_SEC_FIND], tot_sec);
     if (tot_occ) atomicAdd(&A.dstat[DS_OCC_FIND], tot_occ);
     if (tot_blk) atomicAdd(&A.dstat[DS_CAND_BLOCKS], tot_blk);
     if (tot_err) atomicAdd(&A.dstat[DS_FIND_OVERFLOW], tot_err);
@@ -1214,6 +1223,7 @@ __global__ __launch_bounds__(256) void k_filter_extract(FxArgs A) {
   nocc_back = wave_sum(nocc_back); nerr_back = wave_sum(nerr_back); nsub_back = wave_sum(nsub_back);
   if ((threadIdx.x & 63) == 0) {
     if (nocc != nocc_back) atomicAdd(&A.dstat[DS_OCC_EXTRACT], nocc - nocc_back);  // wraps correctly when negative
+    if (nocc) atomicAdd(&A.dstat[DS_SEC_EXTRACT], nocc);  // one granule per evaluation here (a fraction of a per cent of the reads)
     if (nerr != nerr_back) atomicAdd(&A.dstat[DS_EXTRACT_ERRORS], nerr - nerr_back);
     if (nover) atomicAdd(&A.dstat[DS_POOL_OVERFLOW], nover);
     if (nsub != nsub_back) atomicAdd(&A.dstat[DS_SUBSTRING], nsub - nsub_back);
@@ -1256,6 +1266,7 @@ struct SideSh {
   u32 osrc[FX_OUTCAP];
   u64 alive[FX_NSLOT];
   unsigned char D[FX_NSLOT], I[FX_NSLOT];
+  u32 nsec;  // over the whole launch: distinct 64-byte sectors of the rank tables this wave's lane groups asked for
 };
 
 __device__ __forceinline__ u64 readlane64(u64 v, u32 l) {
@@ -1371,6 +1382,10 @@ struct GFx {
     sh.o0[gb + i] = e.c0lo; sh.o1[gb + i] = e.c0hi; sh.o2[gb + i] = e.c1lo; sh.o3[gb + i] = e.c1hi; sh.osrc[gb + i] = e.src;
   }
 
+  __device__ void sec_add(u32 v) {  // v is the same in all lanes of the group
+    if (gl == 0) atomicAdd(&sh.nsec, v);
+  }
+
   static __device__ P sel5(const P v[5], u32 k) { return k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : k == 3 ? v[3] : v[4]; }
 
   // IntervalPair::updateR(b, index) (overlap_builder.cpp:101-106,123-133) from the two rank vectors in registers
@@ -1413,6 +1428,7 @@ struct GFx {
       fm_rank5p<WIDE>(ix, e.c1lo, l);
       fm_rank5p<WIDE>(ix, (P)(e.c1hi + 1), u);
     }
+    sec_add(pop(alive) + pop(gballot(mine && ((u64)e.c1lo >> 7) != (((u64)e.c1hi + 1ull) >> 7))));
     // OverlapBlock::ext (overlap_builder.cpp:181-187), complemented for QUERYCOMP blocks
     const bool x0 = mine && (u[0] != l[0]);
     const bool xa = mine && (qcomp ? (u[4] != l[4]) : (u[1] != l[1]));
@@ -1496,6 +1512,7 @@ struct GFx {
           a4 = *reinterpret_cast<const uint4*>(gq);  // A, C, G, T before the granule
           a5 = pq[0]; a6 = pq[1]; a7 = pq[2];
         }
+        sec_add(2u * pop(alive));
         const u32 r0 = q0 & 63u, r1 = r0 + (q1 - q0);  // 0 <= r0 < r1 <= 64
         const u32 lo0 = r0 < 32u ? r0 : 32u, hi0 = r1 < 32u ? r1 : 32u;           // the range inside the low word
         const u32 lo1 = r0 > 32u ? r0 - 32u : 0u, hi1 = r1 > 32u ? r1 - 32u : 0u;  // ... inside the high word
@@ -1586,6 +1603,7 @@ struct GFx {
       const uint4* q = ix.g + g0 * 4;
       k[0] = q[0]; k[1] = q[1]; k[2] = q[2]; k[3] = q[3];
     }
+    sec_add(pop(alive));
     const int r0 = (int)(p0 & 127u), r1 = (int)(p1 - (g0 << 7));  // 0 <= r0 < r1 <= 128
     const u32 first = ffs0(alive);
     // Cheapest form, and the usual one between two read ends: every alive block's range holds ONE symbol, the same
@@ -1970,6 +1988,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 1 : 
   fm_tables_load(tb, A.fwd, A.rev);
   const u32 wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const u64 wave = (u64)blockIdx.x * 4 + wid, nwaves = (u64)gridDim.x * 4;
+  if (lane == 0) shm[wid].nsec = 0;
+  wave_lds_sync();
   GFx<WIDE, W> fx(A, tb, shm[wid], A.wpool + wave * FX_WPOOL, have2 ? &t2 : nullptr);
   u64 nocc_total = 0, nerr = 0, nsub = 0;
   if (W == 32) {
@@ -2000,7 +2020,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 1 : 
     }
   }
   nocc_total = wave_sum(nocc_total); nerr = wave_sum(nerr); nsub = wave_sum(nsub);
+  wave_lds_sync();
   if (lane == 0) {
+    if (shm[wid].nsec) atomicAdd(&A.dstat[DS_SEC_EXTRACT], (u64)shm[wid].nsec);
     if (nocc_total) atomicAdd(&A.dstat[DS_OCC_EXTRACT], nocc_total);
     if (nerr) atomicAdd(&A.dstat[DS_EXTRACT_ERRORS], nerr);
     if (nsub) atomicAdd(&A.dstat[DS_SUBSTRING], nsub);
@@ -2029,7 +2051,7 @@ struct CorrectSh {
 // Interval::occurrences of the k-mer starting at `s` in sh.seq, with base `ovpos` replaced by rank `ovrank`
 template <bool WIDE>
 __device__ __forceinline__ u32 kmer_occ(const FmRef& f, const FmTables& tb, const unsigned char* seq, u32 s, u32 k, u32 ovpos,
-                                        u32 ovrank) {
+                                        u32 ovrank, u32& nsec) {
   typedef typename PosOf<WIDE>::type P;
   u32 j = k;
   u32 r = (s + j - 1 == ovpos) ? ovrank : base_rank(seq[s + j - 1]);
@@ -2039,6 +2061,7 @@ __device__ __forceinline__ u32 kmer_occ(const FmRef& f, const FmTables& tb, cons
     P l[5], u[5];
     fm_rank5p<WIDE>(f, lo, l);            // getOcc(c, lower - 1)
     fm_rank5p<WIDE>(f, (P)(hi + 1), u);   // getOcc(c, upper)
+    nsec += ((u64)lo >> 7) != (((u64)hi + 1ull) >> 7) ? 2u : 1u;
     P lr = r == 0 ? l[0] : r == 1 ? l[1] : r == 2 ? l[2] : r == 3 ? l[3] : l[4];
     P ur = r == 0 ? u[0] : r == 1 ? u[1] : r == 2 ? u[2] : r == 3 ? u[3] : u[4];
     P pb = (P)tb.C[f.which][r];
@@ -2061,6 +2084,7 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs A) {
   const FmRef F = fm_ref(A.fwd, 0);
   const u64 wave = (u64)blockIdx.x * 4 + wid, nwaves = (u64)gridDim.x * 4;
   const u32 k = A.k;
+  u32 nsec = 0, nlook = 0;  // per lane: distinct 64-byte sectors asked for, k-mer lookups made
   for (u64 rd = wave; rd < A.n_reads; rd += nwaves) {
     const u64 b0 = A.offs[rd];
     const u32 n = uni((u32)(A.offs[rd + 1] - b0));
@@ -2094,7 +2118,8 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs A) {
           bool good = false;
           if (s < nw) {
             if (sh.redo[s]) {
-              sh.cnt[s] = kmer_occ<WIDE>(F, tb, sh.seq, s, k, 0xFFFFFFFFu, 0u);
+              sh.cnt[s] = kmer_occ<WIDE>(F, tb, sh.seq, s, k, 0xFFFFFFFFu, 0u, nsec);
+              ++nlook;
               sh.redo[s] = 0;
             }
             good = sh.cnt[s] >= (sh.minph[s] >= A.cutoff ? A.high : A.low);  // CorrectThreshold::requiredSupport
@@ -2145,7 +2170,8 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs A) {
                 const u32 kidx = side ? (pos < n - k ? pos : n - k) : (pos + 1 >= k ? pos + 1 - k : 0u);
                 const u32 thr = sh.score[pos] >= A.cutoff ? A.high : A.low;
                 const u32 minCount = A.offset > thr ? A.offset : thr;  // max(countVector[..] (always 0) + offset, threshold)
-                cand = kmer_occ<WIDE>(F, tb, sh.seq, kidx, k, pos, brank) >= minCount;
+                cand = kmer_occ<WIDE>(F, tb, sh.seq, kidx, k, pos, brank, nsec) >= minCount;
+                ++nlook;
               }
             }
             // try2Correct succeeds iff exactly one alternative base reaches minCount (:207-223)
@@ -2174,6 +2200,11 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs A) {
     }
     if (lane == 0) A.valid[rd] = (unsigned char)valid;
     wave_lds_sync();
+  }
+  const u64 tsec = wave_sum((u64)nsec), tlook = wave_sum((u64)nlook);
+  if (lane == 0) {
+    if (tsec) atomicAdd(&A.dstat[1], tsec);
+    if (tlook) atomicAdd(&A.dstat[2], tlook);
   }
 }
 

@@ -100,3 +100,31 @@ def fast_reads(G, L, N, seed):
     codes[strand] = (3 - codes[strand])[:, ::-1]
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
     return lut[codes], genome
+
+
+def rank_of_r_names(n):
+    """rank of the name "r<i>" under std::string operator< for i in [0, n): decimal strings compare like their digits
+    left-aligned, a proper prefix first (sorting 2e7 Python strings would take a minute)."""
+    i = np.arange(n, dtype=np.int64)
+    ndig = np.ones(n, dtype=np.int64)
+    p = 10
+    while p <= n:
+        ndig += i >= p
+        p *= 10
+    D = int(ndig.max()) if n else 1
+    key = i * (10 ** (D - ndig))
+    order = np.lexsort((ndig, key))
+    rank = np.empty(n, dtype=np.uint32)
+    rank[order] = np.arange(n, dtype=np.uint32)
+    return rank
+
+
+def substitute(reads, rate, seed):
+    """ASCII read array [N, L] -> copy with each base replaced by a different one with probability `rate`."""
+    rng = np.random.default_rng(seed)
+    code = np.zeros(256, dtype=np.uint8)
+    code[np.frombuffer(b"ACGT", dtype=np.uint8)] = np.arange(4, dtype=np.uint8)
+    c = code[reads]
+    hit = rng.random(reads.shape) < rate
+    c = np.where(hit, (c + rng.integers(1, 4, size=reads.shape, dtype=np.uint8)) & 3, c)
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[c]

@@ -28,7 +28,7 @@ def test_header_symbols_all_exported():
 
 def test_struct_sizes_match_header():
     assert _lib.BLOCK_DTYPE.itemsize == 80 and _lib.EDGE_DTYPE.itemsize == 16
-    assert C.sizeof(_lib.Stats) == 9 * 8
+    assert C.sizeof(_lib.Stats) == 11 * 8
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -25,20 +25,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _name_ranks(n):
-    """rank of "r<i>" under std::string operator<: decimal strings compare like their digits left-aligned, a proper
-    prefix first (sorting 2e7 Python strings would take a minute)"""
-    i = np.arange(n, dtype=np.int64)
-    ndig = np.ones(n, dtype=np.int64)
-    p = 10
-    while p <= n:
-        ndig += i >= p
-        p *= 10
-    D = int(ndig.max()) if n else 1
-    key = i * (10 ** (D - ndig))
-    order = np.lexsort((ndig, key))
-    rank = np.empty(n, dtype=np.uint32)
-    rank[order] = np.arange(n, dtype=np.uint32)
-    return rank
+    from tests.golden.make_reads import rank_of_r_names
+    return rank_of_r_names(n)
 
 
 def test_c1_ecoli_shape_cli_index_overlap_m85(tmp_path):

@@ -1,35 +1,47 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun -- bash tools/run_profiles.sh [kt|pmc|all]): rocprofv3 kernel-trace summaries and PMC
-# passes of bench.py, left under gpurun_out/ for tools/collect_profiles.py.  Counters are collected in their own
-# passes (one TCC counter group per pass: FETCH_SIZE and WRITE_SIZE do not fit one pass together).
+# Runs on the GPU box (gpurun -- bash tools/run_profiles.sh [kt|pmc|calib|correct|all]): rocprofv3 kernel-trace summaries
+# and PMC passes of bench.py, left under gpurun_out/prof/ for tools/collect_profiles.py.  Counters are collected in their
+# own passes with --kernel-trace only (one TCC counter group per pass).
 what=${1:-all}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-B="python3 bench.py --cpu-sample 0 --steps 8 --warmup 2"
+O=gpurun_out/prof; mkdir -p $O
+B="python3 bench.py --cpu-sample 0 --steps 20 --warmup 3"
 P="python3 bench.py --cpu-sample 0 --steps 3 --warmup 1"
 ISO="--subbatches 1 --depth 1"
+RD="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum"
+WR="TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
+HM="TCC_HIT_sum TCC_MISS_sum"
 run() { # name, rocprof args..., -- cmd
   name=$1; shift
-  timeout -k 10 200 rocprofv3 "$@" > gpurun_out/$name.json 2> gpurun_out/$name.err
+  timeout -k 10 240 rocprofv3 "$@" > $O/$name.json 2> $O/$name.err
   rc=$?
-  echo "$name rc=$rc" >> gpurun_out/profiles.log
+  echo "$name rc=$rc" >> $O/profiles.log
   return $rc
 }
-rm -f gpurun_out/profiles.log
+rm -f $O/profiles.log
 if [ "$what" = kt ] || [ "$what" = all ]; then
-  run q_kt   --kernel-trace --stats -d gpurun_out/q_kt   --output-format csv -- $B &&
-  run q_kt1  --kernel-trace --stats -d gpurun_out/q_kt1  --output-format csv -- $B $ISO || exit 1
+  run q_kt   --kernel-trace --stats -d $O/q_kt   --output-format csv -- $B &&
+  run q_kt1  --kernel-trace --stats -d $O/q_kt1  --output-format csv -- $B $ISO || exit 1
 fi
 if [ "$what" = pmc ] || [ "$what" = all ]; then
-  run q_fetch  --kernel-trace --pmc FETCH_SIZE -d gpurun_out/q_fetch  --output-format csv -- $P &&
-  run q_write  --kernel-trace --pmc WRITE_SIZE -d gpurun_out/q_write  --output-format csv -- $P &&
-  run q_tcc    --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d gpurun_out/q_tcc --output-format csv -- $P &&
-  run q_fetch1 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/q_fetch1 --output-format csv -- $P $ISO &&
-  run q_write1 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/q_write1 --output-format csv -- $P $ISO &&
-  run q_tcc1   --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d gpurun_out/q_tcc1 --output-format csv -- $P $ISO || exit 1
+  run q_rd   --kernel-trace --pmc $RD -d $O/q_rd   --output-format csv -- $P &&
+  run q_wr   --kernel-trace --pmc $WR -d $O/q_wr   --output-format csv -- $P &&
+  run q_hm   --kernel-trace --pmc $HM -d $O/q_hm   --output-format csv -- $P &&
+  run q_fetch --kernel-trace --pmc FETCH_SIZE -d $O/q_fetch --output-format csv -- $P &&
+  run q_rd1  --kernel-trace --pmc $RD -d $O/q_rd1  --output-format csv -- $P $ISO &&
+  run q_wr1  --kernel-trace --pmc $WR -d $O/q_wr1  --output-format csv -- $P $ISO &&
+  run q_hm1  --kernel-trace --pmc $HM -d $O/q_hm1  --output-format csv -- $P $ISO || exit 1
 fi
-if [ "$what" = all ] || [ "$what" = bench ]; then
-  python3 bench.py --isolated > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err
-  echo "bench_full rc=$?" >> gpurun_out/profiles.log
+if [ "$what" = calib ] || [ "$what" = all ]; then
+  run c_rd    --kernel-trace --pmc $RD -d $O/c_rd --output-format csv -- build/fetch_calib &&
+  run c_fetch --kernel-trace --pmc FETCH_SIZE -d $O/c_fetch --output-format csv -- build/fetch_calib &&
+  run c_hm    --kernel-trace --pmc $HM -d $O/c_hm --output-format csv -- build/fetch_calib || exit 1
 fi
-cat gpurun_out/profiles.log
+if [ "$what" = correct ] || [ "$what" = all ]; then
+  C="python3 bench.py --workload correct --cpu-sample 0 --steps 5 --warmup 1"
+  run k_kt --kernel-trace --stats -d $O/k_kt --output-format csv -- $C &&
+  run k_rd --kernel-trace --pmc $RD -d $O/k_rd --output-format csv -- $C &&
+  run k_hm --kernel-trace --pmc $HM -d $O/k_hm --output-format csv -- $C || exit 1
+fi
+cat $O/profiles.log
