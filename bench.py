@@ -278,9 +278,9 @@ def bench_overlap(args):
     kavg = ksum / max(args.steps, 1)  # per step, summed over the step's sub-batch launches
     st = stats.as_dict()
     launches = int(nsub.value)
-    # finder launches per sub-batch: two (one per strand's table) when the two-step finder runs, see sigax_api.cpp
-    split = (info["n_symbols"] < (1 << 30) + (1 << 29)) and not info["wide"] and os.environ.get("SIGAX_TWO_STEP", "1") != "0" \
-        and 128 * L + 8 <= 41568
+    # finder launches per sub-batch: two (one per strand's table) with the two-step tables and for big one-step indexes
+    two_step_on = (info["n_symbols"] < (1 << 30) + (1 << 29)) and not info["wide"] and os.environ.get("SIGAX_TWO_STEP", "1") != "0"
+    split = (two_step_on or info["n_symbols"] >= (1 << 30)) and 128 * L + 8 <= 41568
     nsub_step = max(1, launches // (2 if split else 1))
 
     # the same kernels with sub-batching off (no overlap between find and filter/extract): untimed extra steps
@@ -398,6 +398,14 @@ def cpu_baseline(prefix, reads, sample, min_overlap, st, lib, batch):
             "blocks_per_read": o["blocks"] / sample, "n_occ_min_per_read": o["n_occ_min"] / sample}
 
 
+def correct_traffic(N, G, L, k):
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return tj.get("k_correct/%d/%d/%d/%d" % (N, G, L, k), {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def bench_correct(args):
     """BASELINE configs[3]: the `siga correct` k-mer path (KmerCorrector::process, src/correct_processor.cpp:72-229) on
     configs[1]-shaped reads with substitution errors, one GPU.  A step = k_correct over all reads, everything resident."""
@@ -465,15 +473,15 @@ def bench_correct(args):
                    "reads_written": n_valid, "reads_equal_to_truth": restored, "kmer_lookups_per_read": int(stat[2]) / N,
                    "sectors_per_read": int(stat[1]) / N, "algorithmic_bytes_per_read": bytes_step / N},
         "roofline": {"bound": "hbm", "kernel": "k_correct", "achieved": bytes_step / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": bytes_step / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": bytes_step / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": correct_traffic(N, G, L, k),
                      "algorithmic_bytes_per_launch": bytes_step, "avg_launch_ms": kernel_ms,
-                     "request_rate": {"achieved": int(stat[1]) / (kernel_ms * 1e-3) / 1e9, "ceiling": GATHER_CEILING_GLINES,
-                                      "unit": "G lines/s", "frac": int(stat[1]) / (kernel_ms * 1e-3) / 1e9 / GATHER_CEILING_GLINES}},
+                     "note": "the forward index (75 MB) stays in the Infinity Cache and the first steps of every k-mer lookup in "
+                             "L2: `achieved` is algorithmic bytes over time, `traffic` what reached the memory side"},
     }
     if args.cpu_sample > 0:
         from oracle import pyoracle as po
         po.build()
-        sample = min(args.cpu_sample, N)
+        sample = min(args.cpu_sample, N, 50000)  # one thread, about 2.5 k reads/s: 20 s
         fa = os.path.join(workdir, "sample.fa")
         with open(fa, "wb") as f:
             f.write(b"".join(b">r%d\n%s\n" % (i, bytes(r)) for i, r in enumerate(reads[:sample])))

@@ -109,6 +109,9 @@ int  sigax_index_open(const char* bwt_path, const char* rbwt_path, const char* s
 int  sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const uint8_t* rruns, uint64_t n_rruns,
                           uint64_t n_symbols, uint64_t n_strings, const uint32_t* sai, const uint32_t* rsai,
                           int device, sigax_index** out);
+/* A replica of an open index (tables, .sai rows, read metadata set so far) on another GPU of the node, copied device to
+ * device -- over xGMI between peers -- instead of being read, decoded and uploaded again. */
+int  sigax_index_clone(const sigax_index* src, int device, sigax_index** out);
 void sigax_index_close(sigax_index*);
 int  sigax_index_info_get(const sigax_index*, sigax_index_info* out);
 /* Per-read metadata Hit2OverlapConverter keeps (ReadInfo{name,length}, src/overlap_builder.cpp:333-343).
@@ -179,6 +182,13 @@ int  sigax_batch_finish(sigax_batch*, void* stream, sigax_stats* stats);
 int  sigax_batch_device_outputs(sigax_batch*, const sigax_block** d_blocks, const uint64_t** d_block_offs,
                                 const uint8_t** d_substring, const sigax_edge** d_edges);
 int  sigax_batch_download(sigax_batch*, sigax_result* out);
+/* Only what the ASQG writer needs (OverlapPostProcess + Hit2OverlapConverter, src/overlap_builder.cpp:291-375): the
+ * substring flags (n_reads bytes, caller's buffer, may be NULL) and the edge records (malloc'd; release with sigax_free). */
+int  sigax_batch_download_edges(sigax_batch*, uint8_t* substring, sigax_edge** edges, uint64_t* n_edges);
+/* Reads of up to max_read_len bases one batch object can take when `in_flight` batch objects share the device's free
+ * memory now (the reference's threads x batch-size is a host notion; the device batch is sized from HBM). */
+int  sigax_batch_size_hint(sigax_index*, uint32_t max_read_len, uint32_t min_overlap, uint32_t flags, uint32_t in_flight,
+                           uint32_t* max_reads);
 /* Device time of the kernels of the last finished run, measured with HIP events on the streams they were launched on,
  * summed over the run's sub-batch launches: ms[0] find, ms[1] filter/extract (32- and 64-lane launches),
  * ms[2] filter/extract (general), ms[3] order, ms[4] edges.  *n_sub = finder launches of the run (sub-batches, times

@@ -132,6 +132,51 @@ int orc_build_asqg(void* hf, void* hr, const char* reads_path, uint64_t min_over
   return 0;
 }
 
+// Whole `siga overlap` at -t N as the reference runs it (overlap_builder.cpp:439-483): overlap() of all reads under OpenMP
+// (parallel_framework.h:38), then the serial post-processing in input order: VT lines, hit conversion, ED lines.  Plain
+// text out (the reference's gzip filter is left out).  secs3 = {read + parse, overlap (parallel), VT + ED text}; the ED
+// order equals the -t 1 order here because hits are converted per read in input order.
+int orc_build_asqg_mt(void* hf, void* hr, const char* reads_path, uint64_t min_overlap, int irreducible, int rc,
+                      const char* asqg_path, int threads, double* secs3) {
+  OrcIndex* f = (OrcIndex*)hf;
+  OrcIndex* r = (OrcIndex*)hr;
+  auto t0 = std::chrono::steady_clock::now();
+  std::ifstream in(reads_path);
+  if (!in) return -1;
+  std::vector<DNASeq> reads;
+  if (!readSequences(in, &reads)) return -2;
+  auto t1 = std::chrono::steady_clock::now();
+  std::vector<OverlapBlockList> all(reads.size());
+  std::vector<uint8_t> sub(reads.size(), 0);
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic, 64)
+#endif
+  for (int64_t i = 0; i < (int64_t)reads.size(); ++i) {
+    OverlapBuilder builder(&f->b.fm, &r->b.fm, irreducible != 0, rc != 0, nullptr);
+    sub[i] = builder.overlap(reads[i].seq, min_overlap, &all[i]).substring ? 1 : 0;
+  }
+  auto t2 = std::chrono::steady_clock::now();
+  std::ofstream asqg(asqg_path);
+  if (!asqg) return -3;
+  asqg << "HT\tVN:i:1\tOL:i:" << (int)min_overlap << "\tCN:i:1\n";
+  std::vector<ReadInfo> info(reads.size());
+  for (size_t i = 0; i < reads.size(); ++i) {
+    writeVertex(asqg, reads[i], sub[i] != 0);
+    info[i].name = reads[i].name;
+    info[i].length = reads[i].seq.length();
+  }
+  for (size_t i = 0; i < reads.size(); ++i) convertHit(i, all[i], info, f->b.sai, r->b.sai, &asqg);
+  asqg.close();
+  auto t3 = std::chrono::steady_clock::now();
+  if (secs3) {
+    secs3[0] = std::chrono::duration<double>(t1 - t0).count();
+    secs3[1] = std::chrono::duration<double>(t2 - t1).count();
+    secs3[2] = std::chrono::duration<double>(t3 - t2).count();
+  }
+  return 0;
+}
+
 // `siga rmdup` at -t 1 (overlap_builder.cpp:562-704)
 int orc_rmdup(void* hf, void* hr, const char* reads_path, const char* fasta_path, const char* dups_path) {
   OrcIndex* f = (OrcIndex*)hf;

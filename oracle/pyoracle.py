@@ -47,6 +47,7 @@ def lib():
         L.orc_overlap.restype = C.c_int64
         L.orc_overlap.argtypes = [vp, vp, cp, u64, u64, C.c_int, C.c_int, pu64, u64, C.POINTER(C.c_int), pu64]
         L.orc_build_asqg.argtypes = [vp, vp, cp, u64, C.c_int, C.c_int, cp, cp, pu64]
+        L.orc_build_asqg_mt.argtypes = [vp, vp, cp, u64, C.c_int, C.c_int, cp, C.c_int, C.POINTER(C.c_double)]
         L.orc_rmdup.argtypes = [vp, vp, cp, cp, cp]
         L.orc_correct.argtypes = [vp, cp, cp, u64, C.c_int, u64, u64, pu64]
         L.orc_overlap_batch_timed.restype = C.c_double
@@ -158,6 +159,16 @@ def build_asqg(fwd, rev, reads_path, min_overlap, asqg_path, hits_path="", irred
     if r != 0:
         raise RuntimeError("orc_build_asqg failed: %d" % r)
     return {"occ_calls": int(st[0]), "n_occ_min": int(st[1]), "blocks": int(st[2])}
+
+
+def build_asqg_mt(fwd, rev, reads_path, min_overlap, asqg_path, threads=0, irreducible=True, rc=True):
+    """`siga overlap -t N` end to end on the CPU: returns seconds of {parse, overlap (OpenMP), VT + ED text}."""
+    secs = (C.c_double * 3)()
+    r = lib().orc_build_asqg_mt(fwd.h, rev.h, reads_path.encode(), min_overlap, int(irreducible), int(rc), asqg_path.encode(),
+                                threads, secs)
+    if r != 0:
+        raise RuntimeError("orc_build_asqg_mt failed: %d" % r)
+    return {"parse": secs[0], "overlap": secs[1], "text": secs[2]}
 
 
 def rmdup(fwd, rev, reads_path, fasta_path, dups_path):

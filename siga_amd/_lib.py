@@ -41,11 +41,11 @@ class IndexInfo(C.Structure):
 
 # every symbol include/sigax.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "sigax_last_error", "sigax_device_count", "sigax_stream_create", "sigax_stream_destroy", "sigax_index_open", "sigax_index_open_mem", "sigax_index_close",
+    "sigax_last_error", "sigax_device_count", "sigax_stream_create", "sigax_stream_destroy", "sigax_index_open", "sigax_index_open_mem", "sigax_index_clone", "sigax_index_close",
     "sigax_index_info_get", "sigax_index_set_reads", "sigax_occ_batch", "sigax_kmer_count_batch",
     "sigax_correct_batch", "sigax_correct_device", "sigax_overlap_batch", "sigax_result_free", "sigax_batch_create", "sigax_batch_destroy", "sigax_batch_upload",
     "sigax_batch_set_device_reads", "sigax_batch_set_subbatches", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
-    "sigax_batch_download", "sigax_batch_kernel_ms", "sigax_build_strand", "sigax_free",
+    "sigax_batch_download", "sigax_batch_download_edges", "sigax_batch_size_hint", "sigax_batch_kernel_ms", "sigax_build_strand", "sigax_free",
 ]
 
 _lib = None
@@ -70,6 +70,7 @@ def lib():
     L.sigax_stream_destroy.restype = None
     L.sigax_index_open.argtypes = [cp, cp, cp, cp, ci, pvp]
     L.sigax_index_open_mem.argtypes = [vp, u64, vp, u64, u64, u64, vp, vp, ci, pvp]
+    L.sigax_index_clone.argtypes = [vp, ci, pvp]
     L.sigax_index_close.argtypes = [vp]
     L.sigax_index_close.restype = None
     L.sigax_index_info_get.argtypes = [vp, C.POINTER(IndexInfo)]
@@ -90,6 +91,8 @@ def lib():
     L.sigax_batch_finish.argtypes = [vp, vp, C.POINTER(Stats)]
     L.sigax_batch_device_outputs.argtypes = [vp, pvp, pvp, pvp, pvp]
     L.sigax_batch_download.argtypes = [vp, C.POINTER(Result)]
+    L.sigax_batch_download_edges.argtypes = [vp, vp, pvp, C.POINTER(u64)]
+    L.sigax_batch_size_hint.argtypes = [vp, u32, u32, u32, u32, C.POINTER(u32)]
     L.sigax_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 5), C.POINTER(C.c_uint32)]
     L.sigax_batch_set_subbatches.argtypes = [vp, u32]
     L.sigax_build_strand.argtypes = [vp, vp, u64, ci, ci, pvp, C.POINTER(u64), pvp, C.POINTER(u64)]

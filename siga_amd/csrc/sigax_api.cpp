@@ -351,6 +351,75 @@ extern "C" int sigax_index_open(const char* bwt_path, const char* rbwt_path, con
                               have_sai ? rsai.data() : nullptr, device, out);
 }
 
+// Replica of an open index on another GPU of the node, copied device to device (xGMI between MI355X peers) instead of
+// being decoded and uploaded again: SURVEY.md 8(e) "index broadcast at start-up".
+extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index** out) {
+  if (!src || !out) return fail(SIGAX_E_ARG, "NULL argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SIGAX_E_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(SIGAX_E_ARG, "device %d out of range (%d visible)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  if (device != src->device) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(src->device, 0);
+    (void)hipGetLastError();  // already enabled is fine; hipMemcpyPeer works either way (staged when there is no direct path)
+  }
+  sigax_index* ix = new sigax_index();
+  memset(ix, 0, sizeof(*ix));
+  ix->device = device;
+  ix->enqueue_mu = new std::mutex();
+  ix->n_cu = src->n_cu;
+  (void)hipDeviceGetAttribute(&ix->n_cu, hipDeviceAttributeMultiprocessorCount, device);
+  {
+    int prio_least = 0, prio_greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_find, hipStreamNonBlocking, prio_greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_fx, hipStreamNonBlocking, prio_least);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_tail, hipStreamNonBlocking, prio_greatest);
+    if (e != hipSuccess) {
+      sigax_index_close(ix);
+      return fail(SIGAX_E_DEVICE, "creating the pipeline streams: %s", hipGetErrorString(e));
+    }
+  }
+  ix->wide = src->wide;
+  ix->n_symbols = src->n_symbols;
+  ix->n_strings = src->n_strings;
+  ix->n_sai = src->n_sai;
+  ix->n_meta = src->n_meta;
+  ix->split_strands = src->split_strands;
+  const u64 ngran = src->n_symbols / SIGAX_GRANULE_SYMS + 1;
+  const u64 nsuper = ((ngran - 1) >> (SIGAX_SUPER_SHIFT - 7)) + 1;
+  const u64 ng2 = src->n_symbols / SIGAX_GRAN2_SYMS + 1;
+  auto copy = [&](void** dst, const void* from, size_t bytes) -> int {
+    *dst = nullptr;
+    if (!from) return SIGAX_OK;
+    HIP_TRY(hipMalloc(dst, bytes ? bytes : 16));
+    if (bytes) HIP_TRY(hipMemcpyPeer(*dst, device, from, src->device, bytes));
+    ix->device_bytes += bytes;
+    return SIGAX_OK;
+  };
+  int rc = SIGAX_OK;
+  for (int s = 0; s < 2 && rc == SIGAX_OK; ++s) {
+    rc = copy(&ix->d_gran[s], src->d_gran[s], ngran * 64);
+    if (rc == SIGAX_OK) rc = copy(&ix->d_super[s], src->d_super[s], nsuper * 32);
+    if (rc == SIGAX_OK) rc = copy(&ix->d_gran2[s], src->d_gran2[s], ng2 * SIGAX_GRAN2_WORDS * 4);
+    if (rc == SIGAX_OK) rc = copy((void**)&ix->d_sai[s], src->d_sai[s], src->n_sai * 4);
+    ix->st[s] = src->st[s];
+    ix->st[s].granules = (const uint32_t*)ix->d_gran[s];
+    ix->st[s].super = (const u64*)ix->d_super[s];
+    ix->st[s].gran2 = (const uint32_t*)ix->d_gran2[s];
+  }
+  if (rc == SIGAX_OK) rc = copy((void**)&ix->d_read_len, src->d_read_len, src->n_meta * 4);
+  if (rc == SIGAX_OK) rc = copy((void**)&ix->d_name_rank, src->d_name_rank, src->n_meta * 4);
+  if (rc != SIGAX_OK) {
+    sigax_index_close(ix);
+    return rc;
+  }
+  *out = ix;
+  return SIGAX_OK;
+}
+
 extern "C" int sigax_index_info_get(const sigax_index* ix, sigax_index_info* out) {
   if (!ix || !out) return fail(SIGAX_E_ARG, "NULL argument");
   out->n_symbols = ix->n_symbols;
@@ -736,7 +805,10 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.chains_per_wg = 4;
     static const char* env_split = getenv("SIGAX_SPLIT_STRANDS");
     // (only while the 128 reads of such a workgroup still fit the LDS staging buffer: the double step needs them there)
-    const bool split = fa.two_step && (env_split ? env_split[0] != '0' : ix->split_strands) &&
+    // Without the two-step tables (indexes of 1.6 G symbols and more) the same split keeps one launch's gathers inside one
+    // strand's granule table once the two tables together pass the translation reach (profiles/r01_gather_probe.txt).
+    const bool big_one_step = !fa.two_step && ix->n_symbols >= (1ull << 30);
+    const bool split = (env_split ? env_split[0] != '0' : ((fa.two_step && ix->split_strands) || big_one_step)) &&
                        128ull * b->cur_max_len + 8 <= find_stage_capacity();
     b->find_per_sub = split ? 2u : 1u;
     if (split) {
@@ -963,6 +1035,56 @@ extern "C" int sigax_batch_download(sigax_batch* b, sigax_result* out) {
   if (n) HIP_TRY(hipMemcpy(out->substring, b->substring.p, n, hipMemcpyDeviceToHost));
   if (b->last_total_edges)
     HIP_TRY(hipMemcpy(out->edges, b->edges.p, b->last_total_edges * sizeof(sigax_edge), hipMemcpyDeviceToHost));
+  return SIGAX_OK;
+}
+
+// Diagnostic builds (-DSIGAX_FX_PROFILE): which path the extension rounds of the last finished run took.  Not in the header.
+extern "C" int sigax_debug_counters(sigax_batch* b, uint64_t out[32]) {
+  if (!b || !out) return fail(SIGAX_E_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(b->ix->device));
+  HIP_TRY(hipMemcpy(out, (u64*)b->dstat.p + DS_PROF_BASE, 32 * 8, hipMemcpyDeviceToHost));
+  return SIGAX_OK;
+}
+
+// What the ASQG writer needs from a finished batch: substring flags and edge records (not the 80-byte blocks).
+extern "C" int sigax_batch_download_edges(sigax_batch* b, uint8_t* substring, sigax_edge** edges, uint64_t* n_edges) {
+  if (!b || !edges || !n_edges) return fail(SIGAX_E_ARG, "NULL argument");
+  if (!b->finished) return fail(SIGAX_E_STATE, "batch not finished");
+  HIP_TRY(hipSetDevice(b->ix->device));
+  *edges = nullptr;
+  *n_edges = b->last_total_edges;
+  if (substring && b->n_reads) HIP_TRY(hipMemcpy(substring, b->substring.p, b->n_reads, hipMemcpyDeviceToHost));
+  sigax_edge* e = (sigax_edge*)malloc(std::max<size_t>(1, b->last_total_edges) * sizeof(sigax_edge));
+  if (!e) return fail(SIGAX_E_ARG, "host allocation failed");
+  if (b->last_total_edges) {
+    hipError_t err = hipMemcpy(e, b->edges.p, b->last_total_edges * sizeof(sigax_edge), hipMemcpyDeviceToHost);
+    if (err != hipSuccess) {
+      free(e);
+      return fail(SIGAX_E_DEVICE, "copying edge records: %s", hipGetErrorString(err));
+    }
+  }
+  *edges = e;
+  return SIGAX_OK;
+}
+
+// How many reads of up to max_read_len bases one batch object may hold when `in_flight` of them share the device's
+// free memory (the candidate arena is sized for the worst case: 4 chains x (L - m + 1) records per read).
+extern "C" int sigax_batch_size_hint(sigax_index* ix, uint32_t max_read_len, uint32_t min_overlap, uint32_t flags, uint32_t in_flight,
+                                     uint32_t* max_reads) {
+  if (!ix || !max_reads) return fail(SIGAX_E_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(ix->device));
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  const u64 mm = std::max<uint32_t>((flags & SIGAX_DUPLICATE) ? max_read_len : min_overlap, 1u);
+  u64 cap = (max_read_len > mm ? max_read_len - mm : 0u) + 1u;
+  cap = (cap + 1u) & ~1ull;
+  const u64 per_read = 4 * cap * cand_bytes(ix->wide) + max_read_len + ((flags & SIGAX_IRREDUCIBLE) ? 8 : 64) * (2 * 80 + 2 * 16 + 12) + 128;
+  const u64 fixed = (2ull << 30) + (u64)32768 * (4 * (cap + 2) + 128) * SIGAX_ENT_BYTES;  // pools of the lane-group and general kernels
+  const u64 share = (u64)(free_b * 0.85) / std::max<uint32_t>(in_flight, 1u);
+  u64 n = share > fixed ? (share - fixed) / per_read : 0;
+  n = std::min<u64>(n, 1u << 22);
+  if (n < 1024) return fail(SIGAX_E_CAPACITY, "not enough free device memory for a batch of reads of %u bases (%zu bytes free)", max_read_len, free_b);
+  *max_reads = (uint32_t)n;
   return SIGAX_OK;
 }
 

@@ -27,7 +27,8 @@ enum {
   DS_W64_BASE = DS_SLOW_BASE + 8,  // [DS_W64_BASE + i]: (read, side) items sub-batch i queued for the 64-lane launch
   DS_SEC_FIND = DS_W64_BASE + 8,   // distinct 64-byte sectors of the rank tables the finder asked for, step by step
   DS_SEC_EXTRACT,                  // ... filter/extract, round by round
-  DS_COUNT = 48
+  DS_PROF_BASE = 32,               // 32 diagnostic counters (builds with -DSIGAX_FX_PROFILE only)
+  DS_COUNT = 64
 };
 #define SIGAX_MAX_SUB 8
 

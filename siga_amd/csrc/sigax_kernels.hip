@@ -1267,7 +1267,16 @@ struct SideSh {
   u64 alive[FX_NSLOT];
   unsigned char D[FX_NSLOT], I[FX_NSLOT];
   u32 nsec;  // over the whole launch: distinct 64-byte sectors of the rank tables this wave's lane groups asked for
+#ifdef SIGAX_FX_PROFILE
+  u32 prof[16];  // which path each extension round took (diagnostic builds only)
+  u32 prof2[8];
+#endif
 };
+#ifdef SIGAX_FX_PROFILE
+#define FXP(i) do { if (gl == 0) atomicAdd(&sh.prof[i], 1u); } while (0)
+#else
+#define FXP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ u64 readlane64(u64 v, u32 l) {
   u32 lo = __builtin_amdgcn_readlane((u32)v, l), hi = __builtin_amdgcn_readlane((u32)(v >> 32), l);
@@ -1408,6 +1417,9 @@ struct GFx {
   u32 nslot, ni;  // slots handed out, incomings of the current pass
   u64 gAlive;
   u32 gD, gI;
+#ifdef SIGAX_FX_PROFILE
+  u32 dbg_round;
+#endif
 
   enum { RD_ENDED = 0, RD_UPDATED, RD_BRANCHED, RD_BAIL, RD_XERROR };
 
@@ -1495,6 +1507,7 @@ struct GFx {
     const bool mine = (alive >> gl) & 1ull;
     const FmRef ix = ext_index(e.src);
     const u64 p0 = (u64)e.c1lo, p1 = (u64)e.c1hi + 1ull;  // [p0, p1) in the extension index
+    FXP(0);
     // With the two-step table (fm_layout.h), when every alive block's range lies in one 64-row granule, one 128-byte line
     // per block serves: the end of the top-level block ('$' follows it); with a single group, TWO rounds at once when
     // every range holds one (first, second) symbol pair, the same pair (after complementing) for all
@@ -1504,7 +1517,24 @@ struct GFx {
     if (!WIDE && t2 != nullptr) {
       const u32 q0 = (u32)p0, q1 = (u32)p1;
       const bool in2 = mine && q1 > q0 && ((q1 - 1u) >> 6) == (q0 >> 6) && p1 <= ix.n;
+      if (gballot(mine && !in2) != 0) FXP(9);  // a range crosses a 64-row line: no two-step lookup
       if (gballot(mine && !in2) == 0) {
+        FXP(8);
+#ifdef SIGAX_FX_PROFILE
+        {  // how many 128-byte lines do the alive blocks of this round span?
+          u32 mn = mine ? (q0 >> 6) : 0xFFFFFFFFu, mx = mine ? (q0 >> 6) : 0u;
+          for (int off = (W == 64 ? 32 : 16); off > 0; off >>= 1) {
+            mn = min(mn, (u32)__shfl_xor((int)mn, off, 64));
+            mx = max(mx, (u32)__shfl_xor((int)mx, off, 64));
+          }
+          const u32 span = mx - mn;
+          const u32 rr = dbg_round < 3 ? dbg_round : 3;
+          if (gl == 0) atomicAdd(&sh.prof[12 + (span == 0 ? 0 : span == 1 ? 1 : 2)], 1u);
+          if (gl == 0 && span == 0) atomicAdd(&sh.prof2[rr], 1u);
+          if (gl == 0) atomicAdd(&sh.prof2[4 + rr], 1u);
+          ++dbg_round;
+        }
+#endif
         const u32* gq = (find_of(e.src) < 2 ? A.rev.gran2 : A.fwd.gran2) + (u64)(q0 >> 6) * SIGAX_GRAN2_WORDS;
         uint4 a4 = make_uint4(0, 0, 0, 0), a5 = a4, a6 = a4, a7 = a4;
         if (mine) {
@@ -1561,6 +1591,7 @@ struct GFx {
               xerror = true;
               return RD_XERROR;
             }
+            FXP(1);
             return RD_ENDED;
           }
         }
@@ -1589,13 +1620,18 @@ struct GFx {
           }
           nocc += (two ? 4u : 2u) * pop(alive);
           *newAlive = alive;
+          FXP(1);
+          if (two) FXP(10);
           return RD_UPDATED;
         }
       }
     }
     const u64 g0 = p0 >> 7;
     const bool inside = mine && p1 > p0 && ((p1 - 1) >> 7) == g0 && p1 <= ix.n;
-    if (gballot(mine && !inside)) return round(e, alive, newAlive);
+    if (gballot(mine && !inside)) {
+      FXP(4);
+      return round(e, alive, newAlive);
+    }
     const bool qcomp = (af_of(e.src) & 4u) != 0;
     uint4 k[4];
     k[0] = k[1] = k[2] = k[3] = make_uint4(0, 0, 0, 0);
@@ -1641,6 +1677,7 @@ struct GFx {
           e.c1hi = e.c1lo + size;
         }
         *newAlive = alive;
+        FXP(2);
         return RD_UPDATED;
       }
     }
@@ -1703,11 +1740,16 @@ struct GFx {
         xerror = true;
         return RD_XERROR;
       }
+      FXP(3);
       return RD_ENDED;
     }
     const u64 any0 = gballot(x0), any1 = gballot(xa), any2 = gballot(xc), any3 = gballot(xg), any4 = gballot(xt);
     const u32 nz = (any0 != 0) + (any1 != 0) + (any2 != 0) + (any3 != 0) + (any4 != 0);
-    if (nz != 1 || any0) return round(e, alive, newAlive);
+    if (nz != 1 || any0) {
+      FXP(5);
+      return round(e, alive, newAlive);
+    }
+    FXP(3);
     nocc += 2u * pop(alive);
     const u32 c = any1 ? 1u : any2 ? 2u : any3 ? 3u : 4u;
     const u32 b = qcomp ? 5u - c : c;
@@ -1739,6 +1781,9 @@ struct GFx {
     gAlive = 0;
     gD = 0;
     gI = 0;
+#ifdef SIGAX_FX_PROFILE
+    dbg_round = 0;
+#endif
     // Phase 1: a single group (the usual case: every overlapping read agrees on the next base).  With one group the
     // stride-2 ring walk of :728-802 visits it over and over, so this is a plain loop with the group in registers.
     {
@@ -1841,6 +1886,8 @@ struct GFx {
     const u32 nX = nA + c0 + c1, nY = nB + c2 + c3, T = nX + nY;
     if (T > (u32)W) return false;
     if (T == 0) return true;
+    FXP(6);
+    if (T <= 16) FXP(7);
     const bool active = gl < T;
     const u32 list = gl >= nX ? 1u : 0u;
     const u32 k = list ? gl - nX : gl;
@@ -1881,7 +1928,10 @@ struct GFx {
       if (!A.irreducible && same && (loj < e.c0lo || (loj == e.c0lo && kj < k))) ++rank;
       inter |= same & (j != gl) & !(e.c0lo > hij || loj > e.c0hi);  // coord.h:37-40
     }
-    if (gballot(inter)) return false;
+    if (gballot(inter)) {
+      FXP(11);
+      return false;
+    }
     if (A.irreducible) {
       // X += Y; stable sort by length descending (:715-716,1169), ties keep list X first.  Both finds pushed their
       // blocks in increasing length, so the position is a merge rank: blocks after me in my own list, plus the other
@@ -1989,6 +2039,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 1 : 
   const u32 wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const u64 wave = (u64)blockIdx.x * 4 + wid, nwaves = (u64)gridDim.x * 4;
   if (lane == 0) shm[wid].nsec = 0;
+#ifdef SIGAX_FX_PROFILE
+  if (lane < 16) shm[wid].prof[lane] = 0;
+  if (lane < 8) shm[wid].prof2[lane] = 0;
+#endif
   wave_lds_sync();
   GFx<WIDE, W> fx(A, tb, shm[wid], A.wpool + wave * FX_WPOOL, have2 ? &t2 : nullptr);
   u64 nocc_total = 0, nerr = 0, nsub = 0;
@@ -2021,6 +2075,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 1 : 
   }
   nocc_total = wave_sum(nocc_total); nerr = wave_sum(nerr); nsub = wave_sum(nsub);
   wave_lds_sync();
+#ifdef SIGAX_FX_PROFILE
+  if (lane < 16 && shm[wid].prof[lane]) atomicAdd(&A.dstat[DS_PROF_BASE + (W == 64 ? 16 : 0) + lane], (u64)shm[wid].prof[lane]);
+  if (W == 32 && lane < 8 && shm[wid].prof2[lane]) atomicAdd(&A.dstat[DS_PROF_BASE + 24 + lane], (u64)shm[wid].prof2[lane]);
+#endif
   if (lane == 0) {
     if (shm[wid].nsec) atomicAdd(&A.dstat[DS_SEC_EXTRACT], (u64)shm[wid].nsec);
     if (nocc_total) atomicAdd(&A.dstat[DS_OCC_EXTRACT], nocc_total);

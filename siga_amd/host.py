@@ -23,6 +23,10 @@ def lib():
         L.sigah_index_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_uint64]
         L.sigah_overlap_file.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_int, C.c_int, C.c_uint64,
                                          C.c_uint64, C.c_int, C.c_char_p, C.c_uint64]
+        L.sigah_overlap_file_gpus.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_int, C.c_int, C.c_uint64,
+                                              C.c_uint64, C.c_int, C.c_int, C.c_char_p, C.c_uint64]
+        L.sigah_parse_file.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+        L.sigah_parse_file.restype = C.c_int64
         L.sigah_stem.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64]
         L.sigah_write_file.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64]
         L.sigah_correct_file.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -66,11 +70,11 @@ def index_file(reads_path, prefix, threads=2):
         raise RuntimeError("siga index failed: " + err.value.decode())
 
 
-def overlap_file(reads_path, prefix, min_overlap, output, irreducible=True, rc=True, threads=1, batch=10000, device=0):
-    """FMIndex::load + OverlapBuilder::build in the host C++ library (GPU compute)."""
+def overlap_file(reads_path, prefix, min_overlap, output, irreducible=True, rc=True, threads=1, batch=10000, device=0, gpus=1):
+    """FMIndex::load + OverlapBuilder::build in the host C++ library (GPU compute), reads sharded over `gpus` GPUs."""
     err = C.create_string_buffer(512)
-    r = lib().sigah_overlap_file(reads_path.encode(), prefix.encode(), min_overlap, output.encode(), int(irreducible), int(rc),
-                                 threads, batch, device, err, 512)
+    r = lib().sigah_overlap_file_gpus(reads_path.encode(), prefix.encode(), min_overlap, output.encode(), int(irreducible), int(rc),
+                                      threads, batch, device, gpus, err, 512)
     if r != 0:
         raise RuntimeError("siga overlap failed: " + err.value.decode())
 
@@ -88,6 +92,11 @@ def correct_file(reads_path, prefix, output, k=31, threshold=3, rounds=10, offse
     if lib().sigah_correct_file(reads_path.encode(), prefix.encode(), output.encode(), k, threshold, rounds, offset, device,
                                 err, 512) != 0:
         raise RuntimeError("siga correct failed: " + err.value.decode())
+
+
+def parse_file(path, out_path, parallel=True, threads=4):
+    """records of a FASTA/FASTQ file as the host library reads them (parallel loader or record-at-a-time reader)"""
+    return lib().sigah_parse_file(path.encode(), 0 if parallel else 1, out_path.encode(), threads)
 
 
 def write_file(path, data, pieces=1):

@@ -4,12 +4,19 @@
 
 #include <zlib.h>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <numeric>
+#include <string_view>
 #include <thread>
 
 #include "sais.hpp"
@@ -71,6 +78,287 @@ class LineSource {
   size_t _pos, _len;
   bool _eof;
 };
+
+// ------------------------------------------------------------------------------------------------------
+// host parallelism: the GPU replaces the reference's OpenMP loop over reads; what is left on the host (parsing, name
+// ranks, text formatting, deflate) is spread over plain threads
+// ------------------------------------------------------------------------------------------------------
+static unsigned host_threads(size_t requested) {
+  const char* env = getenv("SIGA_HOST_THREADS");
+  if (env && atoi(env) > 0) return (unsigned)atoi(env);
+  unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  unsigned autoN = std::min(hw, 32u);
+  return (unsigned)std::max<size_t>(requested > 1 ? requested : 0, autoN);
+}
+
+template <class F>
+static void parallel_for(size_t n, unsigned nt, F f) {
+  if (n == 0) return;
+  nt = (unsigned)std::min<size_t>(std::max(1u, nt), n);
+  if (nt == 1) {
+    for (size_t i = 0; i < n; ++i) f(i);
+    return;
+  }
+  std::atomic<size_t> next(0);
+  auto work = [&] {
+    for (;;) {
+      size_t i = next.fetch_add(1);
+      if (i >= n) break;
+      f(i);
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+  work();
+  for (auto& x : th) x.join();
+}
+
+static inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; }
+
+// ------------------------------------------------------------------------------------------------------
+// ReadStore: a whole reads file parsed at once with the reference's reader semantics (src/kseq.cpp:140-228), in
+// parallel for FASTA; names and comments are spans of the file image, sequences are packed the way the device batches
+// take them
+// ------------------------------------------------------------------------------------------------------
+struct ReadStore {
+  std::vector<char> file;
+  std::vector<char> seqs;
+  std::vector<uint64_t> offs;                 // n + 1
+  std::vector<uint64_t> head_off;             // raw header (after '>' / '@'), a span of `file`
+  std::vector<uint32_t> head_len, name_len;   // name = head[0, name_len); comment = head[name_len + 1, head_len)
+  std::vector<uint64_t> qual_off;             // FASTQ: span of `file`, seq length long
+  bool fastq = false;
+  size_t size() const { return head_off.size(); }
+  std::string_view name(size_t i) const { return std::string_view(file.data() + head_off[i], name_len[i]); }
+  std::string_view comment(size_t i) const {
+    return name_len[i] < head_len[i] ? std::string_view(file.data() + head_off[i] + name_len[i] + 1, head_len[i] - name_len[i] - 1)
+                                     : std::string_view();
+  }
+  std::string_view seq(size_t i) const { return std::string_view(seqs.data() + offs[i], offs[i + 1] - offs[i]); }
+  std::string_view quality(size_t i) const {
+    return fastq ? std::string_view(file.data() + qual_off[i], offs[i + 1] - offs[i]) : std::string_view();
+  }
+};
+
+static bool slurp(const std::string& path, std::vector<char>* out) {
+  int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) return false;
+  unsigned char magic[2] = {0, 0};
+  ssize_t got = pread(fd, magic, 2, 0);
+  struct stat st;
+  if (fstat(fd, &st) != 0) {
+    close(fd);
+    return false;
+  }
+  if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {  // gzip (Utils::ifstream, src/utils.cpp:50-90)
+    close(fd);
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) return false;
+    gzbuffer(f, 1 << 20);
+    out->resize(std::max<size_t>((size_t)st.st_size * 4, 1 << 20));
+    size_t len = 0;
+    for (;;) {
+      if (out->size() - len < (1u << 20)) out->resize(out->size() * 2);
+      int n = gzread(f, out->data() + len, (unsigned)std::min<size_t>(out->size() - len, 1u << 30));
+      if (n <= 0) break;
+      len += (size_t)n;
+    }
+    gzclose(f);
+    out->resize(len);
+    return true;
+  }
+  out->resize((size_t)st.st_size);
+  size_t len = 0;
+  while (len < out->size()) {
+    ssize_t n = read(fd, out->data() + len, out->size() - len);
+    if (n <= 0) break;
+    len += (size_t)n;
+  }
+  close(fd);
+  out->resize(len);
+  return true;
+}
+
+namespace {
+struct ChunkOut {
+  std::vector<uint64_t> head_off, seq_len, qual_off;
+  std::vector<uint32_t> head_len;
+  std::vector<char> seqs;
+  bool stopped = false;   // the reader returned false inside this chunk: nothing after it is read
+  bool nameless = false;  // a header with no text: its sequence lines leak into the next record (serial semantics only)
+  bool open_empty = false;  // the chunk ends in a named record without sequence
+};
+}  // namespace
+
+// FASTAReader::read over [b, e) of the file image (src/kseq.cpp:187-228); the chunk starts at a header line
+static void parse_fasta_chunk(const char* base, size_t b, size_t e, bool last_chunk, ChunkOut* o) {
+  bool have_name = false;
+  uint64_t hoff = 0;
+  uint32_t hlen = 0;
+  size_t seq_start = o->seqs.size();
+  size_t p = b;
+  auto emit = [&] {
+    o->head_off.push_back(hoff);
+    o->head_len.push_back(hlen);
+    o->seq_len.push_back(o->seqs.size() - seq_start);
+    seq_start = o->seqs.size();
+  };
+  while (p < e) {
+    const char* nl = (const char*)memchr(base + p, '\n', e - p);
+    size_t le = nl ? (size_t)(nl - base) : e;
+    size_t ls = p;
+    p = nl ? le + 1 : e;
+    while (ls < le && is_space(base[ls])) ++ls;
+    while (le > ls && is_space(base[le - 1])) --le;
+    if (ls == le) continue;
+    if (base[ls] == '>') {
+      const size_t cur_seq = o->seqs.size() - seq_start;
+      if (cur_seq > 0 && have_name && hlen > 0) {
+        emit();
+      } else if (have_name && hlen > 0) {  // a named record without sequence: the reader gives up here
+        o->stopped = true;
+        return;
+      }
+      if (have_name && hlen == 0) o->nameless = true;
+      have_name = true;
+      hoff = ls + 1;
+      hlen = (uint32_t)(le - ls - 1);
+    } else {
+      o->seqs.insert(o->seqs.end(), base + ls, base + le);
+    }
+  }
+  const size_t cur_seq = o->seqs.size() - seq_start;
+  if (have_name && hlen == 0) o->nameless = true;
+  if (cur_seq > 0 && have_name && hlen > 0) emit();
+  else if (have_name && hlen > 0 && !last_chunk) o->open_empty = true;  // the next header makes the reader give up
+  else if (cur_seq > 0) o->seqs.resize(seq_start);
+}
+
+// FASTQReader::read (src/kseq.cpp:140-185), serial
+static void parse_fastq(const char* base, size_t e, ChunkOut* o) {
+  int state = 0;
+  uint64_t hoff = 0, soff = 0;
+  uint32_t hlen = 0, slen = 0;
+  size_t p = 0;
+  while (p < e) {
+    const char* nl = (const char*)memchr(base + p, '\n', e - p);
+    size_t le = nl ? (size_t)(nl - base) : e;
+    size_t ls = p;
+    p = nl ? le + 1 : e;
+    while (ls < le && is_space(base[ls])) ++ls;
+    while (le > ls && is_space(base[le - 1])) --le;
+    if (ls == le) continue;
+    if (state == 0) {
+      if (base[ls] != '@') return;
+      hoff = ls + 1;
+      hlen = (uint32_t)(le - ls - 1);
+      state = 1;
+    } else if (state == 1) {
+      soff = ls;
+      slen = (uint32_t)(le - ls);
+      state = 2;
+    } else if (state == 2) {
+      const size_t len = le - ls;
+      const bool ends = len >= hlen && memcmp(base + le - hlen, base + hoff, hlen) == 0;
+      if (base[ls] == '+' && (len == 1 || ends)) state = 3;
+      else return;
+    } else {
+      if (le - ls != slen) return;
+      o->head_off.push_back(hoff);
+      o->head_len.push_back(hlen);
+      o->seq_len.push_back(slen);
+      o->qual_off.push_back(ls);
+      o->seqs.insert(o->seqs.end(), base + soff, base + soff + slen);
+      state = 0;
+    }
+  }
+}
+
+static bool LoadReads(const std::string& path, ReadStore* rs, unsigned nt) {
+  if (!slurp(path, &rs->file)) return false;
+  const char* base = rs->file.data();
+  const size_t size = rs->file.size();
+  if (size == 0 || (base[0] != '@' && base[0] != '>')) return false;  // DNASeqReaderFactory::create (src/kseq.cpp:127-138)
+  rs->fastq = base[0] == '@';
+  std::vector<ChunkOut> outs;
+  if (rs->fastq) {
+    outs.resize(1);
+    parse_fastq(base, size, &outs[0]);
+  } else {
+    // chunk starts: the first header line at or after i * size / K
+    const size_t K = std::max<size_t>(1, std::min<size_t>((size_t)nt * 4, size >> 16));
+    std::vector<size_t> starts(1, 0);
+    for (size_t i = 1; i < K; ++i) {
+      size_t p = i * (size / K);
+      const char* nl = (const char*)memchr(base + p, '\n', size - p);
+      if (!nl) break;
+      p = (size_t)(nl - base) + 1;
+      while (p < size) {  // find a line whose first non-blank character is '>'
+        size_t q = p;
+        while (q < size && base[q] != '\n' && is_space(base[q])) ++q;
+        if (q < size && base[q] == '>') break;
+        const char* n2 = (const char*)memchr(base + p, '\n', size - p);
+        if (!n2) {
+          p = size;
+          break;
+        }
+        p = (size_t)(n2 - base) + 1;
+      }
+      if (p < size && p > starts.back()) starts.push_back(p);
+    }
+    outs.resize(starts.size());
+    parallel_for(starts.size(), nt, [&](size_t i) {
+      const size_t e = i + 1 < starts.size() ? starts[i + 1] : size;
+      parse_fasta_chunk(base, starts[i], e, i + 1 == starts.size(), &outs[i]);
+    });
+    bool nameless = false;
+    for (auto& o : outs) nameless = nameless || o.nameless;
+    if (nameless) {  // state leaks across records: only the serial walk reproduces it
+      outs.assign(1, ChunkOut());
+      parse_fasta_chunk(base, 0, size, true, &outs[0]);
+    }
+  }
+  // concatenate up to the point where the serial reader would have given up
+  size_t nchunks = 0, n = 0, nb = 0;
+  for (; nchunks < outs.size(); ++nchunks) {
+    n += outs[nchunks].head_off.size();
+    nb += outs[nchunks].seqs.size();
+    if (outs[nchunks].stopped || outs[nchunks].open_empty) {
+      ++nchunks;
+      break;
+    }
+  }
+  rs->head_off.resize(n);
+  rs->head_len.resize(n);
+  rs->name_len.resize(n);
+  rs->offs.resize(n + 1);
+  rs->seqs.resize(nb);
+  if (rs->fastq) rs->qual_off.resize(n);
+  std::vector<size_t> rbase(nchunks + 1, 0), bbase(nchunks + 1, 0);
+  for (size_t c = 0; c < nchunks; ++c) {
+    rbase[c + 1] = rbase[c] + outs[c].head_off.size();
+    bbase[c + 1] = bbase[c] + outs[c].seqs.size();
+  }
+  parallel_for(nchunks, nt, [&](size_t c) {
+    const ChunkOut& o = outs[c];
+    uint64_t off = bbase[c];
+    for (size_t k = 0; k < o.head_off.size(); ++k) {
+      const size_t r = rbase[c] + k;
+      rs->head_off[r] = o.head_off[k];
+      rs->head_len[r] = o.head_len[k];
+      const char* h = base + o.head_off[k];
+      uint32_t nl = 0;
+      while (nl < o.head_len[k] && h[nl] != ' ' && h[nl] != '\t') ++nl;  // make_seq_name (src/kseq.cpp:71-79)
+      rs->name_len[r] = nl;
+      rs->offs[r] = off;
+      off += o.seq_len[k];
+      if (rs->fastq) rs->qual_off[r] = o.qual_off[k];
+    }
+    if (!o.seqs.empty()) memcpy(rs->seqs.data() + bbase[c], o.seqs.data(), o.seqs.size());
+  });
+  rs->offs[n] = nb;
+  return true;
+}
 
 static void trim(std::string& s) {  // boost::algorithm::trim
   auto sp = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\v' || c == '\f' || c == '\r'; };
@@ -459,14 +747,16 @@ uint64_t FMIndex::length() const {
 // ------------------------------------------------------------------------------------------------------
 // Utils::ofstream (src/utils.cpp:92-126): gzip when the name ends with .gz.  The gzip stream is ONE member (what any
 // gzip reader, boost's gzip_decompressor included, accepts) whose deflate data is produced block-wise by a pool of
-// threads: every 1 MiB block is deflated on its own as raw deflate ending in a sync flush, the blocks are concatenated
-// in order and the CRC-32s are combined (the pigz scheme, without dictionary priming).
+// threads: every 1 MiB of the text, counted from the start of the stream, is deflated on its own as raw deflate ending in
+// a sync flush, the blocks are concatenated in order and the CRC-32s are combined (the pigz scheme, without dictionary
+// priming).  Block boundaries depend on the text alone, so the file's bytes do not depend on how many threads, batches
+// or GPUs produced it.
 class OutFile {
  public:
-  explicit OutFile(const std::string& path) : _f(nullptr), _gz(false), _crc(0), _total(0) {
+  explicit OutFile(const std::string& path, unsigned threads = 0) : _f(nullptr), _gz(false), _crc(0), _total(0), _nt(threads) {
     _gz = path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
     _f = fopen(path.c_str(), "wb");
-    _buf.reserve(kFlush + (1 << 20));
+    if (_nt == 0) _nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32);
     if (_f && _gz) {
       static const unsigned char hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
       fwrite(hdr, 1, 10, _f);
@@ -477,13 +767,75 @@ class OutFile {
   bool ok() const { return _f != nullptr; }
   void write(const char* p, size_t n) {
     _buf.append(p, n);
-    if (_buf.size() >= kFlush) flush(false);
+    if (_buf.size() >= kFlush) {
+      std::vector<std::string> none;
+      write_parts(none);
+    }
   }
   void write(const std::string& s) { write(s.data(), s.size()); }
+  // the concatenation of `parts` goes out next; whole blocks are deflated now (in parallel), the rest waits in _buf
+  void write_parts(const std::vector<std::string>& parts) {
+    if (!_f) return;
+    if (!_gz) {
+      if (!_buf.empty()) fwrite(_buf.data(), 1, _buf.size(), _f);
+      _buf.clear();
+      for (const std::string& p : parts)
+        if (!p.empty()) fwrite(p.data(), 1, p.size(), _f);
+      return;
+    }
+    std::vector<const std::string*> segs;
+    std::vector<size_t> start;  // offset of each segment in the pending text
+    size_t total = 0;
+    auto add = [&](const std::string* x) {
+      if (x->empty()) return;
+      segs.push_back(x);
+      start.push_back(total);
+      total += x->size();
+    };
+    add(&_buf);
+    for (const std::string& p : parts) add(&p);
+    const size_t nfull = total / kBlock;
+    auto gather = [&](size_t off, size_t len, char* dst) {
+      size_t k = (size_t)(std::upper_bound(start.begin(), start.end(), off) - start.begin()) - 1;
+      while (len) {
+        const size_t in = off - start[k], take = std::min(len, segs[k]->size() - in);
+        memcpy(dst, segs[k]->data() + in, take);
+        dst += take;
+        off += take;
+        len -= take;
+        ++k;
+      }
+    };
+    if (nfull) {
+      std::vector<std::string> outs(nfull);
+      std::vector<uLong> crcs(nfull, 0);
+      parallel_for(nfull, _nt, [&](size_t i) {
+        std::string tmp(kBlock, '\0');
+        gather(i * kBlock, kBlock, &tmp[0]);
+        deflate_block(tmp.data(), kBlock, false, &outs[i], &crcs[i]);
+      });
+      for (size_t i = 0; i < nfull; ++i) {
+        fwrite(outs[i].data(), 1, outs[i].size(), _f);
+        _crc = crc32_combine(_crc, crcs[i], (z_off_t)kBlock);
+      }
+      _total += nfull * kBlock;
+    }
+    std::string rest(total - nfull * kBlock, '\0');
+    if (!rest.empty()) gather(nfull * kBlock, rest.size(), &rest[0]);
+    _buf.swap(rest);
+  }
   bool close() {
     if (!_f) return true;
-    flush(true);
+    std::vector<std::string> none;
+    write_parts(none);
     if (_gz) {
+      std::string out;
+      uLong crc = 0;
+      deflate_block(_buf.data(), _buf.size(), true, &out, &crc);  // the last (possibly empty) block ends the deflate stream
+      fwrite(out.data(), 1, out.size(), _f);
+      _crc = crc32_combine(_crc, crc, (z_off_t)_buf.size());
+      _total += _buf.size();
+      _buf.clear();
       unsigned char tail[8];
       uint32_t c = (uint32_t)_crc, n = (uint32_t)_total;
       for (int i = 0; i < 4; ++i) { tail[i] = (unsigned char)(c >> (8 * i)); tail[4 + i] = (unsigned char)(n >> (8 * i)); }
@@ -510,44 +862,11 @@ class OutFile {
     deflateEnd(&z);
     *crc = crc32(crc32(0L, Z_NULL, 0), (const Bytef*)in, (uInt)n);
   }
-  void flush(bool last) {
-    if (!_f) return;
-    if (!_gz) {
-      if (!_buf.empty()) fwrite(_buf.data(), 1, _buf.size(), _f);
-      _buf.clear();
-      return;
-    }
-    size_t nblocks = (_buf.size() + kBlock - 1) / kBlock;
-    if (nblocks == 0 && last) nblocks = 1;  // an empty final block terminates the deflate stream
-    std::vector<std::string> outs(nblocks);
-    std::vector<uLong> crcs(nblocks, 0);
-    std::atomic<size_t> next(0);
-    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32);
-    nt = (unsigned)std::min<size_t>(nt, nblocks);
-    auto work = [&] {
-      while (true) {
-        size_t i = next.fetch_add(1);
-        if (i >= nblocks) break;
-        size_t b = i * kBlock, e = std::min(_buf.size(), b + kBlock);
-        deflate_block(_buf.data() + b, e > b ? e - b : 0, last && i + 1 == nblocks, &outs[i], &crcs[i]);
-      }
-    };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
-    work();
-    for (auto& x : th) x.join();
-    for (size_t i = 0; i < nblocks; ++i) {
-      size_t b = i * kBlock, e = std::min(_buf.size(), b + kBlock);
-      fwrite(outs[i].data(), 1, outs[i].size(), _f);
-      _crc = crc32_combine(_crc, crcs[i], (z_off_t)(e > b ? e - b : 0));
-    }
-    _total += _buf.size();
-    _buf.clear();
-  }
   FILE* _f;
   bool _gz;
   uLong _crc;
   uint64_t _total;
+  unsigned _nt;
   std::string _buf;
 };
 
@@ -599,15 +918,16 @@ static int parse_int(const std::string& s) {  // std::istream >> int (0 on failu
 }
 
 // OverlapPostProcess::operator() + VertexRecord << (src/overlap_builder.cpp:301-322, src/asqg.cpp:171-186)
-static void write_vertex(std::string& o, const DNASeq& read, bool substring) {
+static void write_vertex(std::string& o, std::string_view name, std::string_view comment_sv, std::string_view seq, bool substring) {
   bool hasCov = false, hasBar = false, hasExt = false;
   int cov = 0;
   std::string bar, ext, val;
-  if (!read.comment.empty()) {
+  if (!comment_sv.empty()) {
+    const std::string comment(comment_sv);
     size_t b = 0;
     while (true) {
-      size_t e = read.comment.find(' ', b);
-      std::string tok = read.comment.substr(b, e == std::string::npos ? std::string::npos : e - b);
+      size_t e = comment.find(' ', b);
+      std::string tok = comment.substr(b, e == std::string::npos ? std::string::npos : e - b);
       if (tok.compare(0, 2, "BX") == 0) {
         if (tag_tokens(tok, 'Z', &val)) { bar = first_word(val); hasBar = true; }
       } else if (tok.compare(0, 2, "CR") == 0) {
@@ -620,9 +940,9 @@ static void write_vertex(std::string& o, const DNASeq& read, bool substring) {
     }
   }
   o += "VT\t";
-  o += read.name;
+  o.append(name.data(), name.size());
   o += '\t';
-  o += read.seq;
+  o.append(seq.data(), seq.size());
   o += substring ? "\tSS:i:1" : "\tSS:i:0";
   if (hasCov) { o += "\tCR:i:"; o += std::to_string(cov); }
   if (hasBar) { o += "\tBX:Z:"; o += bar; }
@@ -632,15 +952,16 @@ static void write_vertex(std::string& o, const DNASeq& read, bool substring) {
 
 // EdgeRecord << (src/asqg.cpp:228-237, src/coord.cpp:4-80) with OverlapBlock::overlap's coordinates
 // (src/overlap_builder.cpp:158-175)
-static void write_edge(std::string& o, const sigax_edge& e, const DNASeqList& reads) {
-  uint64_t ql = reads[e.query].seq.size(), tl = reads[e.target].seq.size(), len = e.length;
+static void write_edge(std::string& o, const sigax_edge& e, const ReadStore& reads) {
+  const std::string_view qn = reads.name(e.query), tn = reads.name(e.target);
+  uint64_t ql = reads.offs[e.query + 1] - reads.offs[e.query], tl = reads.offs[e.target + 1] - reads.offs[e.target], len = e.length;
   uint64_t s0 = ql - len, e0 = ql - 1, s1 = 0, e1 = len - 1;
   if (e.af & 1u) { uint64_t t = s0; s0 = ql - e0 - 1; e0 = ql - t - 1; }
   if (e.af & 2u) { uint64_t t = s1; s1 = tl - e1 - 1; e1 = tl - t - 1; }
   o += "ED\t";
-  o += reads[e.query].name;
+  o.append(qn.data(), qn.size());
   o += ' ';
-  o += reads[e.target].name;
+  o.append(tn.data(), tn.size());
   o += ' ';
   append_u64(o, s0); o += ' ';
   append_u64(o, e0); o += ' ';
@@ -665,6 +986,85 @@ struct PhaseTimer {  // SIGA_TIMING=1: phase times on stderr
   }
 };
 
+// ReadInfo{name,length} of the edge converter (src/overlap_builder.cpp:333-343) as lengths + rank of each name under
+// std::string operator< (equal names, equal rank): sorted chunks merged pairwise, all in parallel
+static void name_ranks(const ReadStore& rs, unsigned nt, std::vector<uint32_t>* lengths, std::vector<uint32_t>* ranks) {
+  const size_t n = rs.size();
+  lengths->resize(n);
+  ranks->resize(n);
+  std::vector<uint32_t> order(n);
+  auto less = [&](uint32_t a, uint32_t b) { return rs.name(a) < rs.name(b); };
+  size_t runs = 1;
+  while (runs < nt && n / (runs * 2) >= 4096) runs *= 2;
+  const size_t step = (n + runs - 1) / std::max<size_t>(runs, 1);
+  parallel_for(runs, nt, [&](size_t r) {
+    const size_t b = std::min(n, r * step), e = std::min(n, b + step);
+    for (size_t i = b; i < e; ++i) {
+      order[i] = (uint32_t)i;
+      (*lengths)[i] = (uint32_t)(rs.offs[i + 1] - rs.offs[i]);
+    }
+    std::stable_sort(order.begin() + b, order.begin() + e, less);
+  });
+  for (size_t width = step; width < n; width *= 2) {
+    const size_t pairs = (n + 2 * width - 1) / (2 * width);
+    parallel_for(pairs, nt, [&](size_t p) {
+      const size_t b = p * 2 * width, m = std::min(n, b + width), e = std::min(n, b + 2 * width);
+      if (m < e) std::inplace_merge(order.begin() + b, order.begin() + m, order.begin() + e, less);
+    });
+  }
+  uint32_t rk = 0;
+  for (size_t k = 0; k < n; ++k) {
+    if (k > 0 && rs.name(order[k]) != rs.name(order[k - 1])) ++rk;
+    (*ranks)[order[k]] = rk;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// OverlapBuilder::build (src/overlap_builder.cpp:423-509).  The reference reads items in batches of threads x batch-size,
+// runs overlap() on them under OpenMP and post-processes the batch serially in input order (parallel::foreach,
+// src/parallel_framework.h:16-59).  Here: the reads are parsed once (in parallel), cut into device batches sized from
+// free HBM, and every GPU of the run keeps two batch objects in flight (upload / kernels / download overlap); the main
+// thread takes finished batches in input order, formats their VT lines on the host threads and feeds the block-parallel
+// gzip writer; the ED lines follow in hits order from the collected 16-byte edge records.  With --gpus N the index is
+// replicated device to device and batches go to whichever GPU is free: the output does not depend on N.
+// ------------------------------------------------------------------------------------------------------
+namespace {
+struct BatchOut {
+  std::vector<uint8_t> substring;
+  sigax_edge* edges = nullptr;
+  uint64_t n_edges = 0;
+  bool ready = false;
+};
+struct Pipeline {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<BatchOut> out;
+  std::atomic<size_t> next{0};
+  std::atomic<bool> failed{false};
+  std::string error;
+  void fail(const std::string& e) {
+    std::lock_guard<std::mutex> g(mu);
+    if (!failed.exchange(true)) error = e;
+    cv.notify_all();
+  }
+};
+}  // namespace
+
+static std::vector<int> device_list(int first, int count) {
+  // SIGA_DEVICE_MAP=0,0,...: logical GPU k of the run is physical device map[k] (rehearsing --gpus N on fewer GPUs)
+  std::vector<int> map;
+  if (const char* env = getenv("SIGA_DEVICE_MAP")) {
+    for (const char* p = env; *p;) {
+      map.push_back(atoi(p));
+      while (*p && *p != ',') ++p;
+      if (*p == ',') ++p;
+    }
+  }
+  std::vector<int> d;
+  for (int k = 0; k < std::max(count, 1); ++k) d.push_back((size_t)k < map.size() ? map[k] : first + k);
+  return d;
+}
+
 bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const std::string& output, size_t threads,
                            size_t batch, size_t* processed) const {
   (void)processed;  // accepted and never written, like the reference (src/overlap_builder.cpp:423-424)
@@ -674,75 +1074,183 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
     _error = "FMIndex not loaded";
     return false;
   }
-  DNASeqList reads;
-  if (!ReadDNASequences(input, reads)) {
+  const unsigned nt = host_threads(threads);
+  ReadStore reads;
+  if (!LoadReads(input, &reads, nt)) {
     _error = "Failed to read file " + input;
     return false;
   }
-  OutFile out(output);
+  pt.lap("parse reads");
+  OutFile out(output, nt);
   if (!out.ok()) {
     _error = "Failed to create ASQG " + output;
     return false;
   }
   // header: src/overlap_builder.cpp:428-437 (the IN tag is never written: :494-495)
-  {
-    std::string h = "HT\tVN:i:1\tOL:i:" + std::to_string((int)minOverlap) + "\tCN:i:1\n";
-    out.write(h);
-  }
+  out.write("HT\tVN:i:1\tOL:i:" + std::to_string((int)minOverlap) + "\tCN:i:1\n");
   const size_t n = reads.size();
-  // ReadInfo{name,length} for the edge converter (src/overlap_builder.cpp:333-343) as lengths + name ranks
-  pt.lap("parse reads");
-  if (!set_read_info(_fmi, reads, &_error)) return false;
-  pt.lap("read info (name ranks)");
-  uint32_t flags = SIGAX_EDGES | (_irreducible ? SIGAX_IRREDUCIBLE : 0u) | (_rc ? SIGAX_RC : 0u);
-  // one device batch object for the whole run (its arenas are allocated once); the reference's threads*batch is a
-  // lower bound for the device batch size, which defaults to up to a million reads
-  size_t per = std::max<size_t>(std::max<size_t>(threads, 1) * std::max<size_t>(batch, 1), 1u << 20);
-  per = std::min(per, std::max<size_t>(n, 1));
-  sigax_batch* dev = nullptr;
-  if (sigax_batch_create(_fmi->handle(), (uint32_t)per, 0, 0, &dev) != SIGAX_OK) {
-    _error = std::string("overlap failed: ") + sigax_last_error();
-    return false;
-  }
-  std::vector<sigax_edge> edges;
-  std::string seqs, text;
-  std::vector<uint64_t> offs;
-  for (size_t base = 0; base < n; base += per) {
-    size_t cnt = std::min(per, n - base);
-    seqs.clear();
-    offs.assign(1, 0);
-    for (size_t i = 0; i < cnt; ++i) {
-      seqs += reads[base + i].seq;
-      offs.push_back(seqs.size());
-    }
-    sigax_result res;
-    int rc = sigax_batch_upload(dev, seqs.data(), offs.data(), (uint32_t)cnt, nullptr);
-    if (rc == SIGAX_OK) rc = sigax_batch_run(dev, (uint32_t)base, (uint32_t)minOverlap, flags, nullptr);
-    if (rc == SIGAX_OK) rc = sigax_batch_finish(dev, nullptr, nullptr);
-    if (rc == SIGAX_OK) rc = sigax_batch_download(dev, &res);
-    if (rc != SIGAX_OK) {
-      _error = std::string("overlap failed: ") + sigax_last_error();
-      sigax_batch_destroy(dev);
+  uint32_t maxLen = 0;
+  {
+    std::vector<uint32_t> lengths, ranks;
+    name_ranks(reads, nt, &lengths, &ranks);
+    for (uint32_t l : lengths) maxLen = std::max(maxLen, l);
+    if (n > 0 && sigax_index_set_reads(_fmi->handle(), lengths.data(), ranks.data(), n) != SIGAX_OK) {
+      _error = std::string("failed to load suffix array index: ") + sigax_last_error();
       return false;
     }
-    pt.lap("GPU batch (upload..download)");
-    text.clear();
-    for (size_t i = 0; i < cnt; ++i) write_vertex(text, reads[base + i], res.substring[i] != 0);
-    out.write(text);
-    edges.insert(edges.end(), res.edges, res.edges + res.n_edges);
-    sigax_result_free(&res);
-    pt.lap("VT lines");
   }
-  sigax_batch_destroy(dev);
-  text.clear();
-  for (const sigax_edge& e : edges) {
-    write_edge(text, e, reads);
-    if (text.size() > (1 << 22)) {
-      out.write(text);
-      text.clear();
+  pt.lap("read info (name ranks)");
+  const uint32_t flags = SIGAX_EDGES | (_irreducible ? SIGAX_IRREDUCIBLE : 0u) | (_rc ? SIGAX_RC : 0u);
+  // the GPUs of this run: the loaded index on the first, device-to-device replicas on the others
+  sigax_index_info inf;
+  sigax_index_info_get(_fmi->handle(), &inf);
+  const std::vector<int> devs = device_list(inf.device, _gpus);
+  std::vector<sigax_index*> idx(devs.size(), nullptr);
+  idx[0] = _fmi->handle();
+  auto drop_replicas = [&] {
+    for (size_t k = 1; k < idx.size(); ++k)
+      if (idx[k]) sigax_index_close(idx[k]);
+  };
+  for (size_t k = 1; k < devs.size(); ++k) {
+    if (sigax_index_clone(_fmi->handle(), devs[k], &idx[k]) != SIGAX_OK) {
+      _error = std::string("failed to replicate the index on GPU ") + std::to_string(devs[k]) + ": " + sigax_last_error();
+      drop_replicas();
+      return false;
     }
   }
-  out.write(text);
+  if (devs.size() > 1) pt.lap("index replicas");
+  // device batches: as many reads as the free memory of a GPU takes with two batches in flight, at most 2^20, and no
+  // more than an even share of the input; the reference's threads x batch-size is a lower bound
+  uint32_t hint = 1u << 20;
+  if (n > 0 && sigax_batch_size_hint(idx[0], std::max(maxLen, 1u), (uint32_t)minOverlap, flags, 2, &hint) != SIGAX_OK) {
+    _error = std::string("overlap failed: ") + sigax_last_error();
+    drop_replicas();
+    return false;
+  }
+  size_t per = std::min<size_t>(hint, 1u << 20);
+  if (const char* env = getenv("SIGA_BATCH_READS")) per = std::min<size_t>(hint, std::max<size_t>(strtoull(env, nullptr, 10), 1));
+  per = std::min(per, std::max<size_t>((n + devs.size() - 1) / devs.size(), 1));
+  if (!getenv("SIGA_BATCH_READS")) per = std::max(per, std::min<size_t>(std::max<size_t>(threads, 1) * std::max<size_t>(batch, 1), hint));
+  per = std::max<size_t>(per, 1);
+  const size_t nbatch = (n + per - 1) / per;
+  Pipeline pl;
+  pl.out.resize(nbatch);
+  auto worker = [&](size_t w) {
+    sigax_index* ix = idx[w];
+    sigax_batch* bt[2] = {nullptr, nullptr};
+    void* st[2] = {nullptr, nullptr};
+    size_t cur[2] = {0, 0};
+    bool busy[2] = {false, false};
+    std::vector<uint64_t> loffs[2];
+    auto cleanup = [&] {
+      for (int k = 0; k < 2; ++k) {
+        if (bt[k]) sigax_batch_destroy(bt[k]);
+        if (st[k]) sigax_stream_destroy(devs[w], st[k]);
+      }
+    };
+    for (int k = 0; k < 2; ++k) {
+      if (sigax_stream_create(devs[w], &st[k]) != SIGAX_OK || sigax_batch_create(ix, (uint32_t)per, 0, maxLen, &bt[k]) != SIGAX_OK) {
+        pl.fail(std::string("overlap failed: ") + sigax_last_error());
+        cleanup();
+        return;
+      }
+    }
+    auto submit = [&](int k) -> bool {
+      const size_t b = pl.next.fetch_add(1);
+      if (b >= nbatch || pl.failed) return false;
+      const size_t lo = b * per, cnt = std::min(per, n - lo);
+      loffs[k].resize(cnt + 1);
+      const uint64_t base = reads.offs[lo];
+      for (size_t i = 0; i <= cnt; ++i) loffs[k][i] = reads.offs[lo + i] - base;
+      int rc = sigax_batch_upload(bt[k], reads.seqs.data() + base, loffs[k].data(), (uint32_t)cnt, st[k]);
+      if (rc == SIGAX_OK) rc = sigax_batch_run(bt[k], (uint32_t)lo, (uint32_t)minOverlap, flags, st[k]);
+      if (rc != SIGAX_OK) {
+        pl.fail(std::string("overlap failed: ") + sigax_last_error());
+        return false;
+      }
+      cur[k] = b;
+      busy[k] = true;
+      return true;
+    };
+    auto collect = [&](int k) -> bool {
+      BatchOut r;
+      const size_t lo = cur[k] * per, cnt = std::min(per, n - lo);
+      r.substring.resize(cnt);
+      int rc = sigax_batch_finish(bt[k], st[k], nullptr);
+      if (rc == SIGAX_OK) rc = sigax_batch_download_edges(bt[k], r.substring.data(), &r.edges, &r.n_edges);
+      busy[k] = false;
+      if (rc != SIGAX_OK) {
+        pl.fail(std::string("overlap failed: ") + sigax_last_error());
+        return false;
+      }
+      r.ready = true;
+      {
+        std::lock_guard<std::mutex> g(pl.mu);
+        pl.out[cur[k]] = std::move(r);
+      }
+      pl.cv.notify_all();
+      return true;
+    };
+    submit(0);
+    submit(1);
+    int k = 0;  // the older of the two runs
+    while (busy[k] && !pl.failed) {
+      if (!collect(k)) break;
+      submit(k);
+      k ^= 1;
+    }
+    cleanup();
+  };
+  std::vector<std::thread> workers;
+  for (size_t w = 0; w < devs.size(); ++w) workers.emplace_back(worker, w);
+  // ordered post-processing (OverlapPostProcess, src/overlap_builder.cpp:291-329): VT lines of batch b
+  std::vector<std::pair<sigax_edge*, uint64_t>> edges;
+  const size_t vt_chunk = 4096;
+  for (size_t b = 0; b < nbatch; ++b) {
+    BatchOut r;
+    {
+      std::unique_lock<std::mutex> g(pl.mu);
+      pl.cv.wait(g, [&] { return pl.out[b].ready || pl.failed; });
+      if (!pl.out[b].ready) break;
+      r = std::move(pl.out[b]);
+    }
+    const size_t lo = b * per, cnt = std::min(per, n - lo);
+    std::vector<std::string> parts((cnt + vt_chunk - 1) / vt_chunk);
+    parallel_for(parts.size(), nt, [&](size_t c) {
+      const size_t cb = c * vt_chunk, ce = std::min(cnt, cb + vt_chunk);
+      std::string& o = parts[c];
+      o.reserve((ce - cb) * (maxLen + 32));
+      for (size_t i = cb; i < ce; ++i) write_vertex(o, reads.name(lo + i), reads.comment(lo + i), reads.seq(lo + i), r.substring[i] != 0);
+    });
+    out.write_parts(parts);
+    edges.emplace_back(r.edges, r.n_edges);
+  }
+  for (auto& t : workers) t.join();
+  drop_replicas();
+  auto free_edges = [&] {
+    for (auto& e : edges) sigax_free(e.first);
+    for (auto& o : pl.out)
+      if (o.edges) sigax_free(o.edges);
+  };
+  if (pl.failed) {
+    _error = pl.error;
+    free_edges();
+    return false;
+  }
+  pt.lap("GPU batches + VT lines");
+  // ED lines in hits order (Hit2OverlapConverter, src/overlap_builder.cpp:345-375 + :474-483)
+  const size_t ed_chunk = 16384;
+  for (auto& eb : edges) {
+    std::vector<std::string> parts((eb.second + ed_chunk - 1) / ed_chunk);
+    parallel_for(parts.size(), nt, [&](size_t c) {
+      const uint64_t cb = c * ed_chunk, ce = std::min<uint64_t>(eb.second, cb + ed_chunk);
+      std::string& o = parts[c];
+      o.reserve((ce - cb) * 56);
+      for (uint64_t i = cb; i < ce; ++i) write_edge(o, eb.first[i], reads);
+    });
+    out.write_parts(parts);
+  }
+  free_edges();
   if (!out.close()) {
     _error = "Failed to write ASQG " + output;
     return false;
@@ -1014,6 +1522,23 @@ int sigah_index_file(const char* reads_path, const char* prefix, int threads, ch
   return sigah_index_build(seqs.data(), offs.data(), reads.size(), prefix, threads, err, errcap);
 }
 
+// `siga overlap`: FMIndex::load + OverlapBuilder::build, reads sharded over `gpus` GPUs starting at `device`
+int sigah_overlap_file_gpus(const char* reads_path, const char* prefix, uint64_t min_overlap, const char* output, int irreducible,
+                            int rc, uint64_t threads, uint64_t batch, int device, int gpus, char* err, uint64_t errcap) {
+  sigah::FMIndex fmi;
+  if (!sigah::FMIndex::load(prefix, fmi, device)) {
+    if (err && errcap) snprintf(err, errcap, "Failed to load FMIndex from %s: %s", prefix, sigax_last_error());
+    return -1;
+  }
+  sigah::OverlapBuilder builder(&fmi, prefix, irreducible != 0, rc != 0);
+  builder.setGPUs(gpus);
+  if (!builder.build(reads_path, min_overlap, output, threads, batch)) {
+    if (err && errcap) snprintf(err, errcap, "%s", builder.error().c_str());
+    return -1;
+  }
+  return 0;
+}
+
 // `siga overlap`: FMIndex::load + OverlapBuilder::build
 int sigah_overlap_file(const char* reads_path, const char* prefix, uint64_t min_overlap, const char* output, int irreducible,
                        int rc, uint64_t threads, uint64_t batch, int device, char* err, uint64_t errcap) {
@@ -1062,6 +1587,37 @@ int sigah_correct_file(const char* reads_path, const char* prefix, const char* o
     return -1;
   }
   return 0;
+}
+
+// test hook: parse a reads file with the parallel loader (mode 0) or the record-at-a-time DNASeqReader (mode 1) and dump
+// "name\tcomment\tseq\tquality\n" per read; returns the number of reads or -1
+int64_t sigah_parse_file(const char* path, int mode, const char* out_path, int threads) {
+  FILE* f = fopen(out_path, "wb");
+  if (!f) return -1;
+  int64_t n = -1;
+  if (mode == 0) {
+    sigah::ReadStore rs;
+    if (sigah::LoadReads(path, &rs, (unsigned)std::max(threads, 1))) {
+      n = (int64_t)rs.size();
+      for (size_t i = 0; i < rs.size(); ++i) {
+        std::string line;
+        line.append(rs.name(i)); line += '\t'; line.append(rs.comment(i)); line += '\t'; line.append(rs.seq(i)); line += '\t';
+        line.append(rs.quality(i)); line += '\n';
+        fwrite(line.data(), 1, line.size(), f);
+      }
+    }
+  } else {
+    sigah::DNASeqList reads;
+    if (sigah::ReadDNASequences(path, reads)) {
+      n = (int64_t)reads.size();
+      for (auto& r : reads) {
+        std::string line = r.name + "\t" + r.comment + "\t" + r.seq + "\t" + r.quality + "\n";
+        fwrite(line.data(), 1, line.size(), f);
+      }
+    }
+  }
+  fclose(f);
+  return n;
 }
 
 // Utils::ofstream as used for <prefix>.asqg.gz: write `n` bytes in `pieces` write() calls (gz when the name ends with .gz)

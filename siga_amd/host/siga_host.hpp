@@ -83,7 +83,9 @@ class FMIndex {
 class OverlapBuilder {
  public:
   OverlapBuilder(const FMIndex* fmi, const std::string& prefix = "default", bool irreducible = true, bool rc = true)
-      : _fmi(fmi), _prefix(prefix), _irreducible(irreducible), _rc(rc) {}
+      : _fmi(fmi), _prefix(prefix), _irreducible(irreducible), _rc(rc), _gpus(1) {}
+  // reads shard over `n` GPUs of the node, starting at the index's device; the index is replicated device to device
+  void setGPUs(int n) { _gpus = n < 1 ? 1 : n; }
 
   // HT, VT (input order), ED (hits order) to `output` (gz when the name ends with .gz).  `threads` is accepted for
   // signature compatibility (the GPU replaces the OpenMP loop); `batch` = reads per device batch.
@@ -103,6 +105,7 @@ class OverlapBuilder {
   std::string _prefix;
   bool _irreducible;
   bool _rc;
+  int _gpus;
   mutable std::string _error;
 };
 

@@ -49,7 +49,8 @@ static int overlap_help() {
          "      -p, --prefix=PREFIX              write index to file using PREFIX instead of prefix of READSFILE\n"
          "      -x, --exhaustive                 output all overlaps, including transitive edges\n"
          "          --no-opposite-strand         treat all reads as forward strand\n"
-         "          --device=NUM                 GPU to use (default: 0)\n"
+         "          --device=NUM                 first GPU to use (default: 0)\n"
+         "          --gpus=NUM                   shard the reads over NUM GPUs of this node, index replicated on each (default: 1)\n"
          "\n");
   return 256;
 }
@@ -98,18 +99,18 @@ static int run_index(int argc, char** argv) {
 }
 
 static int run_overlap(int argc, char** argv) {
-  enum { OPT_BATCH_SIZE = 1, OPT_NO_RC, OPT_DEVICE };
+  enum { OPT_BATCH_SIZE = 1, OPT_NO_RC, OPT_DEVICE, OPT_GPUS };
   static const option longopts[] = {{"log4cxx", required_argument, nullptr, 'c'},     {"ini", required_argument, nullptr, 's'},
                                     {"prefix", required_argument, nullptr, 'p'},      {"threads", required_argument, nullptr, 't'},
                                     {"batch-size", required_argument, nullptr, OPT_BATCH_SIZE},
                                     {"min-overlap", required_argument, nullptr, 'm'}, {"exhaustive", no_argument, nullptr, 'x'},
                                     {"no-opposite-strand", no_argument, nullptr, OPT_NO_RC},
-                                    {"device", required_argument, nullptr, OPT_DEVICE}, {"help", no_argument, nullptr, 'h'},
-                                    {nullptr, 0, nullptr, 0}};
+                                    {"device", required_argument, nullptr, OPT_DEVICE}, {"gpus", required_argument, nullptr, OPT_GPUS},
+                                    {"help", no_argument, nullptr, 'h'}, {nullptr, 0, nullptr, 0}};
   std::string prefix;
   size_t threads = 1, batch = 10000, minOverlap = 10;  // code defaults of src/overlap.cpp:44
   bool exhaustive = false, norc = false, help = false;
-  int device = 0, c;
+  int device = 0, gpus = 1, c;
   while ((c = getopt_long(argc, argv, "c:s:t:p:m:xh", longopts, nullptr)) != -1) {
     switch (c) {
       case 'p': prefix = optarg; break;
@@ -119,6 +120,7 @@ static int run_overlap(int argc, char** argv) {
       case OPT_BATCH_SIZE: batch = strtoull(optarg, nullptr, 10); break;
       case OPT_NO_RC: norc = true; break;
       case OPT_DEVICE: device = atoi(optarg); break;
+      case OPT_GPUS: gpus = atoi(optarg); break;
       case 'h': help = true; break;
       default: break;
     }
@@ -132,6 +134,7 @@ static int run_overlap(int argc, char** argv) {
     return -1;
   }
   sigah::OverlapBuilder builder(&fmi, prefix, !exhaustive, !norc);
+  builder.setGPUs(gpus);
   if (!builder.build(input, minOverlap, prefix + ".asqg.gz", threads, batch)) {
     fprintf(stderr, "Failed to build overlaps from reads %s: %s\n", input.c_str(), builder.error().c_str());
     return -1;

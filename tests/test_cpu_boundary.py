@@ -140,3 +140,59 @@ def test_gzip_writer_single_member_roundtrip(tmp_path):
     plain = str(tmp_path / "x.txt")
     host.write_file(plain, line * 10, 3)
     assert open(plain, "rb").read() == line * 10
+
+
+def test_parallel_loader_equals_record_reader(tmp_path):
+    """The chunk-parallel FASTA loader and the serial FASTQ walk of the host library give the records of the
+    record-at-a-time reader (src/kseq.cpp:140-228 semantics), quirks included: blank and padded lines, multi-line
+    sequences, comments, a named record without sequence (the reader gives up there), a header without text (its
+    sequence leaks into the next record), gz input."""
+    import gzip
+    import random
+    rnd = random.Random(4)
+
+    def seq(n):
+        return "".join(rnd.choice("ACGT") for _ in range(n))
+
+    big = []
+    for i in range(30000):
+        s = seq(rnd.choice([30, 70, 151]))
+        body = s if i % 3 else s[:20] + "\n  " + s[20:] + "  \n\n"
+        big.append(">r%d%s\n%s\n" % (i, " BX:Z:AC CR:i:%d" % i if i % 11 == 0 else ("\tx" if i % 13 == 0 else ""), body))
+    cases = {
+        "big.fa": "".join(big),
+        "stop.fa": "".join(big[:20000]) + ">empty\n>after\nACGT\n" + "".join(big[20000:]),
+        "nameless.fa": "".join(big[:500]) + ">\nAAAA\n>next\nCCCC\n" + "".join(big[500:900]),
+        "spaces.fa": " >x y\n AC GT \n\n\r\n>z\nTT\n",
+        "tail.fa": "".join(big[:100]) + ">last",
+        "reads.fq": "".join("@q%d%s\n%s\n+%s\n%s\n" % (i, " c" if i % 5 == 0 else "", s, "q%d%s" % (i, " c" if i % 5 == 0 else "") if i % 2 else "",
+                                                          "I" * len(s)) for i, s in ((i, seq(50 + i % 7)) for i in range(5000))),
+        "bad.fq": "@a\nACGT\n+\nIIII\n@b\nACGT\n+\nIII\n@c\nAC\n+\nII\n",
+    }
+    for name, text in cases.items():
+        path = str(tmp_path / name)
+        open(path, "w").write(text)
+        for p in (path, path + ".gz"):
+            if p.endswith(".gz"):
+                with gzip.open(p, "wb") as f:
+                    f.write(text.encode())
+            na = host.parse_file(p, str(tmp_path / "a.txt"), parallel=True, threads=7)
+            nb = host.parse_file(p, str(tmp_path / "b.txt"), parallel=False)
+            assert na == nb, (name, na, nb)
+            assert open(tmp_path / "a.txt", "rb").read() == open(tmp_path / "b.txt", "rb").read(), name
+    assert host.parse_file(str(tmp_path / "stop.fa"), str(tmp_path / "a.txt")) == 20000
+    assert host.parse_file(str(tmp_path / "bad.fq"), str(tmp_path / "a.txt")) == 1
+
+
+def test_gzip_writer_bytes_do_not_depend_on_the_call_pattern(tmp_path):
+    import gzip
+    import random
+    rnd = random.Random(1)
+    data = bytes(rnd.getrandbits(8) & 0x3F | 0x40 for _ in range(3 * (1 << 20) + 12345))
+    outs = []
+    for pieces in (1, 7, 1000):
+        p = str(tmp_path / ("w%d.gz" % pieces))
+        host.write_file(p, data, pieces=pieces)
+        outs.append(open(p, "rb").read())
+        assert gzip.decompress(outs[-1]) == data
+    assert outs[0] == outs[1] == outs[2]
