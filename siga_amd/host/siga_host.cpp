@@ -756,7 +756,9 @@ class OutFile {
   explicit OutFile(const std::string& path, unsigned threads = 0) : _f(nullptr), _gz(false), _crc(0), _total(0), _nt(threads) {
     _gz = path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
     _f = fopen(path.c_str(), "wb");
-    if (_nt == 0) _nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32);
+    // deflate at level 6 makes ~12 MB/s per thread on read text: the writer takes up to 128 threads whatever -t says
+    _nt = std::max(_nt, std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 128));
+    if (const char* env = getenv("SIGA_HOST_THREADS")) _nt = std::max(1, atoi(env));
     if (_f && _gz) {
       static const unsigned char hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
       fwrite(hdr, 1, 10, _f);
@@ -848,10 +850,22 @@ class OutFile {
 
  private:
   static const size_t kBlock = 1 << 20, kFlush = 64u << 20;
+  // Level 4 by default: on read text (four-letter sequences with little to match inside a 32 KiB window) zlib's level 6,
+  // what the reference's gzip filter uses, makes 10 MB/s per thread for a file 5 % smaller than level 4 at 62 MB/s; with
+  // the kernels done in milliseconds the deflate of the VT lines was the longest phase of `siga overlap`.
+  // SIGA_GZIP_LEVEL=6 restores the reference's setting.
+  static int gzip_level() {
+    static const int level = [] {
+      const char* env = getenv("SIGA_GZIP_LEVEL");
+      int l = env ? atoi(env) : 4;
+      return l < 1 || l > 9 ? 4 : l;
+    }();
+    return level;
+  }
   static void deflate_block(const char* in, size_t n, bool last, std::string* out, uLong* crc) {
     z_stream z;
     memset(&z, 0, sizeof(z));
-    deflateInit2(&z, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    deflateInit2(&z, gzip_level(), Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
     out->resize(deflateBound(&z, (uLong)n) + 16);
     z.next_in = (Bytef*)in;
     z.avail_in = (uInt)n;
@@ -1050,6 +1064,23 @@ struct Pipeline {
 };
 }  // namespace
 
+}  // namespace sigah
+struct sigah::OverlapBuilder::Preloaded {
+  std::string path;
+  ReadStore reads;
+  std::vector<uint32_t> lengths, ranks;
+  bool ok = false;
+};
+namespace sigah {
+void OverlapBuilder::preload(const std::string& input, size_t threads) const {
+  const unsigned nt = host_threads(threads);
+  auto p = std::make_shared<Preloaded>();
+  p->path = input;
+  p->ok = LoadReads(input, &p->reads, nt);
+  if (p->ok) name_ranks(p->reads, nt, &p->lengths, &p->ranks);
+  _pre = p;
+}
+
 static std::vector<int> device_list(int first, int count) {
   // SIGA_DEVICE_MAP=0,0,...: logical GPU k of the run is physical device map[k] (rehearsing --gpus N on fewer GPUs)
   std::vector<int> map;
@@ -1075,12 +1106,20 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
     return false;
   }
   const unsigned nt = host_threads(threads);
-  ReadStore reads;
-  if (!LoadReads(input, &reads, nt)) {
+  std::shared_ptr<Preloaded> pre = _pre;
+  _pre.reset();
+  if (!pre || pre->path != input) {
+    pre = std::make_shared<Preloaded>();
+    pre->path = input;
+    pre->ok = LoadReads(input, &pre->reads, nt);
+    if (pre->ok) name_ranks(pre->reads, nt, &pre->lengths, &pre->ranks);
+  }
+  if (!pre->ok) {
     _error = "Failed to read file " + input;
     return false;
   }
-  pt.lap("parse reads");
+  ReadStore& reads = pre->reads;
+  pt.lap("parse reads + name ranks");
   OutFile out(output, nt);
   if (!out.ok()) {
     _error = "Failed to create ASQG " + output;
@@ -1090,16 +1129,12 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
   out.write("HT\tVN:i:1\tOL:i:" + std::to_string((int)minOverlap) + "\tCN:i:1\n");
   const size_t n = reads.size();
   uint32_t maxLen = 0;
-  {
-    std::vector<uint32_t> lengths, ranks;
-    name_ranks(reads, nt, &lengths, &ranks);
-    for (uint32_t l : lengths) maxLen = std::max(maxLen, l);
-    if (n > 0 && sigax_index_set_reads(_fmi->handle(), lengths.data(), ranks.data(), n) != SIGAX_OK) {
-      _error = std::string("failed to load suffix array index: ") + sigax_last_error();
-      return false;
-    }
+  for (uint32_t l : pre->lengths) maxLen = std::max(maxLen, l);
+  if (n > 0 && sigax_index_set_reads(_fmi->handle(), pre->lengths.data(), pre->ranks.data(), n) != SIGAX_OK) {
+    _error = std::string("failed to load suffix array index: ") + sigax_last_error();
+    return false;
   }
-  pt.lap("read info (name ranks)");
+  pt.lap("read info to the device");
   const uint32_t flags = SIGAX_EDGES | (_irreducible ? SIGAX_IRREDUCIBLE : 0u) | (_rc ? SIGAX_RC : 0u);
   // the GPUs of this run: the loaded index on the first, device-to-device replicas on the others
   sigax_index_info inf;
@@ -1155,9 +1190,15 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
         return;
       }
     }
+    const bool timing = getenv("SIGA_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double>(b - a).count();
+    };
     auto submit = [&](int k) -> bool {
       const size_t b = pl.next.fetch_add(1);
       if (b >= nbatch || pl.failed) return false;
+      const auto t0 = now();
       const size_t lo = b * per, cnt = std::min(per, n - lo);
       loffs[k].resize(cnt + 1);
       const uint64_t base = reads.offs[lo];
@@ -1170,14 +1211,18 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
       }
       cur[k] = b;
       busy[k] = true;
+      if (timing) fprintf(stderr, "[siga]   gpu %d batch %zu: upload + enqueue %.3f s\n", devs[w], b, secs(t0, now()));
       return true;
     };
     auto collect = [&](int k) -> bool {
       BatchOut r;
       const size_t lo = cur[k] * per, cnt = std::min(per, n - lo);
       r.substring.resize(cnt);
+      const auto t0 = now();
       int rc = sigax_batch_finish(bt[k], st[k], nullptr);
+      const auto t1 = now();
       if (rc == SIGAX_OK) rc = sigax_batch_download_edges(bt[k], r.substring.data(), &r.edges, &r.n_edges);
+      if (timing) fprintf(stderr, "[siga]   gpu %d batch %zu: wait %.3f s, download %.3f s\n", devs[w], cur[k], secs(t0, t1), secs(t1, now()));
       busy[k] = false;
       if (rc != SIGAX_OK) {
         pl.fail(std::string("overlap failed: ") + sigax_last_error());
@@ -1213,16 +1258,21 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
       pl.cv.wait(g, [&] { return pl.out[b].ready || pl.failed; });
       if (!pl.out[b].ready) break;
       r = std::move(pl.out[b]);
+      pl.out[b].edges = nullptr;  // owned by `edges` from here on
     }
     const size_t lo = b * per, cnt = std::min(per, n - lo);
     std::vector<std::string> parts((cnt + vt_chunk - 1) / vt_chunk);
+    const auto tv0 = std::chrono::steady_clock::now();
     parallel_for(parts.size(), nt, [&](size_t c) {
       const size_t cb = c * vt_chunk, ce = std::min(cnt, cb + vt_chunk);
       std::string& o = parts[c];
       o.reserve((ce - cb) * (maxLen + 32));
       for (size_t i = cb; i < ce; ++i) write_vertex(o, reads.name(lo + i), reads.comment(lo + i), reads.seq(lo + i), r.substring[i] != 0);
     });
+    const auto tv1 = std::chrono::steady_clock::now();
     out.write_parts(parts);
+    if (pt.on) fprintf(stderr, "[siga]   batch %zu: VT text %.3f s, deflate + write %.3f s\n", b, std::chrono::duration<double>(tv1 - tv0).count(),
+                       std::chrono::duration<double>(std::chrono::steady_clock::now() - tv1).count());
     edges.emplace_back(r.edges, r.n_edges);
   }
   for (auto& t : workers) t.join();
