@@ -1278,6 +1278,15 @@ struct SideSh {
 #define FXP(i) do { } while (0)
 #endif
 
+// scratch of the 64-lane launch for items of 65..256 blocks (four per lane): bounds / sorted entries
+#define FX_BIGCAP 256
+template <bool WIDE>
+struct BigSh {
+  typedef typename PosOf<WIDE>::type P;
+  P b0[FX_BIGCAP], b1[FX_BIGCAP], b2[FX_BIGCAP], b3[FX_BIGCAP];
+  u32 bsrc[FX_BIGCAP], blen[FX_BIGCAP];
+};
+
 __device__ __forceinline__ u64 readlane64(u64 v, u32 l) {
   u32 lo = __builtin_amdgcn_readlane((u32)v, l), hi = __builtin_amdgcn_readlane((u32)(v >> 32), l);
   return ((u64)hi << 32) | lo;
@@ -1331,6 +1340,7 @@ struct GFx {
   SideSh<WIDE>& sh;
   FmRef F, R;
   Ent* wpool;  // FX_NSLOT group slots of 64 entries (branch copies only), shared by the wave's lane groups
+  BigSh<WIDE>* big;  // 64-lane launch only: scratch for items of more than 64 blocks
   const Find2Tables* t2;  // constants of the two-step table, or NULL when the index has none
   u32 lane;    // lane in the wave
   u32 gb;      // first lane of this lane's group (0, or 32 for the second group when W == 32)
@@ -1343,7 +1353,7 @@ struct GFx {
   u64 fin_cur, fin_end;  // this wave's chunk of the unordered final-block arena (wave-uniform)
 
   __device__ GFx(const FxArgs& a, const FmTables& t, SideSh<WIDE>& s, Ent* wp, const Find2Tables* tt)
-      : A(a), tb(t), sh(s), F(fm_ref(a.fwd, 0)), R(fm_ref(a.rev, 1)), wpool(wp), t2(tt), lane(threadIdx.x & 63u),
+      : A(a), tb(t), sh(s), F(fm_ref(a.fwd, 0)), R(fm_ref(a.rev, 1)), wpool(wp), big(nullptr), t2(tt), lane(threadIdx.x & 63u),
         gb(W == 64 ? 0u : (threadIdx.x & 32u)), gl(W == 64 ? (threadIdx.x & 63u) : (threadIdx.x & 31u)),
         glt((1ull << (W == 64 ? (threadIdx.x & 63u) : (threadIdx.x & 31u))) - 1ull), slots(nullptr), nout(0), nocc(0),
         xerror(false), fin_cur(0), fin_end(0), nslot(1), ni(0), gAlive(0), gD(0), gI(0) {}
@@ -1884,7 +1894,10 @@ struct GFx {
     const u32 c2 = (cc[2] & SIGAX_CC_CONTAIN) ? 1u : 0u, c3 = (cc[3] & SIGAX_CC_CONTAIN) ? 1u : 0u;
     // list X = find A's blocks + containfwd {0,1}; list Y = find B's blocks + containrev {2,3} (:1137-1140)
     const u32 nX = nA + c0 + c1, nY = nB + c2 + c3, T = nX + nY;
-    if (T > (u32)W) return false;
+    if (T > (u32)W) {
+      if (W == 64 && big != nullptr && T <= FX_BIGCAP && A.irreducible) return body_big(L, chA, chB, nA, nB, c0, c2, nX, T);
+      return false;
+    }
     if (T == 0) return true;
     FXP(6);
     if (T <= 16) FXP(7);
@@ -1974,6 +1987,187 @@ struct GFx {
     return true;
   }
 
+  // An item of 65..256 blocks on the 64-lane group, four blocks per lane (deep coverage: at 54x and 250 bp a side holds
+  // 44 blocks on average and a few reads in a thousand pass 64).  Same prologue as body(); the extraction handles the
+  // single-group case only -- every block's range inside one granule, one common next symbol per round until the
+  // top-level blocks end -- and hands anything else (intersecting blocks, a branch, a range across granules) to the
+  // general kernel by returning false.  Without this such items ran on ONE lane each and took longer than the rest of
+  // the batch together.
+  __device__ bool body_big(u32 L, u32 chA, u32 chB, u32 nA, u32 nB, u32 c0, u32 c2, u32 nX, u32 T) {
+    BigSh<WIDE>& bs = *big;
+    E e[4];
+    bool act[4], member[4];
+    u32 nm = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32 i = lane + 64u * k;
+      act[k] = i < T;
+      e[k].c0lo = e[k].c0hi = e[k].c1lo = e[k].c1hi = 0; e[k].src = 0; e[k].len = 0;
+      if (act[k]) {
+        const u32 list = i >= nX ? 1u : 0u, kk = list ? i - nX : i;
+        u32 ch;
+        if (!list) ch = kk < nA ? chA : ((kk == nA && c0) ? 0u : 1u);
+        else ch = kk < nB ? chB : ((kk == nB && c2) ? 2u : 3u);
+        const u32 inchain = (!list ? kk < nA : kk < nB) ? kk : A.cap - 1;
+        load_block(e[k], (ch << 30) | (ch * A.cap + inchain));
+        bs.b0[i] = e[k].c0lo;
+        bs.b1[i] = e[k].c0hi;
+        bs.blen[i] = e[k].len;
+      }
+      member[k] = act[k] && e[k].len != L;  // ContainmentBlockRemover (:1094-1111)
+      nm += pop(__ballot(member[k]));
+    }
+    wave_lds_sync();
+    // SubMaximalBlockFilter: any intersecting pair inside a list needs resolve() (see body())
+    bool inter = false;
+    u32 posn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32 i = lane + 64u * k;
+      posn[k] = 0;
+      if (act[k]) {
+        const u32 list = i >= nX ? 1u : 0u, kk = list ? i - nX : i;
+        const u32 jb = list ? nX : 0u, je = list ? T : nX;
+        for (u32 j = jb; j < je; ++j) {
+          const P loj = bs.b0[j], hij = bs.b1[j];
+          inter |= (j != i) & !(e[k].c0lo > hij || loj > e[k].c0hi);  // coord.h:37-40
+        }
+        // position after X += Y and the stable sort by length descending (:715-716,1169): a merge rank, see body()
+        const u32 obase = list ? 0u : nX, on = list ? nA : nB;
+        u32 lo = 0, hi = on;
+        while (lo < hi) {
+          const u32 mid = (lo + hi) >> 1;
+          const u32 lenm = bs.blen[obase + mid];
+          const bool right = list ? (lenm < e[k].len) : (lenm <= e[k].len);
+          if (right) lo = mid + 1; else hi = mid;
+        }
+        posn[k] = ((list ? nB : nA) - 1u - kk) + (on - lo);
+      }
+    }
+    if (__ballot(inter)) return false;
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (member[k]) {
+        const u32 q = posn[k];
+        bs.b0[q] = e[k].c0lo; bs.b1[q] = e[k].c0hi; bs.b2[q] = e[k].c1lo; bs.b3[q] = e[k].c1hi;
+        bs.bsrc[q] = e[k].src; bs.blen[q] = e[k].len;
+      }
+    wave_lds_sync();
+    bool mine[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32 i = lane + 64u * k;
+      mine[k] = i < nm;
+      e[k].c0lo = e[k].c0hi = e[k].c1lo = e[k].c1hi = 0; e[k].src = 0; e[k].len = 0;
+      if (mine[k]) {
+        e[k].c0lo = bs.b0[i]; e[k].c0hi = bs.b1[i]; e[k].c1lo = bs.b2[i]; e[k].c1hi = bs.b3[i];
+        e[k].src = bs.bsrc[i]; e[k].len = bs.blen[i];
+      }
+    }
+    wave_lds_sync();
+    if (nm == 0) return true;
+    // IrreducibleBlockListExtractor::extract (:711-809), one group.  Block 0 (lane 0, k = 0) is the longest.
+    const u32 topLen = __builtin_amdgcn_readfirstlane(e[0].len);
+    u32 ntop = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ntop += pop(__ballot(mine[k] && e[k].len == topLen));
+    for (u32 guard = 0; guard < (1u << 20); ++guard) {
+      bool odd = false, anyEnd = false;  // a block outside the simple case; a top-level block followed by '$'
+      u32 cq[4];
+      P newlo[4];
+      bool x0[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        cq[k] = 0; newlo[k] = 0; x0[k] = false;
+        if (!mine[k]) continue;
+        const FmRef ix = ext_index(e[k].src);
+        const u64 p0 = (u64)e[k].c1lo, p1 = (u64)e[k].c1hi + 1ull;
+        const u64 g0 = p0 >> 7;
+        if (!(p1 > p0 && ((p1 - 1) >> 7) == g0 && p1 <= ix.n)) {
+          odd = true;
+          continue;
+        }
+        const uint4* q = ix.g + g0 * 4;
+        uint4 kq[4];
+        kq[0] = q[0]; kq[1] = q[1]; kq[2] = q[2]; kq[3] = q[3];
+        const int r0 = (int)(p0 & 127u), r1 = (int)(p1 - (g0 << 7));
+        const u32 j0 = (u32)r0 >> 5, bit0 = (u32)r0 & 31u;
+        const u32 ys = j0 == 0 ? kq[0].y : j0 == 1 ? kq[1].y : j0 == 2 ? kq[2].y : kq[3].y;
+        const u32 zs = j0 == 0 ? kq[0].z : j0 == 1 ? kq[1].z : j0 == 2 ? kq[2].z : kq[3].z;
+        const u32 ws = j0 == 0 ? kq[0].w : j0 == 1 ? kq[1].w : j0 == 2 ? kq[2].w : kq[3].w;
+        const u32 fy = 0u - ((ys >> bit0) & 1u), fz = 0u - ((zs >> bit0) & 1u), fw = 0u - ((ws >> bit0) & 1u);
+        u32 diff = 0, cntb = 0, dol = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int lo = min(max(r0 - 32 * j, 0), 32), hi = min(max(r1 - 32 * j, 0), 32), wd = hi - lo;
+          const u32 rm = wd == 32 ? 0xFFFFFFFFu : (((1u << (wd & 31)) - 1u) << (lo & 31));
+          const u32 below = lo == 32 ? 0xFFFFFFFFu : ((1u << (lo & 31)) - 1u);
+          const u32 d = (kq[j].y ^ fy) | (kq[j].z ^ fz) | (kq[j].w ^ fw);
+          diff |= d & rm;
+          cntb += __popc(~d & below);
+          dol |= ~(kq[j].y | kq[j].z | kq[j].w) & rm;
+        }
+        const u32 c = fw ? 4u : ((fy & 1u) | (fz & 2u));
+        const bool qcomp = (af_of(e[k].src) & 4u) != 0;
+        cq[k] = (qcomp && c) ? 5u - c : c;
+        x0[k] = dol != 0;
+        if (diff != 0) odd = true;  // more than one symbol follows this block
+        if (c != 0) {
+          const u32 hdr = c == 1 ? kq[0].x : c == 2 ? kq[1].x : c == 3 ? kq[2].x : kq[3].x;
+          P lbp = (P)(hdr + cntb);
+          if (WIDE) lbp += (P)ix.super[(p0 >> SIGAX_SUPER_SHIFT) * 4 + (c - 1u)];
+          newlo[k] = (P)tb.C[ix.which][c] + lbp;
+        }
+        if (e[k].len == topLen && x0[k]) anyEnd = true;
+      }
+      sec_add(nm);
+      if (__ballot(anyEnd)) {
+        // the top-level blocks have ended (:747-766): they are blocks 0 .. ntop-1; the first one without '$' is the
+        // "substring read found" error and ends the emission
+        u32 fb = ntop;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u64 m = __ballot(mine[k] && e[k].len == topLen && !x0[k]);
+          if (m) fb = min(fb, ffs0(m) + 64u * k);
+        }
+        nocc += 2u * ntop;
+        if (nout + fb > (u32)FX_OUTCAP) return false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u32 i = lane + 64u * k;
+          if (mine[k] && i < fb) {
+            // capped.updateR('$'): Occ('$') at both ends of the range = position minus the A,C,G,T before it
+            const FmRef ix = ext_index(e[k].src);
+            P l[5], u[5];
+            fm_rank5p<WIDE>(ix, e[k].c1lo, l);
+            fm_rank5p<WIDE>(ix, (P)(e[k].c1hi + 1), u);
+            E br = e[k];
+            apply_updateR(br, 0, ix.which, l, u);
+            out_put(nout + i, br);
+          }
+        }
+        nout += fb;
+        if (fb < ntop) xerror = true;
+        return true;
+      }
+      nocc += 2u * nm;
+      const u32 cfirst = __builtin_amdgcn_readfirstlane(cq[0]);
+      bool differ = odd;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) differ = differ || (mine[k] && cq[k] != cfirst);
+      if (cfirst == 0 || __ballot(differ)) return false;  // a branch, '$' below the top level, a range across granules
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (mine[k]) {
+          const P size = e[k].c1hi - e[k].c1lo;
+          e[k].c1lo = newlo[k];
+          e[k].c1hi = newlo[k] + size;
+        }
+    }
+    return false;
+  }
+
   // Both lane groups of the wave together: run the items, then flush their blocks into the wave's chunk of the
   // unordered arena (one atomic per FX_FIN_CHUNK blocks).  `has` = this group has an item; returns done.
   __device__ bool run(bool has, u32 r, u32 sd) {
@@ -2045,6 +2239,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 1 : 
 #endif
   wave_lds_sync();
   GFx<WIDE, W> fx(A, tb, shm[wid], A.wpool + wave * FX_WPOOL, have2 ? &t2 : nullptr);
+  if constexpr (W == 64) {
+    __shared__ BigSh<WIDE> bigsh[4];
+    fx.big = &bigsh[wid];
+  }
   u64 nocc_total = 0, nerr = 0, nsub = 0;
   if (W == 32) {
     const u64 first = 2ull * A.read_begin, last = 2ull * A.read_end;

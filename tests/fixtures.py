@@ -26,6 +26,8 @@ def named_reads(name):
         return mr.dup_reads()
     if name in ("toy", "mid"):
         return mr.survey_reads(*GOLDEN[name]["gen"])
+    if name == "deep":   # 160x coverage: about 110 blocks per (read, side), beyond one wave's 64 lanes
+        return mr.survey_reads(2500, 100, 4000, 21)
     if name == "tiny":   # 400 x 60 bp from 2 kb, 12x
         return mr.survey_reads(2000, 60, 400, 99)
     if name in ("ragged", "ragged_n"):  # mixed lengths incl. reads shorter than min-overlap, duplicates

@@ -64,6 +64,23 @@ def test_hits_and_asqg_bit_exact(sa, name, m, irr, rc):
     assert s["n_edges"] == len(ed_lines(want_asqg))
 
 
+@pytest.mark.parametrize("irr", [True, False])
+def test_deep_coverage_items_bit_exact(sa, irr):
+    """160x coverage: a (read, side) item holds about 110 blocks, more than the 64 lanes of a wave -- the four-blocks-per-
+    lane path of the 64-lane launch (irreducible mode) or the general kernel (exhaustive mode).  Same bytes as the oracle."""
+    from siga_amd.overlap import format_hits
+    fx = fixture("deep")
+    pair = _pair(sa, fx)
+    want_asqg, want_hits, st = fx.oracle_asqg(30, irreducible=irr, hits=True)
+    got_asqg, res = sa.OverlapBuilder(pair, fx.prefix, irreducible=irr).build(fx.fa, 30)
+    assert format_hits(res) == want_hits
+    assert got_asqg == want_asqg
+    s = res["stats"]
+    assert s["n_occ_find"] + s["n_occ_extract"] == st["n_occ_min"]
+    if irr:
+        assert s["n_slow_reads"] < len(fx.reads) // 10, s  # the lane-group path took them, not the one-lane kernel
+
+
 def test_non_acgt_reads_block_parity(sa):
     """Reads holding an N: per-read block lists must still equal the oracle's (no edges: see fixtures.py)."""
     from oracle import pyoracle as po
