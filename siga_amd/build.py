@@ -27,7 +27,7 @@ def build_libsigax(force=False, verbose=False, out=None, defines=()):
     if not force and not _stale(lib, deps):
         return lib
     os.makedirs(os.path.dirname(lib), exist_ok=True)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "-Wno-unused-value",
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "-Wno-unused-value", "-Wno-int-to-void-pointer-cast",
            "-I" + os.path.join(ROOT, "include"), "-o", lib] + ["-D" + d for d in defines] + srcs
     if verbose:
         print(" ".join(cmd))

@@ -305,8 +305,10 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
   {
     const char* env2 = getenv("SIGAX_TWO_STEP");
     const char* envm = getenv("SIGAX_TWO_STEP_MAX_SYMBOLS");
-    u64 max2 = envm ? strtoull(envm, nullptr, 10) : ((1ull << 30) + (1ull << 29));
-    if (max2 > (1ull << 31)) max2 = 1ull << 31;
+    // every index with 32-bit positions: below SIGAX_COOP_MIN_SYMBOLS the finder gathers per lane with u32 byte offsets
+    // (k_find_n2, tables under 4 GiB), above it lines come cooperatively through LDS with 64-bit addresses (k_find_c2)
+    u64 max2 = envm ? strtoull(envm, nullptr, 10) : 0xFFFFFFF0ull;
+    if (max2 > 0xFFFFFFF0ull) max2 = 0xFFFFFFF0ull;
     const bool want2 = !ix->wide && n_symbols < max2 && !(env2 && env2[0] == '0');
     if (want2) {
       const u64 ng2 = n_symbols / SIGAX_GRAN2_SYMS + 1;
@@ -846,6 +848,18 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.read_end = re;
     fa.stage_bytes = 0;  // set by launch_find
     fa.two_step = (ix->st[0].gran2 && ix->st[1].gran2) ? 1u : 0u;
+    {
+      static const char* env_coop = getenv("SIGAX_FIND_COOP");
+      static const char* env_cmin = getenv("SIGAX_COOP_MIN_SYMBOLS");
+      const u64 coop_min = env_cmin ? strtoull(env_cmin, nullptr, 10) : (1ull << 30);
+      const u64 need = 64ull * b->cur_max_len + 16;  // the workgroup's 64 reads, staged as bytes
+      const bool can = fa.two_step && !ix->wide && need <= 32768;
+      const bool want = env_coop ? env_coop[0] != '0' : ix->n_symbols >= coop_min;
+      fa.coop = (can && want) ? 1u : 0u;
+      fa.coop_stage_bytes = (uint32_t)((need + 15) & ~15ull);
+      // per-lane gathers use 32-bit byte offsets into the two-step table: beyond 2^31 symbols only the cooperative form works
+      if (fa.two_step && !fa.coop && ix->n_symbols >= (1ull << 31)) fa.two_step = 0;
+    }
     fa.arena = b->arena.p;
     fa.chain_cnt = (uint32_t*)b->chain_cnt.p;
     fa.dstat = dstat;
@@ -857,8 +871,8 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     // Without the two-step tables (indexes of 1.6 G symbols and more) the same split keeps one launch's gathers inside one
     // strand's granule table once the two tables together pass the translation reach (profiles/r01_gather_probe.txt).
     const bool big_one_step = !fa.two_step && ix->n_symbols >= (1ull << 30);
-    const bool split = (env_split ? env_split[0] != '0' : ((fa.two_step && ix->split_strands) || big_one_step)) &&
-                       128ull * b->cur_max_len + 8 <= find_stage_capacity();
+    const bool split = fa.coop || ((env_split ? env_split[0] != '0' : ((fa.two_step && ix->split_strands) || big_one_step)) &&
+                                   128ull * b->cur_max_len + 8 <= find_stage_capacity());
     b->find_per_sub = split ? 2u : 1u;
     if (split) {
       // one launch per strand's two-step table (chains 0,1 gather from the forward index, 2,3 from the reverse one)

@@ -430,6 +430,42 @@ __device__ __forceinline__ void find_step2_loads(const void* base, u32 offa, u32
       : "v"(offa), "v"(offa_c), "v"(offb), "v"(offb_c), "s"(base)
       : "memory");
 }
+// The same through LDS, cooperatively (the finder for tables beyond the translation reach of per-lane gathers): eight
+// lanes fetch the eight 16-byte pieces of ONE 128-byte line with one instruction that writes LDS directly
+// (global_load_lds_dwordx4: destination = wave-uniform base + lane x 16), so a wave instruction touches 8 lines instead
+// of 64 and a double step costs 16 such instructions for the wave's 64 chains x 2 lines.  Then every lane reads the five
+// pieces it needs of its own two lines.  Slot of (chain 8t + j, piece p) in instruction t's 1 KiB: (p ^ (t & 1)) * 8 + j,
+// which spreads the sixteen lanes of a ds_read_b128 group over the sixteen 16-byte bank groups.
+// la / lb = line index of the lane's lower / upper position (any valid line for idle lanes), c = first symbol (1..4).
+__device__ __forceinline__ void find_step2_dma(const uint32_t* gran2, u32 la, u32 lb, u32 c, uint4* stage, u32 lane, Gran2& a, Gran2& b) {
+  const u32 j = lane & 7u, pp = lane >> 3;
+  const char* base = reinterpret_cast<const char*>(gran2);
+  // the records parked by the previous step have been read back (find_flush) before the area is written again
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (u32 t = 0; t < 8; ++t) {
+    const u32 kap = 8u * t + j;
+    const u32 lA = (u32)__shfl((int)la, (int)kap, 64), lB = (u32)__shfl((int)lb, (int)kap, 64);
+    const u32 p = pp ^ (t & 1u);
+    const char* sa = base + (u64)lA * 128u + p * 16u;
+    const char* sb = base + (u64)lB * 128u + p * 16u;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                     (__attribute__((address_space(3))) void*)(u32)(size_t)(stage + t * 64u), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                     (__attribute__((address_space(3))) void*)(u32)(size_t)(stage + 512u + t * 64u), 16, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const u32 tt = lane >> 3, x = tt & 1u;
+  const uint4* qa = stage + tt * 64u + j;
+  const uint4* qb = qa + 512u;
+  auto ld = [](const uint4* q) { const uint4 v = *q; v4u r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; };
+  a.s = ld(qa + ((0u ^ x) * 8u)); a.pc = ld(qa + ((c ^ x) * 8u)); a.p5 = ld(qa + ((5u ^ x) * 8u)); a.p6 = ld(qa + ((6u ^ x) * 8u)); a.p7 = ld(qa + ((7u ^ x) * 8u));
+  b.s = ld(qb + ((0u ^ x) * 8u)); b.pc = ld(qb + ((c ^ x) * 8u)); b.p5 = ld(qb + ((5u ^ x) * 8u)); b.p6 = ld(qb + ((6u ^ x) * 8u)); b.p7 = ld(qb + ((7u ^ x) * 8u));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 struct Rank2 {
   u32 a, c, g, t;      // rows j < p with c1(j) = A, C, G, T
   u32 pa, pc, pg, pt;  // rows j < p with c1(j) = c and c2(j) = A, C, G, T
@@ -474,12 +510,18 @@ __device__ __forceinline__ void find2_tables_load(Find2Tables& t, const FmStrand
 // that row and write the pieces with one store instruction: one 64-byte request per line instead of one 16-byte
 // request per piece (measured at C2: the finder's 160 M scattered piece stores cost 1.8 of its 12.3 ms; the memory
 // system counts requests, not bytes).  `tag` = destination byte address | number of 16-byte pieces to write - 1.
-struct FindStage {
-  uint4 row[256][4];
-  u64 tag[256];
+template <int NT>
+struct FindStageT {  // a half-filled row waits here for the lane's next record, across steps
+  uint4 row_[NT][4];
+  u64 tag_[NT];
+  __device__ __forceinline__ uint4* row(u32 t) { return row_[t]; }
+  __device__ __forceinline__ u64& tag(u32 t) { return tag_[t]; }
 };
+typedef FindStageT<256> FindStage;
+typedef FindStageT<128> FindStageC;
 
-__device__ __forceinline__ void find_flush(FindStage& sg, bool want, u32 tid) {
+template <class SG>
+__device__ __forceinline__ void find_flush(SG& sg, bool want, u32 tid) {
   const u32 lane = tid & 63u, q0 = tid & ~3u, piece = tid & 3u;
   __builtin_amdgcn_wave_barrier();
   u64 bal = __ballot(want);
@@ -487,9 +529,9 @@ __device__ __forceinline__ void find_flush(FindStage& sg, bool want, u32 tid) {
   while (__ballot(qm != 0) != 0) {             // wave-uniform trip count; quads with nothing left idle through
     if (qm != 0) {
       const u32 src = q0 + (u32)__builtin_ctz(qm);
-      const u64 tag = sg.tag[src];
+      const u64 tag = sg.tag(src);
       if (piece <= (u32)(tag & 3u)) {
-        const uint4 v = sg.row[src][piece];
+        const uint4 v = sg.row(src)[piece];
         *reinterpret_cast<uint4*>((tag & ~(u64)3) + piece * 16u) = v;
       }
       qm &= qm - 1u;
@@ -500,16 +542,17 @@ __device__ __forceinline__ void find_flush(FindStage& sg, bool want, u32 tid) {
 
 // STAGED: the workgroup's 64 reads (one contiguous byte range of the batch) are in LDS at `rd`, first byte = the
 // 4-byte-aligned address at or below the first read's first base; rd_base = that address's offset in A.seqs.
-template <bool WIDE, bool STAGED, bool TWO>
-__device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindStage& sg, const Find2Tables& t2,
-                                          const unsigned char* rd, u64 rd_base) {
+// COOP: the double step's lines come through LDS (find_step2_dma); NT = threads of the workgroup
+template <bool WIDE, bool STAGED, bool TWO, bool COOP = false, int NT = 256, class SG = FindStage>
+__device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& sg, const Find2Tables& t2,
+                                          const unsigned char* rd, u64 rd_base, uint4* coop_stage = nullptr) {
   // A workgroup = 64 reads; wave o of it walks chain o of each, so everything that depends on the chain (which index
   // is primary, complementing, the direction the read is consumed in) is wave-uniform and lives in scalar registers.
   // (With chains_per_wg == 2 a workgroup is 128 reads and two chains: the launch gathers from one strand's tables.)
   const u32 tid = threadIdx.x;
   const u32 wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const u32 o = A.chain_base + (wv & (A.chains_per_wg - 1u));
-  const u32 read = A.read_begin + blockIdx.x * (256u / A.chains_per_wg) + (A.chains_per_wg == 4u ? 0u : (wv >> 1) * 64u) + (tid & 63u);
+  const u32 read = A.read_begin + blockIdx.x * ((u32)NT / A.chains_per_wg) + (wv / A.chains_per_wg) * 64u + (tid & 63u);
   typedef typename PosOf<WIDE>::type P;
   u32 nocc = 0;
   u32 nsec = 0;  // wave total (scalar): distinct 64-byte sectors of the rank tables asked for (a two-step line is two)
@@ -561,13 +604,13 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
     bool fl = false;
     if (nb < A.cap - 1 && !full) {
       if (WIDE) {
-        cand_store(reinterpret_cast<Cand<WIDE>*>(&sg.row[tid][0]), c0lo, d, c1lo, r0lo, c1lo, szv, len, af);
-        sg.tag[tid] = slot_addr(nb) | 3u;
+        cand_store(reinterpret_cast<Cand<WIDE>*>(sg.row(tid)), c0lo, d, c1lo, r0lo, c1lo, szv, len, af);
+        sg.tag(tid) = slot_addr(nb) | 3u;
         fl = true;
       } else {
-        cand_store(reinterpret_cast<Cand<WIDE>*>(&sg.row[tid][(nb & 1u) * 2]), c0lo, d, c1lo, r0lo, c1lo, szv, len, af);
+        cand_store(reinterpret_cast<Cand<WIDE>*>(sg.row(tid) + (nb & 1u) * 2), c0lo, d, c1lo, r0lo, c1lo, szv, len, af);
         if (nb & 1u) {
-          sg.tag[tid] = slot_addr(nb - 1) | 3u;
+          sg.tag(tid) = slot_addr(nb - 1) | 3u;
           fl = true;
         }
       }
@@ -595,13 +638,23 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
       if (__ballot(on && !ok2) == 0) {
         bool fl1 = false, fl2 = false, two_lines = false;
         P lo1n = 0, lo0n = 0, szn = 0, ldn = 0, dd2 = 0, nlo1 = 0, nlo0 = 0, nsz = 0;
+        Gran2 ga, gb;
+        u32 pl = 0, pu = 0;
         if (on) {
           const u32 nn = (u32)PI.n;  // never leave the table, whatever an invalid interval holds
-          const u32 pl = (u32)lo0 > nn ? nn : (u32)lo0, pu = (u32)(lo0 + sz) > nn ? nn : (u32)(lo0 + sz);
-          Gran2 ga, gb;
-          const u32 oa = (pl >> 6) * 128u, ob = (pu >> 6) * 128u;
-          two_lines = oa != ob;
-          find_step2_loads(PI2, oa, oa + 16u * c, ob, ob + 16u * c, ga, gb);
+          pl = (u32)lo0 > nn ? nn : (u32)lo0;
+          pu = (u32)(lo0 + sz) > nn ? nn : (u32)(lo0 + sz);
+          two_lines = (pl >> 6) != (pu >> 6);
+        }
+        if (COOP) {
+          // all 64 lanes take part in the loads (an idle chain asks for line 0)
+          find_step2_dma(reinterpret_cast<const uint32_t*>(PI2), pl >> 6, pu >> 6, on ? c : 1u, coop_stage + wv * 1024u, tid & 63u, ga, gb);
+        }
+        if (on) {
+          if (!COOP) {
+            const u32 oa = (pl >> 6) * 128u, ob = (pu >> 6) * 128u;
+            find_step2_loads(PI2, oa, oa + 16u * c, ob, ob + 16u * c, ga, gb);
+          }
           const Rank2 l = rank2_from(ga, pl & 63u, c), u = rank2_from(gb, pu & 63u, c);
           const u32 da = u.a - l.a, dc = u.c - l.c, dg = u.g - l.g, dt = u.t - l.t;
           const u32 dd = (u32)sz - (da + dc + dg + dt);  // '$' extensions of the current string
@@ -678,7 +731,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
   // a single record left in the row (u32 positions, odd count): 32 bytes = two pieces
   {
     const bool tail = !WIDE && live && !full && (nb & 1u);
-    if (tail) sg.tag[tid] = slot_addr(nb - 1) | 1u;
+    if (tail) sg.tag(tid) = slot_addr(nb - 1) | 1u;
     find_flush(sg, tail, tid);
   }
   bool contain = false;
@@ -709,8 +762,8 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
       // range and probe.updateR('$') reuses the two positions of rext.
       P ld = lo0 - (l.a + l.c + l.g + l.t);
       P lpd = lo1 - (lp.a + lp.c + lp.g + lp.t);
-      cand_store(reinterpret_cast<Cand<WIDE>*>(&sg.row[tid][0]), ld, sz, lpd, lo0, lo1, sz, L, af);
-      sg.tag[tid] = slot_addr(A.cap - 1) | (WIDE ? 3u : 1u);
+      cand_store(reinterpret_cast<Cand<WIDE>*>(sg.row(tid)), ld, sz, lpd, lo0, lo1, sz, L, af);
+      sg.tag(tid) = slot_addr(A.cap - 1) | (WIDE ? 3u : 1u);
       flagbits |= SIGAX_CC_CONTAIN;
       contain = true;
     }
@@ -735,8 +788,9 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, FindS
 // Copies the workgroup's reads into the dynamic LDS when they fit (whole aligned words: the words holding the first and
 // the last base belong to the same allocation as the bases); returns whether it did.
 extern __shared__ __attribute__((aligned(16))) unsigned char find_dyn_lds[];
+template <int NT = 256>
 __device__ __forceinline__ bool find_stage_reads(const FindArgs& A, u64* rd_base) {
-  const u32 per = 256u / A.chains_per_wg;
+  const u32 per = (u32)NT / A.chains_per_wg;
   const u32 r0 = A.read_begin + blockIdx.x * per;
   const u32 r1 = r0 + per < A.read_end ? r0 + per : A.read_end;
   const u64 lo = A.offs[r0], hi = A.offs[r1];
@@ -747,7 +801,7 @@ __device__ __forceinline__ bool find_stage_reads(const FindArgs& A, u64* rd_base
   const u32* src = reinterpret_cast<const u32*>(alo);
   u32* dst = reinterpret_cast<u32*>(find_dyn_lds);
   const u32 nw = (u32)((nbytes + 3) >> 2);
-  for (u32 w = threadIdx.x; w < nw; w += 256u) dst[w] = src[w];
+  for (u32 w = threadIdx.x; w < nw; w += (u32)NT) dst[w] = src[w];
   return true;
 }
 
@@ -774,6 +828,20 @@ __global__ __launch_bounds__(256) void k_find_n2(FindArgs A) {
   fm_tables_load(tb, A.fwd, A.rev);
   if (staged) find_body<false, true, true>(A, tb, sg, t2, find_dyn_lds, rd_base);
   else find_body<false, false, false>(A, tb, sg, t2, find_dyn_lds, rd_base);
+}
+// u32 positions, two-step table of any size below 2^32 symbols, lines fetched cooperatively through LDS: a workgroup =
+// 2 waves = the two chains of one strand for 64 reads (launched once per strand)
+__global__ __launch_bounds__(128) void k_find_c2(FindArgs A) {
+  __shared__ FmTables tb;
+  __shared__ Find2Tables t2;
+  __shared__ __attribute__((aligned(16))) uint4 stage[2 * 1024];
+  u64 rd_base = 0;
+  const bool staged = find_stage_reads<128>(A, &rd_base);
+  find2_tables_load(t2, A.fwd, A.rev);
+  fm_tables_load(tb, A.fwd, A.rev);
+  __shared__ FindStageC sg;
+  if (staged) find_body<false, true, true, true, 128, FindStageC>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
+  else find_body<false, false, false, false, 128, FindStageC>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
 }
 __global__ __launch_bounds__(256) void k_find_w(FindArgs A) {
   __shared__ FmTables tb;
@@ -2660,6 +2728,13 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
   unsigned lds = (unsigned)find_stage_capacity();  // the record staging rows are part of the budget
   FindArgs b = a;
   b.stage_bytes = lds;  // the residency cap doubles as the staging buffer for the workgroup's reads
+  if (!wide && a.coop && a.two_step && a.fwd.gran2 && a.rev.gran2 && a.chains_per_wg == 2) {
+    // 64 reads per workgroup; the dynamic LDS holds exactly their bases (no residency padding: LDS is what limits it)
+    const unsigned gc = nblk((u64)(a.read_end - a.read_begin), 64u);
+    b.stage_bytes = a.coop_stage_bytes;
+    hipLaunchKernelGGL(k_find_c2, dim3(gc), dim3(128), a.coop_stage_bytes, st, b);
+    return;
+  }
   if (wide) hipLaunchKernelGGL(k_find_w, dim3(g), dim3(bs), lds, st, b);
   else if (a.two_step && a.fwd.gran2 && a.rev.gran2) hipLaunchKernelGGL(k_find_n2, dim3(g), dim3(bs), lds, st, b);
   else hipLaunchKernelGGL(k_find_n, dim3(g), dim3(bs), lds, st, b);

@@ -49,3 +49,9 @@ def test_arena_regrow_and_rerun():
     buffers on the overflowing run)."""
     _run_parity({"SIGAX_TEST_FIN_CAP": "64", "SIGAX_TEST_EDGE_CAP": "16"}, "hits_and_asqg and (toy or dup or rep)")
     _run_parity({"SIGAX_TEST_POOL_CAP": "24", "SIGAX_GENERAL_ONLY": "1", "SIGAX_TEST_FIN_CAP": "100"}, "hits_and_asqg and (toy or rep or corner)")
+
+
+def test_cooperative_finder_bit_exact():
+    """k_find_c2 (two-step lines fetched eight lanes per line through LDS; what indexes of 2^30 symbols and more run) forced
+    on the small fixtures: same bytes as the oracle, ragged reads, non-ACGT bases, duplicates and deep coverage included."""
+    _run_parity({"SIGAX_FIND_COOP": "1"}, "hits_and_asqg or non_acgt or duplicate or in_flight or deep or mid")
