@@ -408,22 +408,25 @@ __global__ __launch_bounds__(256) void k_build2_b(const u64* offs, u32* gran2, u
   if (g < ng2) gran2[g * SIGAX_GRAN2_WORDS + col] = (u32)offs[g];
 }
 
+#ifndef SIGAX_FIND_POLICY
+#define SIGAX_FIND_POLICY ""  // cache-policy bits of the finder's table loads (A/B builds: " nt", " sc1", " sc0 sc1")
+#endif
 struct Gran2 {  // the five 16-byte pieces of a two-step granule one step needs
   v4u s, pc, p5, p6, p7;  // one-symbol counts; pair counts [first symbol c][x = A..T]; planes
 };
 // both positions of a double step: ten loads back to back, one wait (u32 offsets from a scalar base: table < 4 GiB)
 __device__ __forceinline__ void find_step2_loads(const void* base, u32 offa, u32 offa_c, u32 offb, u32 offb_c, Gran2& a, Gran2& b) {
   asm volatile(
-      "global_load_dwordx4 %0, %10, %14\n\t"
-      "global_load_dwordx4 %5, %12, %14\n\t"
-      "global_load_dwordx4 %1, %11, %14\n\t"
-      "global_load_dwordx4 %2, %10, %14 offset:80\n\t"
-      "global_load_dwordx4 %3, %10, %14 offset:96\n\t"
-      "global_load_dwordx4 %4, %10, %14 offset:112\n\t"
-      "global_load_dwordx4 %6, %13, %14\n\t"
-      "global_load_dwordx4 %7, %12, %14 offset:80\n\t"
-      "global_load_dwordx4 %8, %12, %14 offset:96\n\t"
-      "global_load_dwordx4 %9, %12, %14 offset:112\n\t"
+      "global_load_dwordx4 %0, %10, %14" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %5, %12, %14" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %1, %11, %14" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %2, %10, %14 offset:80" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %3, %10, %14 offset:96" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %4, %10, %14 offset:112" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %6, %13, %14" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %7, %12, %14 offset:80" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %8, %12, %14 offset:96" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %9, %12, %14 offset:112" SIGAX_FIND_POLICY "\n\t"
       "s_waitcnt vmcnt(0)"
       : "=&v"(a.s), "=&v"(a.pc), "=&v"(a.p5), "=&v"(a.p6), "=&v"(a.p7), "=&v"(b.s), "=&v"(b.pc), "=&v"(b.p5), "=&v"(b.p6),
         "=&v"(b.p7)

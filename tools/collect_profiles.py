@@ -20,7 +20,7 @@ def counters(name):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     if f:
         for r in csv.DictReader(open(f)):
-            out[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
+            out[r['Kernel_Name'].split('(')[0].replace('void ', '')][r['Counter_Name']].append(float(r['Counter_Value']))
     return {k: {c: {'mean_per_launch': sum(x) / len(x), 'launches': len(x)} for c, x in v.items()} for k, v in out.items()}
 def rd_bytes(c):
     g = lambda n: c.get(n, {}).get('mean_per_launch', 0.0)
@@ -36,7 +36,7 @@ for tag, d in (('default', 'q_kt'), ('sub1', 'q_kt1'), ('correct', 'k_kt')):
     shutil.copy(ks, 'profiles/%s_kernel_stats_%s.csv' % (R, tag))
     b = last_json('%s/%s.json' % (O, d))
     json.dump(b, open('profiles/%s_bench_under_rocprof_%s.json' % (R, tag), 'w'))
-    rows = {r['Name'].split('(')[0]: r for r in csv.DictReader(open(ks))}
+    rows = {r['Name'].split('(')[0].replace('void ', ''): r for r in csv.DictReader(open(ks))}
     for k, r in rows.items():
         if k.startswith('k_find') or k.startswith('k_filter_extract_fast') or k.startswith('k_correct'):
             print(tag, 'rocprof', k, 'calls', r['Calls'], 'avg ms', float(r['AverageNs']) / 1e6)
