@@ -53,8 +53,9 @@ def parse_args():
     ap.add_argument("--subbatches", type=int, default=2,
                     help="sub-batches per step (0 = library default for one batch at a time: 4 at this size); sub-batch i's "
                          "filter/extract kernels run beside sub-batch i+1's finder")
-    ap.add_argument("--depth", type=int, default=2,
-                    help="batches in flight on the index (2 = batch k+1's finder starts beside batch k's filter/extract tail)")
+    ap.add_argument("--depth", type=int, default=3,
+                    help="batches in flight on the index (batch k+1's finder starts beside batch k's filter/extract tail; the third "
+                         "hides batch k-1's scan / scatter / edge tail and its copy to the host)")
     ap.add_argument("--isolated", action="store_true",
                     help="after the timed steps, also time 2 steps with sub-batching off and report them under roofline.isolated")
     ap.add_argument("--emulate-world", type=int, default=0,

@@ -637,7 +637,7 @@ struct sigax_batch {
   uint32_t read_base, minov, flags;
   bool ran;
   // arenas
-  DevBuf arena, chain_cnt, pool, wpool, work, work64, occ_side, slow_flag, offs2, item_base, fin, fin_cnt, substring, block_offs, outb, edge_cnt,
+  DevBuf arena, chain_cnt, pool, wpool, work, work64, work64b, occ_side, slow_flag, offs2, item_base, fin, fin_cnt, substring, block_offs, outb, edge_cnt,
       edge_offs, edges, partial, dstat;
   uint32_t cap;
   uint32_t pool_cap;
@@ -657,7 +657,7 @@ struct sigax_batch {
 extern "C" void sigax_batch_destroy(sigax_batch* b) {
   if (!b) return;
   hipSetDevice(b->ix->device);
-  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin,
+  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin,
                    &b->fin_cnt, &b->substring, &b->block_offs, &b->outb, &b->edge_cnt, &b->edge_offs, &b->edges,
                    &b->partial, &b->dstat};
   for (DevBuf* d : all)
@@ -790,6 +790,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   if ((rc = ensure(&b->wpool, (size_t)fast_grid * 4 * fast_pool_entries_per_wave() * SIGAX_ENT_BYTES)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->work, ((size_t)n + 1) * 4)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->work64, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->work64b, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
   // general filter/extract kernel (reads the fast kernel queued): persistent lanes with a private pool each
   unsigned want_grid = (unsigned)std::min<u64>(128, ((u64)n + 255) / 256);
   if (want_grid == 0) want_grid = 1;
@@ -902,6 +903,8 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     xa.slow_counter = dstat + DS_SLOW_BASE + i;
     xa.work64 = (uint32_t*)b->work64.p + 2 * (size_t)rb;
     xa.w64_counter = dstat + DS_W64_BASE + i;
+    xa.work64b = (uint32_t*)b->work64b.p + 2 * (size_t)rb;
+    xa.w64b_counter = dstat + DS_W64B_BASE + i;
     xa.read_begin = rb;
     xa.read_end = re;
     xa.item_base = (u64*)b->item_base.p;

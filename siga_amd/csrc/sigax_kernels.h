@@ -28,7 +28,8 @@ enum {
   DS_SEC_FIND = DS_W64_BASE + 8,   // distinct 64-byte sectors of the rank tables the finder asked for, step by step
   DS_SEC_EXTRACT,                  // ... filter/extract, round by round
   DS_PROF_BASE = 32,               // 32 diagnostic counters (builds with -DSIGAX_FX_PROFILE only)
-  DS_COUNT = 64
+  DS_W64B_BASE = 64,               // [DS_W64B_BASE + i]: items the lean 64-lane launch of sub-batch i queued for the full one
+  DS_COUNT = 80
 };
 #define SIGAX_MAX_SUB 8
 
@@ -67,6 +68,8 @@ struct FxArgs {
   unsigned long long* slow_counter;
   uint32_t* work64;   // 32-lane launch: (read, side) items queued for the 64-lane launch, counted in *w64_counter
   unsigned long long* w64_counter;
+  uint32_t* work64b;  // lean 64-lane launch: items queued for the full 64-lane launch, counted in *w64b_counter
+  unsigned long long* w64b_counter;
   uint32_t read_begin, read_end;  // fast kernel: this launch's sub-batch
   sigax_block* fin;   // unordered final blocks, allocated in per-wave / per-lane chunks
   unsigned long long* item_base;  // [n_reads][2]: where a (read, side) item's blocks start in `fin`

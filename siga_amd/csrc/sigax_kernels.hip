@@ -1400,10 +1400,11 @@ __device__ __forceinline__ void fm_rank5p(const FmRef& s, typename PosOf<WIDE>::
 // single-group rounds served by the two-step line are compiled in; an item that needs anything else (a branch, a range
 // across lines, the exhaustive output order) is queued for the 64-lane launch, which has everything.  Without the rarely
 // taken code the kernel needs no scratch (124 VGPRs, was 128 + 17 spilled) and runs 1.2-1.4x faster.
-template <bool WIDE, int W, bool LEANP = false>
+// LEANP = 2: the same for indexes without two-step tables (64-bit positions): only the one-granule rounds.
+template <bool WIDE, int W, int LEANP = 0>
 struct GFx {
   typedef typename PosOf<WIDE>::type P;
-  static constexpr bool LEAN = LEANP;
+  static constexpr bool LEAN = LEANP != 0;
   struct E {  // a block's capped pair in registers
     P c0lo, c0hi, c1lo, c1hi;
     u32 src;  // bits 30-31: which find produced it (0..3); bits 0-29: slot in the read's candidate region
@@ -1600,7 +1601,7 @@ struct GFx {
     // blocks and neither of them '$': both rounds are then "usual" rounds (no top-level end, no branch), capped[0] and
     // the range size do not move, and capped[1].lower = C[e] + Occ(e, C[c]) + R2(e, c, lower).  If only the first
     // symbol is common, ONE round from the same line.  Anything else goes on to the one-step forms below.
-    if (!WIDE && t2 != nullptr) {
+    if (!WIDE && LEANP != 2 && t2 != nullptr) {
       const u32 q0 = (u32)p0, q1 = (u32)p1;
       const bool in2 = mine && q1 > q0 && ((q1 - 1u) >> 6) == (q0 >> 6) && p1 <= ix.n;
       if (gballot(mine && !in2) != 0) FXP(9);  // a range crosses a 64-row line: no two-step lookup
@@ -1712,11 +1713,12 @@ struct GFx {
         }
       }
     }
-    if (LEAN) return RD_BAIL;  // not servable from one two-step line
+    if (LEANP == 1) return RD_BAIL;  // not servable from one two-step line
     const u64 g0 = p0 >> 7;
     const bool inside = mine && p1 > p0 && ((p1 - 1) >> 7) == g0 && p1 <= ix.n;
     if (gballot(mine && !inside)) {
       FXP(4);
+      if (LEAN) return RD_BAIL;
       return round(e, alive, newAlive);
     }
     const bool qcomp = (af_of(e.src) & 4u) != 0;
@@ -1834,6 +1836,7 @@ struct GFx {
     const u32 nz = (any0 != 0) + (any1 != 0) + (any2 != 0) + (any3 != 0) + (any4 != 0);
     if (nz != 1 || any0) {
       FXP(5);
+      if (LEAN) return RD_BAIL;
       return round(e, alive, newAlive);
     }
     FXP(3);
@@ -2301,8 +2304,11 @@ struct GFx {
 // W == 32: two (read, side) items per wave, one per half; items that do not fit (more than 32 blocks, branching beyond
 // the half's slots, output beyond its share) are queued for the W == 64 launch, which in turn queues what it cannot
 // finish for the general kernel.
-template <bool WIDE, int W, bool LEAN = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 1 : 4))) void k_filter_extract_fast(FxArgs A) {
+#ifndef SIGAX_FX_LEAN_WAVES
+#define SIGAX_FX_LEAN_WAVES 4  // register budget of the lean launch as waves per SIMD (4: up to 128, it takes 89; 6: 80 with 6 spilled)
+#endif
+template <bool WIDE, int W, int LEAN = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? (LEAN ? 2 : 1) : (LEAN ? SIGAX_FX_LEAN_WAVES : 4)))) void k_filter_extract_fast(FxArgs A) {
   __shared__ FmTables tb;
   __shared__ Find2Tables t2;
   __shared__ SideSh<WIDE> shm[4];
@@ -2337,15 +2343,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 1 : 
       fx.account(has, done, item, nocc_total, nerr, nsub);
     }
   } else {
-    const u64 n = *A.w64_counter;
+    // the lean 64-lane launch takes what the 32-lane one queued and queues what it cannot finish for the full one,
+    // which queues reads for the general kernel
+    const u64 n = LEAN ? *A.w64_counter : *A.w64b_counter;
+    const u32* in = LEAN ? A.work64 : A.work64b;
     for (u64 i = wave; i < n; i += nwaves) {
-      const u64 item = A.work64[i];
+      const u64 item = in[i];
       bool done = fx.run(true, (u32)(item >> 1), (u32)(item & 1));
       if (!done && lane == 0) {
         const u32 r = (u32)(item >> 1);
         A.fin_cnt[item] = 0;
         A.occ_side[item] = 0;
-        if (atomicExch(&A.slow_flag[r], 1u) == 0u) A.work_out[atomicAdd(A.slow_counter, 1ull)] = r;
+        if (LEAN) A.work64b[atomicAdd(A.w64b_counter, 1ull)] = (u32)item;
+        else if (atomicExch(&A.slow_flag[r], 1u) == 0u) A.work_out[atomicAdd(A.slow_counter, 1ull)] = r;
       }
       fx.account(true, done, item, nocc_total, nerr, nsub);
     }
@@ -2753,16 +2763,35 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
 
 void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid32, unsigned grid64, hipStream_t st) {
   if (a.read_end <= a.read_begin) return;
+  static const bool no_lean = getenv("SIGAX_FX_NO_LEAN") != nullptr;  // A/B aid
+  const bool lean = a.irreducible && !no_lean;
+  const bool have2 = a.fwd.gran2 && a.rev.gran2;
+  // 32-lane launch -> lean 64-lane launch -> full 64-lane launch (-> general kernel, launched by the caller).  Without
+  // the lean stage the full launch reads the 32-lane launch's queue directly.
+  FxArgs full = a;
+  if (!lean) {
+    full.work64b = a.work64;
+    full.w64b_counter = a.w64_counter;
+  }
   if (wide) {
-    hipLaunchKernelGGL((k_filter_extract_fast<true, 32>), dim3(grid32), dim3(256), 0, st, a);
-    hipLaunchKernelGGL((k_filter_extract_fast<true, 64>), dim3(grid64), dim3(256), 0, st, a);
+    if (lean) {
+      hipLaunchKernelGGL((k_filter_extract_fast<true, 32, 2>), dim3(grid32), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_filter_extract_fast<true, 64, 2>), dim3(grid64), dim3(256), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((k_filter_extract_fast<true, 32>), dim3(grid32), dim3(256), 0, st, a);
+    }
+    hipLaunchKernelGGL((k_filter_extract_fast<true, 64>), dim3(grid64), dim3(256), 0, st, full);
   } else {
-    static const bool no_lean = getenv("SIGAX_FX_NO_LEAN") != nullptr;  // A/B aid
-    if (a.irreducible && a.fwd.gran2 && a.rev.gran2 && !no_lean)
-      hipLaunchKernelGGL((k_filter_extract_fast<false, 32, true>), dim3(grid32), dim3(256), 0, st, a);
-    else
+    if (lean && have2) {
+      hipLaunchKernelGGL((k_filter_extract_fast<false, 32, 1>), dim3(grid32), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_filter_extract_fast<false, 64, 1>), dim3(grid64), dim3(256), 0, st, a);
+    } else if (lean) {
+      hipLaunchKernelGGL((k_filter_extract_fast<false, 32, 2>), dim3(grid32), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_filter_extract_fast<false, 64, 2>), dim3(grid64), dim3(256), 0, st, a);
+    } else {
       hipLaunchKernelGGL((k_filter_extract_fast<false, 32>), dim3(grid32), dim3(256), 0, st, a);
-    hipLaunchKernelGGL((k_filter_extract_fast<false, 64>), dim3(grid64), dim3(256), 0, st, a);
+    }
+    hipLaunchKernelGGL((k_filter_extract_fast<false, 64>), dim3(grid64), dim3(256), 0, st, full);
   }
 }
 
