@@ -356,7 +356,9 @@ def bench_overlap(args):
                                         "algorithmic_bytes_per_launch": bytes_fx / nsub_step, "avg_launch_ms": fx_ms,
                                         "note": "latency-bound: a chain of dependent rank lookups per (read, side)"},
             "whole_path": {"achieved": bytes_step / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": bytes_step / step_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": bytes_step},
+                           "frac": bytes_step / step_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": bytes_step,
+                           "traffic_find_plus_filter_extract": (launches * traffic + nsub_step * fx_traffic) if (traffic and fx_traffic) else None,
+                           "note": "algorithmic bytes count filter/extract's lines per lane; L2 absorbs most of those (compare traffic)"},
         }
         if iso is not None:
             ims = float(iso[0])

@@ -93,3 +93,8 @@ if cal:
         c['FETCH_SIZE_bytes'] = c.get('FETCH_SIZE', 0) * 1024
     json.dump(cal, open('profiles/%s_fetch_calibration.json' % R, 'w'), indent=1)
     print(json.dumps(cal, indent=1))
+
+if os.path.exists('%s/bench_full.json' % O):
+    b = last_json('%s/bench_full.json' % O)
+    json.dump(b, open('profiles/%s_bench_default.json' % R, 'w'))
+    print('bench_full', b['value'], b['ms_per_step'], b['roofline']['frac'], b['roofline'].get('isolated', {}).get('frac'))
