@@ -305,8 +305,8 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
   {
     const char* env2 = getenv("SIGAX_TWO_STEP");
     const char* envm = getenv("SIGAX_TWO_STEP_MAX_SYMBOLS");
-    // every index with 32-bit positions: below SIGAX_COOP_MIN_SYMBOLS the finder gathers per lane with u32 byte offsets
-    // (k_find_n2, tables under 4 GiB), above it lines come cooperatively through LDS with 64-bit addresses (k_find_c2)
+    // every index with 32-bit positions: below SIGAX_COOP_MIN_SYMBOLS (2^31) the finder gathers per lane with u32 byte
+    // offsets (k_find_n2, tables under 4 GiB), above it lines come cooperatively through LDS with 64-bit addresses (k_find_c2)
     u64 max2 = envm ? strtoull(envm, nullptr, 10) : 0xFFFFFFF0ull;
     if (max2 > 0xFFFFFFF0ull) max2 = 0xFFFFFFF0ull;
     const bool want2 = !ix->wide && n_symbols < max2 && !(env2 && env2[0] == '0');
@@ -852,7 +852,9 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     {
       static const char* env_coop = getenv("SIGAX_FIND_COOP");
       static const char* env_cmin = getenv("SIGAX_COOP_MIN_SYMBOLS");
-      const u64 coop_min = env_cmin ? strtoull(env_cmin, nullptr, 10) : (1ull << 30);
+      // from 2^31 symbols the per-lane finder's 32-bit byte offsets no longer reach the table; below, it is the faster one
+      // (1.2e9 symbols, one rank's view of an 8-GPU job: 80 M reads/s per lane vs 66 M cooperative, gpurun_out/emu/)
+      const u64 coop_min = env_cmin ? strtoull(env_cmin, nullptr, 10) : (1ull << 31);
       const u64 need = 64ull * b->cur_max_len + 16;  // the workgroup's 64 reads, staged as bytes
       const bool can = fa.two_step && !ix->wide && need <= 32768;
       const bool want = env_coop ? env_coop[0] != '0' : ix->n_symbols >= coop_min;

@@ -436,37 +436,71 @@ __device__ __forceinline__ void find_step2_loads(const void* base, u32 offa, u32
 // The same through LDS, cooperatively (the finder for tables beyond the translation reach of per-lane gathers): eight
 // lanes fetch the eight 16-byte pieces of ONE 128-byte line with one instruction that writes LDS directly
 // (global_load_lds_dwordx4: destination = wave-uniform base + lane x 16), so a wave instruction touches 8 lines instead
-// of 64 and a double step costs 16 such instructions for the wave's 64 chains x 2 lines.  Then every lane reads the five
-// pieces it needs of its own two lines.  Slot of (chain 8t + j, piece p) in instruction t's 1 KiB: (p ^ (t & 1)) * 8 + j,
-// which spreads the sixteen lanes of a ds_read_b128 group over the sixteen 16-byte bank groups.
-// la / lb = line index of the lane's lower / upper position (any valid line for idle lanes), c = first symbol (1..4).
+// of 64.  Every chain's lower line goes to region A (8 instructions for the wave's 64 chains); five chains in six have
+// their upper position in the same line, so only the chains whose upper line differs are listed (ballot + prefix count)
+// and fetched into the small region B, sixteen chains per pass (almost always one pass of two instructions).  Then
+// every lane reads the five pieces it needs of its own line(s).  Slot of (chain 8t + j, piece p) in instruction t's 1 KiB:
+// (p ^ (t & 1)) * 8 + j, which spreads the sixteen lanes of a ds_read_b128 group over the sixteen 16-byte bank groups.
+// la / lb = line index of the lane's lower / upper position (0 for idle lanes), c = first symbol (1..4).
+#define COOP_A_U4 512u   // region A: 64 chains x 8 pieces
+#define COOP_B_U4 128u   // region B: 16 chains x 8 pieces per pass
+#define COOP_WAVE_U4 (COOP_A_U4 + COOP_B_U4 + 16u)  // + 64 u32 of list
 __device__ __forceinline__ void find_step2_dma(const uint32_t* gran2, u32 la, u32 lb, u32 c, uint4* stage, u32 lane, Gran2& a, Gran2& b) {
   const u32 j = lane & 7u, pp = lane >> 3;
   const char* base = reinterpret_cast<const char*>(gran2);
-  // the records parked by the previous step have been read back (find_flush) before the area is written again
+  u32* list = reinterpret_cast<u32*>(stage + COOP_A_U4 + COOP_B_U4);
+  const bool differ = lb != la;
+  const u64 dmask = __ballot(differ);
+  const u32 nd = (u32)__popcll(dmask);
+  const u32 r = (u32)__popcll(dmask & ((1ull << lane) - 1ull));  // my place among the chains with a second line
+  // the records parked by the previous step have been read back (find_flush) and the previous step's pieces consumed
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (differ) list[r] = lb;
 #pragma unroll
   for (u32 t = 0; t < 8; ++t) {
-    const u32 kap = 8u * t + j;
-    const u32 lA = (u32)__shfl((int)la, (int)kap, 64), lB = (u32)__shfl((int)lb, (int)kap, 64);
+    const u32 lA = (u32)__shfl((int)la, (int)(8u * t + j), 64);
     const u32 p = pp ^ (t & 1u);
     const char* sa = base + (u64)lA * 128u + p * 16u;
-    const char* sb = base + (u64)lB * 128u + p * 16u;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
                                      (__attribute__((address_space(3))) void*)(u32)(size_t)(stage + t * 64u), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
-                                     (__attribute__((address_space(3))) void*)(u32)(size_t)(stage + 512u + t * 64u), 16, 0, 0);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
   const u32 tt = lane >> 3, x = tt & 1u;
-  const uint4* qa = stage + tt * 64u + j;
-  const uint4* qb = qa + 512u;
-  auto ld = [](const uint4* q) { const uint4 v = *q; v4u r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; };
-  a.s = ld(qa + ((0u ^ x) * 8u)); a.pc = ld(qa + ((c ^ x) * 8u)); a.p5 = ld(qa + ((5u ^ x) * 8u)); a.p6 = ld(qa + ((6u ^ x) * 8u)); a.p7 = ld(qa + ((7u ^ x) * 8u));
-  b.s = ld(qb + ((0u ^ x) * 8u)); b.pc = ld(qb + ((c ^ x) * 8u)); b.p5 = ld(qb + ((5u ^ x) * 8u)); b.p6 = ld(qb + ((6u ^ x) * 8u)); b.p7 = ld(qb + ((7u ^ x) * 8u));
+  auto ld = [](const uint4* q) { const uint4 v = *q; v4u w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; return w; };
+  bool gotA = false;
+  const u32 npass = (nd + 15u) >> 4;
+  for (u32 ps = 0; ps < npass || !gotA; ++ps) {  // wave-uniform trip count; at least once, for region A
+    if (ps < npass) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the list is written; the previous pass's readers are done
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (u32 t = 0; t < 2; ++t) {
+        const u32 rk = 16u * ps + 8u * t + j;
+        if (rk < nd) {
+          const u32 lB = list[rk];
+          const u32 p = pp ^ (t & 1u);
+          const char* sb = base + (u64)lB * 128u + p * 16u;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                           (__attribute__((address_space(3))) void*)(u32)(size_t)(stage + COOP_A_U4 + t * 64u), 16, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (!gotA) {
+      const uint4* qa = stage + tt * 64u + j;
+      a.s = ld(qa + ((0u ^ x) * 8u)); a.pc = ld(qa + ((c ^ x) * 8u)); a.p5 = ld(qa + ((5u ^ x) * 8u)); a.p6 = ld(qa + ((6u ^ x) * 8u)); a.p7 = ld(qa + ((7u ^ x) * 8u));
+      gotA = true;
+    }
+    if (differ && (r >> 4) == ps) {
+      const u32 q = r & 15u, tb = q >> 3, xb = tb & 1u;
+      const uint4* qb = stage + COOP_A_U4 + tb * 64u + (q & 7u);
+      b.s = ld(qb + ((0u ^ xb) * 8u)); b.pc = ld(qb + ((c ^ xb) * 8u)); b.p5 = ld(qb + ((5u ^ xb) * 8u)); b.p6 = ld(qb + ((6u ^ xb) * 8u)); b.p7 = ld(qb + ((7u ^ xb) * 8u));
+    }
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (!differ) b = a;
 }
 
 struct Rank2 {
@@ -651,7 +685,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
         }
         if (COOP) {
           // all 64 lanes take part in the loads (an idle chain asks for line 0)
-          find_step2_dma(reinterpret_cast<const uint32_t*>(PI2), pl >> 6, pu >> 6, on ? c : 1u, coop_stage + wv * 1024u, tid & 63u, ga, gb);
+          find_step2_dma(reinterpret_cast<const uint32_t*>(PI2), pl >> 6, pu >> 6, on ? c : 1u, coop_stage + wv * COOP_WAVE_U4, tid & 63u, ga, gb);
         }
         if (on) {
           if (!COOP) {
@@ -837,7 +871,7 @@ __global__ __launch_bounds__(256) void k_find_n2(FindArgs A) {
 __global__ __launch_bounds__(128) void k_find_c2(FindArgs A) {
   __shared__ FmTables tb;
   __shared__ Find2Tables t2;
-  __shared__ __attribute__((aligned(16))) uint4 stage[2 * 1024];
+  __shared__ __attribute__((aligned(16))) uint4 stage[2 * COOP_WAVE_U4];
   u64 rd_base = 0;
   const bool staged = find_stage_reads<128>(A, &rd_base);
   find2_tables_load(t2, A.fwd, A.rev);
