@@ -40,7 +40,7 @@ def log(*a):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="overlap", choices=["overlap", "correct"])
     ap.add_argument("--reads-per-gpu", type=int, default=1000000)

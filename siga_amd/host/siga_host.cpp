@@ -702,15 +702,21 @@ bool StrandIndex::writeSAI(const std::string& path) const {
   FILE* f = fopen(path.c_str(), "wb");
   if (!f) return false;
   std::string buf;
-  buf.reserve(1 << 20);
+  buf.reserve((1 << 20) + 64);
   char tmp[64];
   snprintf(tmp, sizeof(tmp), "%u\n%llu\n%llu\n", 0xCACAu, (unsigned long long)sai.size(), (unsigned long long)sai.size());
   buf += tmp;
   bool ok = true;
-  for (uint32_t id : sai) {
-    int n = snprintf(tmp, sizeof(tmp), "%u 0\n", id);
-    buf.append(tmp, n);
-    if (buf.size() > (1 << 20) - 64) {
+  for (uint32_t id : sai) {  // "<readIdx> 0\n" (src/suffix_array.cpp:17-44)
+    char d[12];
+    int n = 0;
+    do {
+      d[n++] = (char)('0' + id % 10);
+      id /= 10;
+    } while (id);
+    while (n) buf.push_back(d[--n]);
+    buf.append(" 0\n", 3);
+    if (buf.size() > (1 << 20)) {
       ok = ok && fwrite(buf.data(), 1, buf.size(), f) == buf.size();
       buf.clear();
     }
@@ -1518,23 +1524,35 @@ int sigah_index_build_dev(const char* seqs, const uint64_t* offs, uint64_t n_rea
     if (do_fwd && do_rev) return sigah_index_build(seqs, offs, n_reads, prefix, threads, err, errcap);
   }
   std::string p(prefix), e;
+  // the files of one strand are written on a side thread while the other strand is sorted
+  std::thread writer;
+  bool write_ok = true;
+  auto join_writer = [&] {
+    if (writer.joinable()) writer.join();
+  };
   for (int rev = 0; rev < 2; ++rev) {
     if ((rev == 0 && !do_fwd) || (rev == 1 && !do_rev)) continue;
-    sigah::StrandIndex ix;
+    auto ix = std::make_shared<sigah::StrandIndex>();
     int rc = 0;
-    bool ok = device >= 0 && sigah::BuildStrandIndexGPU(seqs, offs, n_reads, rev != 0, device, &ix, &e, &rc);
+    bool ok = device >= 0 && sigah::BuildStrandIndexGPU(seqs, offs, n_reads, rev != 0, device, ix.get(), &e, &rc);
     if (!ok && (device < 0 || rc == SIGAX_E_CAPACITY)) {
       if (device >= 0) fprintf(stderr, "siga index: %s; using the host suffix sorter\n", e.c_str());
-      ok = sigah::BuildStrandIndex(seqs, offs, n_reads, rev != 0, &ix, &e, (unsigned)std::max(threads, 1));
-    }
-    if (ok) {
-      ok = ix.writeSAI(p + (rev ? ".rsai" : ".sai")) && ix.writeBWT(p + (rev ? ".rbwt" : ".bwt"));
-      if (!ok) e = "cannot write index files with prefix " + p;
+      ok = sigah::BuildStrandIndex(seqs, offs, n_reads, rev != 0, ix.get(), &e, (unsigned)std::max(threads, 1));
     }
     if (!ok) {
+      join_writer();
       if (err && errcap) snprintf(err, errcap, "%s", e.c_str());
       return -1;
     }
+    join_writer();
+    writer = std::thread([ix, p, rev, &write_ok] {
+      if (!(ix->writeSAI(p + (rev ? ".rsai" : ".sai")) && ix->writeBWT(p + (rev ? ".rbwt" : ".bwt")))) write_ok = false;
+    });
+  }
+  join_writer();
+  if (!write_ok) {
+    if (err && errcap) snprintf(err, errcap, "cannot write index files with prefix %s", p.c_str());
+    return -1;
   }
   return 0;
 }
@@ -1542,18 +1560,16 @@ int sigah_index_build_dev(const char* seqs, const uint64_t* offs, uint64_t n_rea
 // `siga index READS` with the device builder (device < 0: host builder)
 int sigah_index_file_dev(const char* reads_path, const char* prefix, int device, int threads, int do_fwd, int do_rev, char* err,
                          uint64_t errcap) {
-  sigah::DNASeqList reads;
-  if (!sigah::ReadDNASequences(reads_path, reads, 0)) {
+  sigah::PhaseTimer pt;
+  sigah::ReadStore rs;
+  if (!sigah::LoadReads(reads_path, &rs, sigah::host_threads((size_t)std::max(threads, 1)))) {
     if (err && errcap) snprintf(err, errcap, "Failed to open input file %s", reads_path);
     return -1;
   }
-  std::string seqs;
-  std::vector<uint64_t> offs(1, 0);
-  for (auto& r : reads) {
-    seqs += r.seq;
-    offs.push_back(seqs.size());
-  }
-  return sigah_index_build_dev(seqs.data(), offs.data(), reads.size(), prefix, device, threads, do_fwd, do_rev, err, errcap);
+  pt.lap("parse reads");
+  int rc = sigah_index_build_dev(rs.seqs.data(), rs.offs.data(), rs.size(), prefix, device, threads, do_fwd, do_rev, err, errcap);
+  pt.lap("suffix sort + index files");
+  return rc;
 }
 
 // `siga index READS`
