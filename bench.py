@@ -64,7 +64,9 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow on fewer GPUs than ranks (edge records gathered via host)")
     ap.add_argument("--kmer", type=int, default=31, help="--workload correct: k-mer size (31 = code default, 41 = example script)")
-    ap.add_argument("--error-rate", type=float, default=0.01, help="--workload correct: substitutions per base")
+    ap.add_argument("--error-rate", type=float, default=None,
+                    help="substitutions per base: --workload correct default 0.01; --workload overlap default 0 (the BASELINE configs are "
+                         "error-free), > 0 shows what uncorrected reads cost (branches in the extraction)")
     return ap.parse_args()
 
 
@@ -134,6 +136,11 @@ def bench_overlap(args):
     # ---- synthetic reads (every rank draws the same set) and the index (rank 0 builds on its GPU, everyone loads) ----
     t0 = time.time()
     reads, _ = fast_reads(G, L, n_total, args.seed)  # uint8 [n_total, L]
+    if args.error_rate:
+        from tests.golden.make_reads import substitute
+        reads = substitute(reads, args.error_rate, args.seed + 100)
+        workdir += "_e%g" % args.error_rate
+        prefix = os.path.join(workdir, "reads")
     if rank == 0:
         sbuild.build_all()
         os.makedirs(workdir, exist_ok=True)
@@ -424,7 +431,8 @@ def bench_correct(args):
     N, G, L, k = args.reads_per_gpu, args.genome_per_gpu, args.read_len, args.kmer
     t0 = time.time()
     clean, _ = fast_reads(G, L, N, args.seed)
-    reads = substitute(clean, args.error_rate, args.seed + 100)
+    err_rate = 0.01 if args.error_rate is None else args.error_rate
+    reads = substitute(clean, err_rate, args.seed + 100)
     workdir = args.workdir or os.path.join(tempfile.gettempdir(), "siga_bench_correct_%d_%d_%d_%d" % (N, G, L, args.seed))
     os.makedirs(workdir, exist_ok=True)
     prefix = os.path.join(workdir, "reads")
@@ -472,7 +480,7 @@ def bench_correct(args):
         "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "siga correct -k %d -x 3 -i 10 -O 1 on synthetic %dx%d bp reads from %d bp genome with %.2g "
-                               "substitutions per base; FM-index of those reads resident in HBM" % (k, N, L, G, args.error_rate),
+                               "substitutions per base; FM-index of those reads resident in HBM" % (k, N, L, G, err_rate),
                    "reads_written": n_valid, "reads_equal_to_truth": restored, "kmer_lookups_per_read": int(stat[2]) / N,
                    "sectors_per_read": int(stat[1]) / N, "algorithmic_bytes_per_read": bytes_step / N},
         "roofline": {"bound": "hbm", "kernel": "k_correct", "achieved": bytes_step / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,

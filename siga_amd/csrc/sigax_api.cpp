@@ -647,6 +647,8 @@ struct sigax_batch {
   hipEvent_t ev[EV_COUNT];
   hipEvent_t sev[SIGAX_MAX_SUB][SV_COUNT];
   unsigned nsub;
+  bool lean_off;      // see sigax_batch_finish
+  unsigned lean_off_runs;
   unsigned nsub_req;  // 0 = automatic
   unsigned find_per_sub;  // finder launches per sub-batch (2 = one per strand's two-step table)
   sigax_stats last;
@@ -698,6 +700,8 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
   for (int i = 0; i < SIGAX_MAX_SUB; ++i)
     for (int j = 0; j < SV_COUNT; ++j) b->sev[i][j] = nullptr;
   b->nsub = 1;
+  b->lean_off = false;
+  b->lean_off_runs = 0;
   b->nsub_req = 0;
   b->find_per_sub = 1;
   {
@@ -896,6 +900,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     xa.n_reads = n;
     xa.cap = b->cap;
     xa.irreducible = (b->flags & SIGAX_IRREDUCIBLE) ? 1u : 0u;
+    xa.no_lean = b->lean_off ? 1u : 0u;
     xa.arena = b->arena.p;
     xa.chain_cnt = (const uint32_t*)b->chain_cnt.p;
     xa.pool = (Ent*)b->pool.p;
@@ -1049,6 +1054,23 @@ extern "C" int sigax_batch_finish(sigax_batch* b, void* stream, sigax_stats* sta
     b->last.n_substring = ds[DS_SUBSTRING];
     b->last.n_slow_reads = 0;
     for (int i = 0; i < SIGAX_MAX_SUB; ++i) b->last.n_slow_reads += ds[DS_SLOW_BASE + i];
+    {
+      // Reads with sequencing errors make the extraction branch (every erroneous overlap becomes a group of its own that
+      // is walked to the end of its read); the lean launches hand such items on after wasted work.  If more than a
+      // quarter of the (read, side) items went on, this batch object starts its next 32 runs with the full launches,
+      // then tries the lean ones again.
+      u64 q64 = 0;
+      for (int i = 0; i < SIGAX_MAX_SUB; ++i) q64 += ds[DS_W64_BASE + i];
+      const u64 items = 2ull * b->n_reads;
+      if (!b->lean_off) {
+        if (q64 * 4 > items) {
+          b->lean_off = true;
+          b->lean_off_runs = 32;
+        }
+      } else if (--b->lean_off_runs == 0) {
+        b->lean_off = false;
+      }
+    }
     b->last.n_extract_errors = ds[DS_EXTRACT_ERRORS];
     b->last.n_sectors_find = ds[DS_SEC_FIND];
     b->last.n_sectors_extract = ds[DS_SEC_EXTRACT];

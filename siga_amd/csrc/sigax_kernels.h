@@ -56,6 +56,7 @@ struct FxArgs {
   FmStrand fwd, rev;
   const unsigned long long* offs;
   uint32_t n_reads, cap, irreducible;
+  uint32_t no_lean;   // skip the lean (single-group only) launches: the previous run of this batch object sent most items on
   const void* arena;
   const uint32_t* chain_cnt;
   Ent* pool;          // [lanes][pool_cap]

@@ -1538,6 +1538,7 @@ struct GFx {
   u32 nslot, ni;  // slots handed out, incomings of the current pass
   u64 gAlive;
   u32 gD, gI;
+  bool inreg;     // this item's groups are disjoint lane sets: no pool traffic
 #ifdef SIGAX_FX_PROFILE
   u32 dbg_round;
 #endif
@@ -1600,16 +1601,22 @@ struct GFx {
       *newAlive = gballot(ok);
       return RD_UPDATED;
     }
+    const E e0 = e;
     for (u32 c = 0; c < 5; ++c) {
       u64 ak = c == 0 ? any0 : c == 1 ? any1 : c == 2 ? any2 : c == 3 ? any3 : any4;
       if (!ak) continue;
       if (nslot >= NSLOT || ni >= NSLOT) return RD_BAIL;
       u32 ns = nslot++;
-      E br = e;
+      E br = e0;
       u32 b = qcomp ? comp_rank(c) : c;
       if (mine) apply_updateR(br, b, ix.which, l, u);
       bool ok = mine && valid(br.c0lo, br.c0hi) && valid(br.c1lo, br.c1hi);
-      if (ok) pool_put(wpool + ns * 64 + lane, br);
+      if (ok) {
+        // single-row blocks follow exactly one symbol: the branch PARTITIONS the group's lanes and every lane keeps its
+        // block in registers; only blocks with wider ranges are copied (to the wave's pool in global memory)
+        if (inreg) e = br;
+        else pool_put(wpool + ns * 64 + lane, br);
+      }
       u64 m = gballot(ok);
       if (gl == ns) gAlive = m;
       if (gl == ni) gI = ns;
@@ -1905,6 +1912,7 @@ struct GFx {
     gAlive = 0;
     gD = 0;
     gI = 0;
+    inreg = gballot(gl < n && e.c1hi != e.c1lo) == 0;  // every block a single row (ranges never grow)
 #ifdef SIGAX_FX_PROFILE
     dbg_round = 0;
 #endif
@@ -1939,7 +1947,7 @@ struct GFx {
       while (p != ng) {
         const u32 slot = gshfl(gD, p);
         const u64 alive = gshfl(gAlive, slot);
-        if (slot != cur) {
+        if (slot != cur && !inreg) {
           if (cur != 0xFFFFFFFFu) {
             const u64 was = gshfl(gAlive, cur);
             if ((was >> gl) & 1ull) pool_put(wpool + cur * 64 + lane, e);
@@ -2798,7 +2806,7 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
 void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid32, unsigned grid64, hipStream_t st) {
   if (a.read_end <= a.read_begin) return;
   static const bool no_lean = getenv("SIGAX_FX_NO_LEAN") != nullptr;  // A/B aid
-  const bool lean = a.irreducible && !no_lean;
+  const bool lean = a.irreducible && !no_lean && !a.no_lean;
   const bool have2 = a.fwd.gran2 && a.rev.gran2;
   // 32-lane launch -> lean 64-lane launch -> full 64-lane launch (-> general kernel, launched by the caller).  Without
   // the lean stage the full launch reads the 32-lane launch's queue directly.
