@@ -1958,7 +1958,7 @@ struct GFx {
         bool eraseGroup = true;
         if (alive) {
           u64 na = 0;
-          int st = round_fast(e, alive, &na, false);
+          int st = round_fast(e, alive, &na, ng == 1);  // a lone group may take two rounds at once, as in phase 1
           if (st == RD_BAIL) return false;
           if (st == RD_XERROR) return true;
           if (st == RD_UPDATED) {
