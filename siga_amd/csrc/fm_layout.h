@@ -47,9 +47,13 @@
 #define SIGAX_GRAN2_SYMS 64
 #define SIGAX_GRAN2_WORDS 32
 
+/* 64-bit-position indexes: the 20 counters of a two-step line are relative to the line's superblock of 2^SIGAX_SUPER_SHIFT
+ * rows; super2[sb][20] holds the absolute values at the superblock's first row (same order as the line's words 0..19). */
+
 struct FmStrand {
   const uint32_t* granules;  /* n_granules x 16 u32 */
   const uint32_t* gran2;     /* (n / 64 + 1) x 32 u32, or NULL */
+  const unsigned long long* super2;  /* [n_super][20], wide mode with two-step tables; else NULL */
   const unsigned long long* super;    /* [n_super][4] absolute A,C,G,T counts at each superblock start (wide mode) */
   unsigned long long n;             /* symbols */
   unsigned long long C[5];           /* FMIndex::_pred (src/fmindex.cpp:156-160) */

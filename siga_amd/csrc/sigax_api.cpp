@@ -84,6 +84,7 @@ struct sigax_index {
   FmStrand st[2];  // 0 forward (.bwt), 1 reverse (.rbwt); pointers are device pointers
   void* d_gran[2];
   void* d_gran2[2];  // two-step tables (fm_layout.h) or NULL
+  void* d_super2[2]; // ... their superblock bases (64-bit positions) or NULL
   void* d_super[2];
   uint32_t* d_sai[2];
   u64 n_sai;
@@ -228,6 +229,7 @@ extern "C" void sigax_index_close(sigax_index* ix) {
   for (int s = 0; s < 2; ++s) {
     if (ix->d_gran[s]) hipFree(ix->d_gran[s]);
     if (ix->d_gran2[s]) hipFree(ix->d_gran2[s]);
+    if (ix->d_super2[s]) hipFree(ix->d_super2[s]);
     if (ix->d_super[s]) hipFree(ix->d_super[s]);
     if (ix->d_sai[s]) hipFree(ix->d_sai[s]);
   }
@@ -307,9 +309,9 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
     const char* envm = getenv("SIGAX_TWO_STEP_MAX_SYMBOLS");
     // every index with 32-bit positions: below SIGAX_COOP_MIN_SYMBOLS (2^31) the finder gathers per lane with u32 byte
     // offsets (k_find_n2, tables under 4 GiB), above it lines come cooperatively through LDS with 64-bit addresses (k_find_c2)
-    u64 max2 = envm ? strtoull(envm, nullptr, 10) : 0xFFFFFFF0ull;
-    if (max2 > 0xFFFFFFF0ull) max2 = 0xFFFFFFF0ull;
-    const bool want2 = !ix->wide && n_symbols < max2 && !(env2 && env2[0] == '0');
+    // 64-bit-position indexes too: the lines' counters are then relative to 2^32-row superblocks (fm_layout.h)
+    const u64 max2 = envm ? strtoull(envm, nullptr, 10) : ~0ull;
+    const bool want2 = n_symbols < max2 && !(env2 && env2[0] == '0');
     if (want2) {
       const u64 ng2 = n_symbols / SIGAX_GRAN2_SYMS + 1;
       void *cnt = nullptr, *offs = nullptr, *partial = nullptr, *total = nullptr;
@@ -317,14 +319,21 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
       if (e == hipSuccess) e = hipMalloc(&offs, (ng2 + 2) * 8);
       if (e == hipSuccess) e = hipMalloc(&partial, scan_partials_needed(ng2) * 8);
       if (e == hipSuccess) e = hipMalloc(&total, 8);
+      const u64 nsup2 = ((ng2 - 1) >> (SIGAX_SUPER_SHIFT - 6)) + 1;
       for (int s = 0; s < 2 && e == hipSuccess; ++s) {
         e = hipMalloc(&ix->d_gran2[s], ng2 * SIGAX_GRAN2_WORDS * 4);
         if (e != hipSuccess) break;
         ix->device_bytes += ng2 * SIGAX_GRAN2_WORDS * 4;
-        launch_build2(ix->st[s], (uint32_t*)ix->d_gran2[s], (uint32_t*)cnt, (u64*)offs, (u64*)partial, (u64*)total, nullptr);
+        if (ix->wide) {
+          e = hipMalloc(&ix->d_super2[s], nsup2 * 20 * 8);
+          if (e != hipSuccess) break;
+        }
+        launch_build2(ix->st[s], ix->wide, (uint32_t*)ix->d_gran2[s], (u64*)ix->d_super2[s], (uint32_t*)cnt, (u64*)offs, (u64*)partial,
+                      (u64*)total, nullptr);
         e = hipDeviceSynchronize();
         if (e == hipSuccess) e = hipGetLastError();
         ix->st[s].gran2 = (const uint32_t*)ix->d_gran2[s];
+        ix->st[s].super2 = (const u64*)ix->d_super2[s];
       }
       ix->split_strands = true;
       if (cnt) hipFree(cnt);
@@ -339,8 +348,10 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
             hipFree(ix->d_gran2[s]);
             ix->device_bytes -= ng2 * SIGAX_GRAN2_WORDS * 4;
           }
-          ix->d_gran2[s] = nullptr;
+          if (ix->d_super2[s]) hipFree(ix->d_super2[s]);
+          ix->d_gran2[s] = ix->d_super2[s] = nullptr;
           ix->st[s].gran2 = nullptr;
+          ix->st[s].super2 = nullptr;
         }
         ix->split_strands = false;
         if (getenv("SIGAX_VERBOSE")) fprintf(stderr, "[sigax] two-step tables not built (%s): one-step finder\n", hipGetErrorString(e));
@@ -455,11 +466,13 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
     rc = copy(&ix->d_gran[s], src->d_gran[s], ngran * 64);
     if (rc == SIGAX_OK) rc = copy(&ix->d_super[s], src->d_super[s], nsuper * 32);
     if (rc == SIGAX_OK) rc = copy(&ix->d_gran2[s], src->d_gran2[s], ng2 * SIGAX_GRAN2_WORDS * 4);
+    if (rc == SIGAX_OK) rc = copy(&ix->d_super2[s], src->d_super2[s], (((ng2 - 1) >> (SIGAX_SUPER_SHIFT - 6)) + 1) * 20 * 8);
     if (rc == SIGAX_OK) rc = copy((void**)&ix->d_sai[s], src->d_sai[s], src->n_sai * 4);
     ix->st[s] = src->st[s];
     ix->st[s].granules = (const uint32_t*)ix->d_gran[s];
     ix->st[s].super = (const u64*)ix->d_super[s];
     ix->st[s].gran2 = (const uint32_t*)ix->d_gran2[s];
+    ix->st[s].super2 = (const u64*)ix->d_super2[s];
   }
   if (rc == SIGAX_OK) rc = copy((void**)&ix->d_read_len, src->d_read_len, src->n_meta * 4);
   if (rc == SIGAX_OK) rc = copy((void**)&ix->d_name_rank, src->d_name_rank, src->n_meta * 4);
@@ -860,8 +873,8 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
       // (1.2e9 symbols, one rank's view of an 8-GPU job: 80 M reads/s per lane vs 66 M cooperative, gpurun_out/emu/)
       const u64 coop_min = env_cmin ? strtoull(env_cmin, nullptr, 10) : (1ull << 31);
       const u64 need = 64ull * b->cur_max_len + 16;  // the workgroup's 64 reads, staged as bytes
-      const bool can = fa.two_step && !ix->wide && need <= 32768;
-      const bool want = env_coop ? env_coop[0] != '0' : ix->n_symbols >= coop_min;
+      const bool can = fa.two_step && need <= 32768;
+      const bool want = env_coop ? env_coop[0] != '0' : (ix->wide || ix->n_symbols >= coop_min);
       fa.coop = (can && want) ? 1u : 0u;
       fa.coop_stage_bytes = (uint32_t)((need + 15) & ~15ull);
       // per-lane gathers use 32-bit byte offsets into the two-step table: beyond 2^31 symbols only the cooperative form works

@@ -138,7 +138,7 @@ void launch_scan(const uint32_t* cnt, unsigned long long n, unsigned long long* 
 unsigned long long scan_partials_needed(unsigned long long n);
 // Two-step table of one strand (fm_layout.h): gran2 = (n/64+1) x 32 u32; cnt = 20 x (n/64+1) u32, offs = (n/64+2) u64,
 // partial = scan_partials_needed(n/64+1) u64, total = 1 u64 of scratch.
-void launch_build2(const FmStrand& s, uint32_t* gran2, uint32_t* cnt, unsigned long long* offs, unsigned long long* partial,
+void launch_build2(const FmStrand& s, bool wide, uint32_t* gran2, unsigned long long* super2, uint32_t* cnt, unsigned long long* offs, unsigned long long* partial,
                    unsigned long long* total, hipStream_t st);
 void launch_order_scatter(const OrderArgs& a, hipStream_t st);
 unsigned long long fast_fin_chunk();

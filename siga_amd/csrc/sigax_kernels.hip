@@ -366,6 +366,7 @@ __device__ __forceinline__ void store_block(sigax_block* dst, u64 c0lo, u64 c0hi
 
 // ---- two-step table (fm_layout.h) -------------------------------------------------------------------------------
 // built on the device from the one-step granules: one wave per 64 rows
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_build2_a(FmStrand s, u32* gran2, u32* cnt, u64 ng2) {
   const FmRef F = fm_ref(s, 0);
   const u32 lane = threadIdx.x & 63u;
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void k_build2_a(FmStrand s, u32* gran2, u32* c
     if (p < s.n) {
       c1 = fm_char(F, p);
       if (c1 >= 1 && c1 <= 4) {
-        const Cnt4 k = fm_rank<false>(F, p);
+        const Cnt4 k = fm_rank<WIDE>(F, p);
         const u64 rk = c1 == 1 ? k.a : c1 == 2 ? k.c : c1 == 3 ? k.g : k.t;
         c2 = fm_char(F, s.C[c1] + rk);  // BWT[LF(p)]
       } else {
@@ -403,9 +404,18 @@ __global__ __launch_bounds__(256) void k_build2_a(FmStrand s, u32* gran2, u32* c
     }
   }
 }
-__global__ __launch_bounds__(256) void k_build2_b(const u64* offs, u32* gran2, u32 col, u64 ng2) {
+// counter `col` of every line; with 64-bit positions relative to the line's superblock, whose base goes to super2
+__global__ __launch_bounds__(256) void k_build2_b(const u64* offs, u32* gran2, u32 col, u64 ng2, u64* super2) {
   const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (g < ng2) gran2[g * SIGAX_GRAN2_WORDS + col] = (u32)offs[g];
+  if (g >= ng2) return;
+  u64 base = 0;
+  if (super2) {
+    const u32 sh = SIGAX_SUPER_SHIFT - 6;  // lines per superblock = 2^sh
+    const u64 first = (g >> sh) << sh;
+    base = offs[first];
+    if (g == first) super2[(g >> sh) * 20 + col] = base;
+  }
+  gran2[g * SIGAX_GRAN2_WORDS + col] = (u32)(offs[g] - base);
 }
 
 #ifndef SIGAX_FIND_POLICY
@@ -525,19 +535,24 @@ __device__ __forceinline__ Rank2 rank2_from(const Gran2& q, u32 r, u32 c) {  // 
   return o;
 }
 // constants of a double step, per strand: Cc[c][e] = Occ(e, C[c]); Cd[c] = Occ('$', C[c])
-struct Find2Tables {
-  u32 Cc[2][4][4];
-  u32 Cd[2][4];
+template <bool WIDE>
+struct Find2TablesT {
+  typedef typename PosOf<WIDE>::type P;
+  P Cc[2][4][4];
+  P Cd[2][4];
 };
-__device__ __forceinline__ void find2_tables_load(Find2Tables& t, const FmStrand& fwd, const FmStrand& rev) {
+typedef Find2TablesT<false> Find2Tables;
+template <bool WIDE>
+__device__ __forceinline__ void find2_tables_load(Find2TablesT<WIDE>& t, const FmStrand& fwd, const FmStrand& rev) {
+  typedef typename PosOf<WIDE>::type P;
   if (threadIdx.x < 8) {
     const u32 which = threadIdx.x >> 2, c = (threadIdx.x & 3u) + 1u;
     const FmStrand& st = which ? rev : fwd;
     const FmRef F = fm_ref(st, which);
     const u64 pos = st.C[c];
-    const Cnt4 k = fm_rank<false>(F, pos);
-    t.Cc[which][c - 1][0] = (u32)k.a; t.Cc[which][c - 1][1] = (u32)k.c; t.Cc[which][c - 1][2] = (u32)k.g; t.Cc[which][c - 1][3] = (u32)k.t;
-    t.Cd[which][c - 1] = (u32)(pos - (k.a + k.c + k.g + k.t));
+    const Cnt4 k = fm_rank<WIDE>(F, pos);
+    t.Cc[which][c - 1][0] = (P)k.a; t.Cc[which][c - 1][1] = (P)k.c; t.Cc[which][c - 1][2] = (P)k.g; t.Cc[which][c - 1][3] = (P)k.t;
+    t.Cd[which][c - 1] = (P)(pos - (k.a + k.c + k.g + k.t));
   }
 }
 
@@ -581,7 +596,7 @@ __device__ __forceinline__ void find_flush(SG& sg, bool want, u32 tid) {
 // 4-byte-aligned address at or below the first read's first base; rd_base = that address's offset in A.seqs.
 // COOP: the double step's lines come through LDS (find_step2_dma); NT = threads of the workgroup
 template <bool WIDE, bool STAGED, bool TWO, bool COOP = false, int NT = 256, class SG = FindStage>
-__device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& sg, const Find2Tables& t2,
+__device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& sg, const Find2TablesT<WIDE>& t2,
                                           const unsigned char* rd, u64 rd_base, uint4* coop_stage = nullptr) {
   // A workgroup = 64 reads; wave o of it walks chain o of each, so everything that depends on the chain (which index
   // is primary, complementing, the direction the read is consumed in) is wave-uniform and lives in scalar registers.
@@ -609,6 +624,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
   const u64* CP = tb.C[PI.which];
   const u64* CO = tb.C[OI.which];
   const void* PI2 = pf ? (const void*)A.fwd.gran2 : (const void*)A.rev.gran2;  // two-step table of the primary index
+  const u64* PS2 = pf ? A.fwd.super2 : A.rev.super2;                           // ... its superblock bases (64-bit positions)
   const bool comp = (o & 1u) != 0;            // chains 1 (revcomp) and 3 (complement)
   const bool fromStart = (o == 1 || o == 2);  // reversed strings are consumed from the read's first base
   const u32 af = o == 0 ? SIGAX_AF_CHAIN0 : o == 1 ? SIGAX_AF_CHAIN1 : o == 2 ? SIGAX_AF_CHAIN2 : SIGAX_AF_CHAIN3;
@@ -676,45 +692,59 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
         bool fl1 = false, fl2 = false, two_lines = false;
         P lo1n = 0, lo0n = 0, szn = 0, ldn = 0, dd2 = 0, nlo1 = 0, nlo0 = 0, nsz = 0;
         Gran2 ga, gb;
-        u32 pl = 0, pu = 0;
+        P pl = 0, pu = 0;
         if (on) {
-          const u32 nn = (u32)PI.n;  // never leave the table, whatever an invalid interval holds
-          pl = (u32)lo0 > nn ? nn : (u32)lo0;
-          pu = (u32)(lo0 + sz) > nn ? nn : (u32)(lo0 + sz);
+          const P nn = (P)PI.n;  // never leave the table, whatever an invalid interval holds
+          pl = lo0 > nn ? nn : lo0;
+          const P up = (P)(lo0 + sz);
+          pu = (up > nn || up < lo0) ? nn : up;
           two_lines = (pl >> 6) != (pu >> 6);
         }
         if (COOP) {
           // all 64 lanes take part in the loads (an idle chain asks for line 0)
-          find_step2_dma(reinterpret_cast<const uint32_t*>(PI2), pl >> 6, pu >> 6, on ? c : 1u, coop_stage + wv * COOP_WAVE_U4, tid & 63u, ga, gb);
+          find_step2_dma(reinterpret_cast<const uint32_t*>(PI2), (u32)(pl >> 6), (u32)(pu >> 6), on ? c : 1u,
+                         coop_stage + wv * COOP_WAVE_U4, tid & 63u, ga, gb);
         }
         if (on) {
           if (!COOP) {
-            const u32 oa = (pl >> 6) * 128u, ob = (pu >> 6) * 128u;
+            const u32 oa = (u32)(pl >> 6) * 128u, ob = (u32)(pu >> 6) * 128u;
             find_step2_loads(PI2, oa, oa + 16u * c, ob, ob + 16u * c, ga, gb);
           }
-          const Rank2 l = rank2_from(ga, pl & 63u, c), u = rank2_from(gb, pu & 63u, c);
-          const u32 da = u.a - l.a, dc = u.c - l.c, dg = u.g - l.g, dt = u.t - l.t;
-          const u32 dd = (u32)sz - (da + dc + dg + dt);  // '$' extensions of the current string
-          const u32 ld = (u32)lo0 - (l.a + l.c + l.g + l.t);
-          if (s >= A.minov && dd > 0) fl1 = emit((P)ld, (P)dd, lo1, lo0, sz, s);
+          const Rank2 lr = rank2_from(ga, (u32)pl & 63u, c), ur = rank2_from(gb, (u32)pu & 63u, c);
+          // counts in the index's position type; with 64-bit positions the line's counters are relative to its superblock
+          P la = lr.a, lcn = lr.c, lg = lr.g, lt = lr.t, ua = ur.a, ucn = ur.c, ug = ur.g, ut = ur.t;
+          P lpa = lr.pa, lpc = lr.pc, lpg = lr.pg, lpt = lr.pt, upa = ur.pa, upc = ur.pc, upg = ur.pg, upt = ur.pt;
+          if (WIDE) {
+            const u64* sl = PS2 + ((u64)pl >> SIGAX_SUPER_SHIFT) * 20;
+            const u64* su = PS2 + ((u64)pu >> SIGAX_SUPER_SHIFT) * 20;
+            const u32 pb = 4u + (c - 1u) * 4u;
+            la += (P)sl[0]; lcn += (P)sl[1]; lg += (P)sl[2]; lt += (P)sl[3];
+            ua += (P)su[0]; ucn += (P)su[1]; ug += (P)su[2]; ut += (P)su[3];
+            lpa += (P)sl[pb]; lpc += (P)sl[pb + 1]; lpg += (P)sl[pb + 2]; lpt += (P)sl[pb + 3];
+            upa += (P)su[pb]; upc += (P)su[pb + 1]; upg += (P)su[pb + 2]; upt += (P)su[pb + 3];
+          }
+          const P da = ua - la, dc = ucn - lcn, dg = ug - lg, dt = ut - lt;
+          const P dd = sz - (da + dc + dg + dt);  // '$' extensions of the current string
+          const P ld = lo0 - (la + lcn + lg + lt);
+          if (s >= A.minov && dd > 0) fl1 = emit(ld, dd, lo1, lo0, sz, s);
           // first step, symbol c (overlap_builder.cpp:112-122)
-          const u32 acc1 = sel5<u32>(c, 0u, dd, dd + da, dd + da + dc, dd + da + dc + dg);
-          const u32 lc = sel5<u32>(c, ld, l.a, l.c, l.g, l.t);
-          const u32 dcc = sel5<u32>(c, dd, da, dc, dg, dt);
-          lo1n = lo1 + (P)acc1;
-          lo0n = (P)CP[c] + (P)lc;
-          szn = (P)dcc;
+          const P acc1 = sel5<P>(c, (P)0, dd, dd + da, dd + da + dc, dd + da + dc + dg);
+          const P lc = sel5<P>(c, ld, la, lcn, lg, lt);
+          const P dcc = sel5<P>(c, dd, da, dc, dg, dt);
+          lo1n = lo1 + acc1;
+          lo0n = (P)CP[c] + lc;
+          szn = dcc;
           // second step, symbol e, from the pair counts: Occ(e, lo0n) = Cc[c][e] + R2(e, c, lower), same for upper
-          const u32 d2a = u.pa - l.pa, d2c = u.pc - l.pc, d2g = u.pg - l.pg, d2t = u.pt - l.pt;
-          const u32 l2d = lc - (l.pa + l.pc + l.pg + l.pt);  // rows below with first symbol c and '$' before it
-          dd2 = (P)(dcc - (d2a + d2c + d2g + d2t));
-          ldn = (P)(t2.Cd[PI.which][c - 1] + l2d);               // Occ('$', lo0n)
-          const u32 acc2 = sel5<u32>(e, 0u, (u32)dd2, (u32)dd2 + d2a, (u32)dd2 + d2a + d2c, (u32)dd2 + d2a + d2c + d2g);
-          const u32 l2e = sel5<u32>(e, 0u, l.pa, l.pc, l.pg, l.pt);
-          const u32 d2e = sel5<u32>(e, 0u, d2a, d2c, d2g, d2t);
-          nlo1 = lo1n + (P)acc2;
-          nlo0 = (P)CP[e] + (P)(t2.Cc[PI.which][c - 1][e - 1] + l2e);
-          nsz = (P)d2e;
+          const P d2a = upa - lpa, d2c = upc - lpc, d2g = upg - lpg, d2t = upt - lpt;
+          const P l2d = lc - (lpa + lpc + lpg + lpt);  // rows below with first symbol c and '$' before it
+          dd2 = dcc - (d2a + d2c + d2g + d2t);
+          ldn = t2.Cd[PI.which][c - 1] + l2d;               // Occ('$', lo0n)
+          const P acc2 = sel5<P>(e, (P)0, dd2, dd2 + d2a, dd2 + d2a + d2c, dd2 + d2a + d2c + d2g);
+          const P l2e = sel5<P>(e, (P)0, lpa, lpc, lpg, lpt);
+          const P d2e = sel5<P>(e, (P)0, d2a, d2c, d2g, d2t);
+          nlo1 = lo1n + acc2;
+          nlo0 = (P)CP[e] + t2.Cc[PI.which][c - 1][e - 1] + l2e;
+          nsz = d2e;
         }
         nsec += 2u * (u32)(__popcll(__ballot(on)) + __popcll(__ballot(two_lines)));
         find_flush(sg, fl1, tid);
@@ -880,10 +910,23 @@ __global__ __launch_bounds__(128) void k_find_c2(FindArgs A) {
   if (staged) find_body<false, true, true, true, 128, FindStageC>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
   else find_body<false, false, false, false, 128, FindStageC>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
 }
+// the same with 64-bit positions (indexes of 2^32 symbols and more: BASELINE configs[4])
+__global__ __launch_bounds__(128) void k_find_c2w(FindArgs A) {
+  __shared__ FmTables tb;
+  __shared__ Find2TablesT<true> t2;
+  __shared__ __attribute__((aligned(16))) uint4 stage[2 * COOP_WAVE_U4];
+  u64 rd_base = 0;
+  const bool staged = find_stage_reads<128>(A, &rd_base);
+  find2_tables_load<true>(t2, A.fwd, A.rev);
+  fm_tables_load(tb, A.fwd, A.rev);
+  __shared__ FindStageC sg;
+  if (staged) find_body<true, true, true, true, 128, FindStageC>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
+  else find_body<true, false, false, false, 128, FindStageC>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
+}
 __global__ __launch_bounds__(256) void k_find_w(FindArgs A) {
   __shared__ FmTables tb;
   __shared__ FindStage sg;
-  __shared__ Find2Tables t2;  // unused here
+  __shared__ Find2TablesT<true> t2;  // unused here
   u64 rd_base = 0;
   const bool staged = find_stage_reads(A, &rd_base);
   fm_tables_load(tb, A.fwd, A.rev);
@@ -1452,7 +1495,7 @@ struct GFx {
   FmRef F, R;
   Ent* wpool;  // FX_NSLOT group slots of 64 entries (branch copies only), shared by the wave's lane groups
   BigSh<WIDE>* big;  // 64-lane launch only: scratch for items of more than 64 blocks
-  const Find2Tables* t2;  // constants of the two-step table, or NULL when the index has none
+  const Find2TablesT<WIDE>* t2;  // constants of the two-step table, or NULL when the index has none
   u32 lane;    // lane in the wave
   u32 gb;      // first lane of this lane's group (0, or 32 for the second group when W == 32)
   u32 gl;      // lane inside the group
@@ -1463,7 +1506,7 @@ struct GFx {
   bool xerror;
   u64 fin_cur, fin_end;  // this wave's chunk of the unordered final-block arena (wave-uniform)
 
-  __device__ GFx(const FxArgs& a, const FmTables& t, SideSh<WIDE>& s, Ent* wp, const Find2Tables* tt)
+  __device__ GFx(const FxArgs& a, const FmTables& t, SideSh<WIDE>& s, Ent* wp, const Find2TablesT<WIDE>* tt)
       : A(a), tb(t), sh(s), F(fm_ref(a.fwd, 0)), R(fm_ref(a.rev, 1)), wpool(wp), big(nullptr), t2(tt), lane(threadIdx.x & 63u),
         gb(W == 64 ? 0u : (threadIdx.x & 32u)), gl(W == 64 ? (threadIdx.x & 63u) : (threadIdx.x & 31u)),
         glt((1ull << (W == 64 ? (threadIdx.x & 63u) : (threadIdx.x & 31u))) - 1ull), slots(nullptr), nout(0), nocc(0),
@@ -1642,15 +1685,15 @@ struct GFx {
     // blocks and neither of them '$': both rounds are then "usual" rounds (no top-level end, no branch), capped[0] and
     // the range size do not move, and capped[1].lower = C[e] + Occ(e, C[c]) + R2(e, c, lower).  If only the first
     // symbol is common, ONE round from the same line.  Anything else goes on to the one-step forms below.
-    if (!WIDE && LEANP != 2 && t2 != nullptr) {
-      const u32 q0 = (u32)p0, q1 = (u32)p1;
+    if (LEANP != 2 && t2 != nullptr) {
+      const P q0 = (P)p0, q1 = (P)p1;
       const bool in2 = mine && q1 > q0 && ((q1 - 1u) >> 6) == (q0 >> 6) && p1 <= ix.n;
       if (gballot(mine && !in2) != 0) FXP(9);  // a range crosses a 64-row line: no two-step lookup
       if (gballot(mine && !in2) == 0) {
         FXP(8);
 #ifdef SIGAX_FX_PROFILE
         {  // how many 128-byte lines do the alive blocks of this round span?
-          u32 mn = mine ? (q0 >> 6) : 0xFFFFFFFFu, mx = mine ? (q0 >> 6) : 0u;
+          u32 mn = mine ? (u32)(q0 >> 6) : 0xFFFFFFFFu, mx = mine ? (u32)(q0 >> 6) : 0u;
           for (int off = (W == 64 ? 32 : 16); off > 0; off >>= 1) {
             mn = min(mn, (u32)__shfl_xor((int)mn, off, 64));
             mx = max(mx, (u32)__shfl_xor((int)mx, off, 64));
@@ -1664,6 +1707,8 @@ struct GFx {
         }
 #endif
         const u32* gq = (find_of(e.src) < 2 ? A.rev.gran2 : A.fwd.gran2) + (u64)(q0 >> 6) * SIGAX_GRAN2_WORDS;
+        // 64-bit positions: the line's counters are relative to its superblock (fm_layout.h)
+        const u64* sq = WIDE ? (find_of(e.src) < 2 ? A.rev.super2 : A.fwd.super2) + ((u64)q0 >> SIGAX_SUPER_SHIFT) * 20 : nullptr;
         uint4 a4 = make_uint4(0, 0, 0, 0), a5 = a4, a6 = a4, a7 = a4;
         if (mine) {
           const uint4* pq = reinterpret_cast<const uint4*>(gq + 20);
@@ -1671,7 +1716,7 @@ struct GFx {
           a5 = pq[0]; a6 = pq[1]; a7 = pq[2];
         }
         sec_add(2u * pop(alive));
-        const u32 r0 = q0 & 63u, r1 = r0 + (q1 - q0);  // 0 <= r0 < r1 <= 64
+        const u32 r0 = (u32)q0 & 63u, r1 = r0 + (u32)(q1 - q0);  // 0 <= r0 < r1 <= 64
         const u32 lo0 = r0 < 32u ? r0 : 32u, hi0 = r1 < 32u ? r1 : 32u;           // the range inside the low word
         const u32 lo1 = r0 > 32u ? r0 - 32u : 0u, hi1 = r1 > 32u ? r1 - 32u : 0u;  // ... inside the high word
         const u32 w0 = hi0 - lo0, w1 = hi1 - lo1;
@@ -1705,9 +1750,10 @@ struct GFx {
             const u32 ne = pop(emitMask);
             if (nout + ne > OUTCAP) return RD_BAIL;
             if ((emitMask >> gl) & 1ull) {
-              const u32 acgt = a4.x + a4.y + a4.z + a4.w + __popc(~ds0 & bl0) + __popc(~ds1 & bl1);
+              P acgt = (P)(a4.x + a4.y + a4.z + a4.w + __popc(~ds0 & bl0) + __popc(~ds1 & bl1));
+              if (WIDE) acgt += (P)(sq[0] + sq[1] + sq[2] + sq[3]);
               const u32 nd = __popc(ds0 & rm0) + __popc(ds1 & rm1);
-              const P ld = (P)(q0 - acgt);  // Occ('$', lower - 1); C['$'] = 0
+              const P ld = q0 - acgt;  // Occ('$', lower - 1); C['$'] = 0
               E br = e;
               br.c0hi = br.c0lo + (P)nd - 1;
               br.c1lo = ld;
@@ -1736,13 +1782,16 @@ struct GFx {
           if (mine) {
             const P size = e.c1hi - e.c1lo;
             if (two) {
-              const u32 hdr = gq[4 + (c - 1u) * 4 + (x - 1u)];
+              const u32 hi = 4 + (c - 1u) * 4 + (x - 1u);
               const u32 below = __popc(~(d10 | d20) & bl0) + __popc(~(d11 | d21) & bl1);
-              e.c1lo = (P)tb.C[ix.which][x] + (P)(t2->Cc[ix.which][c - 1][x - 1] + hdr + below);
+              P v = (P)tb.C[ix.which][x] + t2->Cc[ix.which][c - 1][x - 1] + (P)(gq[hi] + below);
+              if (WIDE) v += (P)sq[hi];
+              e.c1lo = v;
             } else {
-              const u32 hdr = gq[c - 1u];
               const u32 below = __popc(~d10 & bl0) + __popc(~d11 & bl1);
-              e.c1lo = (P)tb.C[ix.which][c] + (P)(hdr + below);
+              P v = (P)tb.C[ix.which][c] + (P)(gq[c - 1u] + below);
+              if (WIDE) v += (P)sq[c - 1u];
+              e.c1lo = v;
             }
             e.c1hi = e.c1lo + size;
           }
@@ -2352,10 +2401,10 @@ struct GFx {
 template <bool WIDE, int W, int LEAN = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? (LEAN ? 2 : 1) : (LEAN ? SIGAX_FX_LEAN_WAVES : 4)))) void k_filter_extract_fast(FxArgs A) {
   __shared__ FmTables tb;
-  __shared__ Find2Tables t2;
+  __shared__ Find2TablesT<WIDE> t2;
   __shared__ SideSh<WIDE> shm[4];
-  const bool have2 = !WIDE && A.fwd.gran2 != nullptr && A.rev.gran2 != nullptr;
-  if (have2) find2_tables_load(t2, A.fwd, A.rev);
+  const bool have2 = A.fwd.gran2 != nullptr && A.rev.gran2 != nullptr;
+  if (have2) find2_tables_load<WIDE>(t2, A.fwd, A.rev);
   fm_tables_load(tb, A.fwd, A.rev);
   const u32 wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const u64 wave = (u64)blockIdx.x * 4 + wid, nwaves = (u64)gridDim.x * 4;
@@ -2791,11 +2840,12 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
   unsigned lds = (unsigned)find_stage_capacity();  // the record staging rows are part of the budget
   FindArgs b = a;
   b.stage_bytes = lds;  // the residency cap doubles as the staging buffer for the workgroup's reads
-  if (!wide && a.coop && a.two_step && a.fwd.gran2 && a.rev.gran2 && a.chains_per_wg == 2) {
+  if (a.coop && a.two_step && a.fwd.gran2 && a.rev.gran2 && a.chains_per_wg == 2) {
     // 64 reads per workgroup; the dynamic LDS holds exactly their bases (no residency padding: LDS is what limits it)
     const unsigned gc = nblk((u64)(a.read_end - a.read_begin), 64u);
     b.stage_bytes = a.coop_stage_bytes;
-    hipLaunchKernelGGL(k_find_c2, dim3(gc), dim3(128), a.coop_stage_bytes, st, b);
+    if (wide) hipLaunchKernelGGL(k_find_c2w, dim3(gc), dim3(128), a.coop_stage_bytes, st, b);
+    else hipLaunchKernelGGL(k_find_c2, dim3(gc), dim3(128), a.coop_stage_bytes, st, b);
     return;
   }
   if (wide) hipLaunchKernelGGL(k_find_w, dim3(g), dim3(bs), lds, st, b);
@@ -2816,7 +2866,10 @@ void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid32, uns
     full.w64b_counter = a.w64_counter;
   }
   if (wide) {
-    if (lean) {
+    if (lean && have2) {
+      hipLaunchKernelGGL((k_filter_extract_fast<true, 32, 1>), dim3(grid32), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_filter_extract_fast<true, 64, 1>), dim3(grid64), dim3(256), 0, st, a);
+    } else if (lean) {
       hipLaunchKernelGGL((k_filter_extract_fast<true, 32, 2>), dim3(grid32), dim3(256), 0, st, a);
       hipLaunchKernelGGL((k_filter_extract_fast<true, 64, 2>), dim3(grid64), dim3(256), 0, st, a);
     } else {
@@ -2855,12 +2908,14 @@ void launch_scan(const u32* cnt, u64 n, u64* partial, u64* offs, u64* total_out,
   hipLaunchKernelGGL(k_scan_apply, dim3(g), dim3(256), 0, st, cnt, n, (const u64*)partial, offs);
 }
 
-void launch_build2(const FmStrand& s, u32* gran2, u32* cnt, u64* offs, u64* partial, u64* total, hipStream_t st) {
+void launch_build2(const FmStrand& s, bool wide, u32* gran2, u64* super2, u32* cnt, u64* offs, u64* partial, u64* total, hipStream_t st) {
   const u64 ng2 = s.n / SIGAX_GRAN2_SYMS + 1;
-  hipLaunchKernelGGL(k_build2_a, dim3((unsigned)std::min<u64>(nblk(ng2, 4), 65536)), dim3(256), 0, st, s, gran2, cnt, ng2);
+  const unsigned g = (unsigned)std::min<u64>(nblk(ng2, 4), 65536);
+  if (wide) hipLaunchKernelGGL(k_build2_a<true>, dim3(g), dim3(256), 0, st, s, gran2, cnt, ng2);
+  else hipLaunchKernelGGL(k_build2_a<false>, dim3(g), dim3(256), 0, st, s, gran2, cnt, ng2);
   for (u32 col = 0; col < 20; ++col) {
     launch_scan(cnt + (u64)col * ng2, ng2, partial, offs, total, st);
-    hipLaunchKernelGGL(k_build2_b, dim3(nblk(ng2, 256)), dim3(256), 0, st, (const u64*)offs, gran2, col, ng2);
+    hipLaunchKernelGGL(k_build2_b, dim3(nblk(ng2, 256)), dim3(256), 0, st, (const u64*)offs, gran2, col, ng2, wide ? super2 : (u64*)nullptr);
   }
 }
 
