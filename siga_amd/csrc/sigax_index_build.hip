@@ -334,20 +334,31 @@ struct IsRow {
 // RL units (src/rlstring.h:10-63) with the 31-cap of src/bwt.cpp:17: a unit starts where the symbol changes or where
 // the run's offset is a multiple of 31.  One thread per 64 symbols; count pass, scan, write pass.
 #define RL_CHUNK 64
-__device__ __forceinline__ u32 rl_offset_at(const unsigned char* __restrict__ B, u64 s) {  // run offset (mod 31) of symbol s
-  const unsigned char c = B[s];
-  u64 k = 0;
-  while (k < s && B[s - 1 - k] == c) ++k;
-  return (u32)(k % 31);
-}
-template <bool WRITE>
-__global__ __launch_bounds__(256) void k_rl_units(const unsigned char* __restrict__ B, u64 n, u32* __restrict__ cnt, const u64* __restrict__ uoff,
-                                                 unsigned char* __restrict__ runs) {
+// where the run holding a chunk's first symbol starts: per chunk the last position (+1) at which the symbol changes, then
+// an inclusive max-scan over the chunks (a long run -- a homopolymer region at depth -- must not be walked back per chunk)
+__global__ __launch_bounds__(256) void k_rl_heads(const unsigned char* __restrict__ B, u64 n, u64* __restrict__ lasthead) {
   const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
   const u64 s = t * RL_CHUNK;
   if (s >= n) return;
   const u64 e = s + RL_CHUNK < n ? s + RL_CHUNK : n;
-  u32 o = rl_offset_at(B, s);
+  u64 last = 0;  // 0 = no run starts in this chunk
+  for (u64 i = s; i < e; ++i)
+    if (i == 0 || B[i] != B[i - 1]) last = i + 1;
+  lasthead[t] = last;
+}
+struct MaxU64 {
+  __device__ u64 operator()(u64 a, u64 b) const { return a > b ? a : b; }
+};
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_rl_units(const unsigned char* __restrict__ B, u64 n, const u64* __restrict__ headscan, u32* __restrict__ cnt,
+                                                 const u64* __restrict__ uoff, unsigned char* __restrict__ runs) {
+  const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u64 s = t * RL_CHUNK;
+  if (s >= n) return;
+  const u64 e = s + RL_CHUNK < n ? s + RL_CHUNK : n;
+  // offset (mod 31) of the chunk's first symbol inside its run
+  u32 o = 0;
+  if (s > 0 && B[s] == B[s - 1]) o = (u32)((s - (headscan[t - 1] - 1)) % 31);
   u32 count = 0;
   u64 w = WRITE ? uoff[t] : 0;
   unsigned char prev = B[s];
@@ -689,20 +700,33 @@ static int build_strand(const char* seqs, const uint64_t* offs, uint64_t n_reads
   // RL units
   const u64 nchunks = (n + RL_CHUNK - 1) / RL_CHUNK;
   u32* cnt = nullptr;
-  u64 *uoff = nullptr, *partial = nullptr, *total = nullptr;
+  u64 *uoff = nullptr, *partial = nullptr, *total = nullptr, *headscan = nullptr, *lasthead = nullptr;
+  IB_TRY(pool.alloc(&headscan, nchunks + 1));
+  IB_TRY(pool.alloc(&lasthead, nchunks + 1));
   IB_TRY(pool.alloc(&cnt, nchunks + 1));
   IB_TRY(pool.alloc(&uoff, nchunks + 2));
   IB_TRY(pool.alloc(&partial, scan_partials_needed(nchunks)));
   IB_TRY(pool.alloc(&total, 1));
   u64 nruns = 0;
   if (n) {
-    hipLaunchKernelGGL(k_rl_units<false>, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, 0, (const unsigned char*)B, n, cnt, (const u64*)nullptr, (unsigned char*)nullptr);
+    hipLaunchKernelGGL(k_rl_heads, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, 0, (const unsigned char*)B, n, lasthead);
+    {
+      size_t tb = 0;
+      IB_TRY(rocprim::inclusive_scan(nullptr, tb, lasthead, headscan, (size_t)nchunks, MaxU64()));
+      void* tmp = nullptr;
+      IB_TRY(pool.alloc((char**)&tmp, tb));
+      IB_TRY(rocprim::inclusive_scan(tmp, tb, lasthead, headscan, (size_t)nchunks, MaxU64()));
+      IB_TRY(hipDeviceSynchronize());
+      pool.release(tmp);
+      pool.release(lasthead);
+    }
+    hipLaunchKernelGGL(k_rl_units<false>, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, 0, (const unsigned char*)B, n, (const u64*)headscan, cnt, (const u64*)nullptr, (unsigned char*)nullptr);
     launch_scan(cnt, nchunks, partial, uoff, total, 0);
     IB_TRY(hipMemcpy(&nruns, total, 8, hipMemcpyDeviceToHost));
   }
   unsigned char* d_runs = nullptr;
   IB_TRY(pool.alloc(&d_runs, nruns + 16));
-  if (n) hipLaunchKernelGGL(k_rl_units<true>, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, 0, (const unsigned char*)B, n, (u32*)nullptr, (const u64*)uoff, d_runs);
+  if (n) hipLaunchKernelGGL(k_rl_units<true>, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, 0, (const unsigned char*)B, n, (const u64*)headscan, (u32*)nullptr, (const u64*)uoff, d_runs);
   IB_TRY(hipDeviceSynchronize());
   IB_TRY(hipGetLastError());
   uint8_t* runs = (uint8_t*)malloc(std::max<u64>(nruns, 1));

@@ -65,6 +65,7 @@ def test_gpu_index_repeats_and_degenerate_sets(tmp_path):
         "polya": ["A" * 70] * 40 + ["A" * k for k in range(1, 60)],
         "tandem": ["ACG" * 30, "CGA" * 30, "GAC" * 30] * 30 + [base[i:i + 90] for i in range(0, 200, 3)],
         "deep": [base[i:i + 100] for i in range(0, 200)] * 2,          # 200x coverage of a short genome, each read twice
+        "runs": ["A" * 200] * 60 + ["C" * 150] * 40 + ["ACGT" * 10],  # BWT runs of thousands of symbols: many 31-unit runs
         "single": ["ACGTTGCA"],
         "ones": ["A", "C", "A", "T", "N", "A"],
     }
