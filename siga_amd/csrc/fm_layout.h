@@ -50,8 +50,14 @@
 /* 64-bit-position indexes: the 20 counters of a two-step line are relative to the line's superblock of 2^SIGAX_SUPER_SHIFT
  * rows; super2[sb][20] holds the absolute values at the superblock's first row (same order as the line's words 0..19). */
 
+/* Row-end table (built on the device at open time, one u64 per BWT row, optional): for the suffix at row p, how many
+ * backward steps lead to the first symbol of its read (high word: t = its offset in the read, BWT[row] = '$' after t steps)
+ * and Occ('$') at that row (low word) -- what a single-row block's right extension to the end of its read arrives at
+ * (IrreducibleBlockListExtractor::extract, src/overlap_builder.cpp:747-766), without walking there. */
+
 struct FmStrand {
   const uint32_t* granules;  /* n_granules x 16 u32 */
+  const unsigned long long* rowend;  /* [n] (t << 32 | dollar rank), or NULL */
   const uint32_t* gran2;     /* (n / 64 + 1) x 32 u32, or NULL */
   const unsigned long long* super2;  /* [n_super][20], wide mode with two-step tables; else NULL */
   const unsigned long long* super;    /* [n_super][4] absolute A,C,G,T counts at each superblock start (wide mode) */

@@ -85,6 +85,7 @@ struct sigax_index {
   void* d_gran[2];
   void* d_gran2[2];  // two-step tables (fm_layout.h) or NULL
   void* d_super2[2]; // ... their superblock bases (64-bit positions) or NULL
+  void* d_rowend[2]; // row-end tables (fm_layout.h) or NULL
   void* d_super[2];
   uint32_t* d_sai[2];
   u64 n_sai;
@@ -230,6 +231,7 @@ extern "C" void sigax_index_close(sigax_index* ix) {
     if (ix->d_gran[s]) hipFree(ix->d_gran[s]);
     if (ix->d_gran2[s]) hipFree(ix->d_gran2[s]);
     if (ix->d_super2[s]) hipFree(ix->d_super2[s]);
+    if (ix->d_rowend[s]) hipFree(ix->d_rowend[s]);
     if (ix->d_super[s]) hipFree(ix->d_super[s]);
     if (ix->d_sai[s]) hipFree(ix->d_sai[s]);
   }
@@ -358,6 +360,41 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
       }
     }
   }
+  // Row-end tables for the irreducible extractor (8 bytes per symbol and strand): a branch that leaves ONE single-row block
+  // in a group -- what a substitution in an overlapping read does -- is resolved by one lookup instead of a walk to the end
+  // of that read (~100 dependent rounds).  An accelerator like the two-step tables: skipped when memory is short or
+  // SIGAX_ROWEND=0, and the extractor then walks.
+  {
+    const char* envr = getenv("SIGAX_ROWEND");
+    size_t mfree = 0, mtotal = 0;
+    (void)hipMemGetInfo(&mfree, &mtotal);
+    const u64 need = 16ull * n_symbols;
+    if (!(envr && envr[0] == '0') && ix->st[0].C[1] < 0xFFFFFFFFull && n_symbols > 0 && need < mfree / 2) {
+      hipError_t e = hipSuccess;
+      for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+        e = hipMalloc(&ix->d_rowend[s], n_symbols * 8);
+        if (e != hipSuccess) break;
+        e = hipMemset(ix->d_rowend[s], 0, n_symbols * 8);
+        if (e != hipSuccess) break;
+        launch_rowend_build(ix->st[s], ix->wide, ix->st[s].C[1], (u64*)ix->d_rowend[s], nullptr);
+        e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipGetLastError();
+      }
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        for (int s = 0; s < 2; ++s) {
+          if (ix->d_rowend[s]) hipFree(ix->d_rowend[s]);
+          ix->d_rowend[s] = nullptr;
+        }
+        if (getenv("SIGAX_VERBOSE")) fprintf(stderr, "[sigax] row-end tables not built (%s): the extractor walks\n", hipGetErrorString(e));
+      } else {
+        for (int s = 0; s < 2; ++s) {
+          ix->st[s].rowend = (const u64*)ix->d_rowend[s];
+          ix->device_bytes += n_symbols * 8;
+        }
+      }
+    }
+  }
   if (sai && rsai) {
     const uint32_t* ss[2] = {sai, rsai};
     for (int s = 0; s < 2; ++s)  // k_edges indexes the read tables with these ids
@@ -468,7 +505,9 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
     if (rc == SIGAX_OK) rc = copy(&ix->d_gran2[s], src->d_gran2[s], ng2 * SIGAX_GRAN2_WORDS * 4);
     if (rc == SIGAX_OK) rc = copy(&ix->d_super2[s], src->d_super2[s], (((ng2 - 1) >> (SIGAX_SUPER_SHIFT - 6)) + 1) * 20 * 8);
     if (rc == SIGAX_OK) rc = copy((void**)&ix->d_sai[s], src->d_sai[s], src->n_sai * 4);
+    if (rc == SIGAX_OK) rc = copy(&ix->d_rowend[s], src->d_rowend[s], src->n_symbols * 8);
     ix->st[s] = src->st[s];
+    ix->st[s].rowend = (const u64*)ix->d_rowend[s];
     ix->st[s].granules = (const uint32_t*)ix->d_gran[s];
     ix->st[s].super = (const u64*)ix->d_super[s];
     ix->st[s].gran2 = (const uint32_t*)ix->d_gran2[s];
@@ -650,7 +689,7 @@ struct sigax_batch {
   uint32_t read_base, minov, flags;
   bool ran;
   // arenas
-  DevBuf arena, chain_cnt, pool, wpool, work, work64, work64b, occ_side, slow_flag, offs2, item_base, fin, fin_cnt, substring, block_offs, outb, edge_cnt,
+  DevBuf arena, chain_cnt, pool, wpool, work, work64, work64b, work64c, occ_side, slow_flag, offs2, item_base, fin, fin_cnt, substring, block_offs, outb, edge_cnt,
       edge_offs, edges, partial, dstat;
   uint32_t cap;
   uint32_t pool_cap;
@@ -660,6 +699,8 @@ struct sigax_batch {
   hipEvent_t ev[EV_COUNT];
   hipEvent_t sev[SIGAX_MAX_SUB][SV_COUNT];
   unsigned nsub;
+  u64 qhint[3];       // items per sub-batch in the three filter/extract queues in the previous run (~0: none yet)
+  bool qhint_lean_off;  // ... measured with lean_off in this state
   bool lean_off;      // see sigax_batch_finish
   unsigned lean_off_runs;
   unsigned nsub_req;  // 0 = automatic
@@ -672,7 +713,7 @@ struct sigax_batch {
 extern "C" void sigax_batch_destroy(sigax_batch* b) {
   if (!b) return;
   hipSetDevice(b->ix->device);
-  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin,
+  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->work64c, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin,
                    &b->fin_cnt, &b->substring, &b->block_offs, &b->outb, &b->edge_cnt, &b->edge_offs, &b->edges,
                    &b->partial, &b->dstat};
   for (DevBuf* d : all)
@@ -715,6 +756,8 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
   b->nsub = 1;
   b->lean_off = false;
   b->lean_off_runs = 0;
+  b->qhint[0] = b->qhint[1] = b->qhint[2] = ~0ull;
+  b->qhint_lean_off = false;
   b->nsub_req = 0;
   b->find_per_sub = 1;
   {
@@ -808,6 +851,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   if ((rc = ensure(&b->work, ((size_t)n + 1) * 4)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->work64, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->work64b, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->work64c, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
   // general filter/extract kernel (reads the fast kernel queued): persistent lanes with a private pool each
   unsigned want_grid = (unsigned)std::min<u64>(128, ((u64)n + 255) / 256);
   if (want_grid == 0) want_grid = 1;
@@ -913,7 +957,8 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     xa.n_reads = n;
     xa.cap = b->cap;
     xa.irreducible = (b->flags & SIGAX_IRREDUCIBLE) ? 1u : 0u;
-    xa.no_lean = b->lean_off ? 1u : 0u;
+    static const bool skip_strict = getenv("SIGAX_FX_SKIP_STRICT") != nullptr;  // A/B aid
+    xa.no_lean = (b->lean_off || skip_strict) ? 1u : 0u;
     xa.arena = b->arena.p;
     xa.chain_cnt = (const uint32_t*)b->chain_cnt.p;
     xa.pool = (Ent*)b->pool.p;
@@ -925,6 +970,14 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     xa.w64_counter = dstat + DS_W64_BASE + i;
     xa.work64b = (uint32_t*)b->work64b.p + 2 * (size_t)rb;
     xa.w64b_counter = dstat + DS_W64B_BASE + i;
+    xa.work64c = (uint32_t*)b->work64c.p + 2 * (size_t)rb;
+    xa.w64c_counter = dstat + DS_W64C_BASE + i;
+    xa.q_in = nullptr;
+    xa.q_in_n = nullptr;
+    xa.q_out = nullptr;
+    xa.q_out_n = nullptr;
+    xa.q_wide = nullptr;
+    xa.q_wide_n = nullptr;
     xa.read_begin = rb;
     xa.read_end = re;
     xa.item_base = (u64*)b->item_base.p;
@@ -940,7 +993,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
       xa.work = nullptr;
       xa.n_work = 0;
       xa.n_work_ptr = nullptr;
-      launch_filter_extract_fast(xa, ix->wide, fast_grid, std::min(fast_grid, 512u), ix->s_fx);
+      launch_filter_extract_fast(xa, ix->wide, fast_grid, std::min(fast_grid, 512u), b->qhint_lean_off == b->lean_off ? b->qhint : nullptr, ix->s_fx);
       xa.work = (const uint32_t*)b->work.p + rb;  // the general kernel redoes what the fast one queued
       xa.n_work = 0;
       xa.n_work_ptr = dstat + DS_SLOW_BASE + i;
@@ -1068,15 +1121,22 @@ extern "C" int sigax_batch_finish(sigax_batch* b, void* stream, sigax_stats* sta
     b->last.n_slow_reads = 0;
     for (int i = 0; i < SIGAX_MAX_SUB; ++i) b->last.n_slow_reads += ds[DS_SLOW_BASE + i];
     {
-      // Reads with sequencing errors make the extraction branch (every erroneous overlap becomes a group of its own that
-      // is walked to the end of its read); the lean launches hand such items on after wasted work.  If more than a
-      // quarter of the (read, side) items went on, this batch object starts its next 32 runs with the full launches,
-      // then tries the lean ones again.
+      // Reads with sequencing errors make the extraction branch; the strict lean launch hands such items on after wasted
+      // work.  If more than a tenth of the (read, side) items went on, this batch object starts its next 32 runs with the
+      // branching lean launch (9 % slower on items that do not branch, no wasted work on those that do: measured equal
+      // at 8 % handed on, 12 % ahead at 23 %, tools/ab_skip_strict.sh), then tries the strict one again.
       u64 q64 = 0;
       for (int i = 0; i < SIGAX_MAX_SUB; ++i) q64 += ds[DS_W64_BASE + i];
+      for (int k = 0; k < 3; ++k) {
+        const int base = k == 0 ? DS_W64_BASE : k == 1 ? DS_W64B_BASE : DS_W64C_BASE;
+        u64 m = 0;
+        for (int i = 0; i < SIGAX_MAX_SUB; ++i) m = std::max<u64>(m, ds[base + i]);
+        b->qhint[k] = m;
+      }
+      b->qhint_lean_off = b->lean_off;
       const u64 items = 2ull * b->n_reads;
       if (!b->lean_off) {
-        if (q64 * 4 > items) {
+        if (q64 * 10 > items) {
           b->lean_off = true;
           b->lean_off_runs = 32;
         }

@@ -28,7 +28,8 @@ enum {
   DS_SEC_FIND = DS_W64_BASE + 8,   // distinct 64-byte sectors of the rank tables the finder asked for, step by step
   DS_SEC_EXTRACT,                  // ... filter/extract, round by round
   DS_PROF_BASE = 32,               // 32 diagnostic counters (builds with -DSIGAX_FX_PROFILE only)
-  DS_W64B_BASE = 64,               // [DS_W64B_BASE + i]: items the lean 64-lane launch of sub-batch i queued for the full one
+  DS_W64B_BASE = 64,               // [DS_W64B_BASE + i], [DS_W64C_BASE + i]: items in the second and third queue between
+  DS_W64C_BASE = 72,               // sub-batch i's filter/extract launches
   DS_COUNT = 80
 };
 #define SIGAX_MAX_SUB 8
@@ -67,10 +68,22 @@ struct FxArgs {
   Ent* wpool;         // fast kernel: [waves][fast_pool_entries_per_wave()]
   uint32_t* work_out; // fast kernel: reads queued for the general kernel, counted in *slow_counter
   unsigned long long* slow_counter;
-  uint32_t* work64;   // 32-lane launch: (read, side) items queued for the 64-lane launch, counted in *w64_counter
+  // fast kernels: three queues of (read, side) items between the launches of launch_filter_extract_fast, each counted
+  // in its *counter; the first launch's count also tells the caller how many items needed more than the strict lean form
+  uint32_t* work64;
   unsigned long long* w64_counter;
-  uint32_t* work64b;  // lean 64-lane launch: items queued for the full 64-lane launch, counted in *w64b_counter
+  uint32_t* work64b;
   unsigned long long* w64b_counter;
+  uint32_t* work64c;
+  unsigned long long* w64c_counter;
+  // set per launch by launch_filter_extract_fast: input queue (NULL: the sub-batch's read range) and output queue (NULL:
+  // the last launch, which queues reads for the general kernel)
+  const uint32_t* q_in;
+  const unsigned long long* q_in_n;
+  uint32_t* q_out;
+  unsigned long long* q_out_n;
+  uint32_t* q_wide;  // optional: items with more blocks than the launch's lane group has lanes skip the next launch
+  unsigned long long* q_wide_n;
   uint32_t read_begin, read_end;  // fast kernel: this launch's sub-batch
   sigax_block* fin;   // unordered final blocks, allocated in per-wave / per-lane chunks
   unsigned long long* item_base;  // [n_reads][2]: where a (read, side) item's blocks start in `fin`
@@ -131,7 +144,8 @@ void launch_kmer_count(const FmStrand& s, bool wide, const unsigned char* kmers,
 void launch_find(const FindArgs& a, bool wide, hipStream_t st);
 unsigned long long find_stage_capacity();  // bytes of reads a finder workgroup can stage in LDS
 void launch_filter_extract(const FxArgs& a, bool wide, unsigned grid, hipStream_t st);
-void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid32, unsigned grid64, hipStream_t st);
+// qhint: items the three queues held last time (per sub-batch; ~0 = unknown), or NULL
+void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid32, unsigned grid64, const unsigned long long* qhint, hipStream_t st);
 unsigned long long fast_pool_entries_per_wave();
 void launch_scan(const uint32_t* cnt, unsigned long long n, unsigned long long* partial, unsigned long long* offs,
                  unsigned long long* total_out, hipStream_t st);
@@ -140,6 +154,8 @@ unsigned long long scan_partials_needed(unsigned long long n);
 // partial = scan_partials_needed(n/64+1) u64, total = 1 u64 of scratch.
 void launch_build2(const FmStrand& s, bool wide, uint32_t* gran2, unsigned long long* super2, uint32_t* cnt, unsigned long long* offs, unsigned long long* partial,
                    unsigned long long* total, hipStream_t st);
+// Row-end table of one strand (fm_layout.h): out = n u64, zeroed by the caller
+void launch_rowend_build(const FmStrand& s, bool wide, unsigned long long n_strings, unsigned long long* out, hipStream_t st);
 void launch_order_scatter(const OrderArgs& a, hipStream_t st);
 unsigned long long fast_fin_chunk();
 unsigned long long cand_bytes(bool wide);

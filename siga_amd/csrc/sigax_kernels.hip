@@ -349,6 +349,43 @@ __global__ __launch_bounds__(256) void k_kmer_count(FmStrand s, const unsigned c
 }
 
 // -------------------------------------------------------------------------------------------------------
+// k_rowend_build: the row-end table of fm_layout.h.  One lane per symbol of rank 0 in the text (a read's terminator, or a
+// non-ACGT base, which the index stores as rank 0 too: alphabet.h:19-39): from the row of the suffix that starts there (rows
+// 0 .. C['A']-1) walk backwards (LF) to the row whose BWT symbol has rank 0, once to learn the distance and Occ('$') there,
+// once more to write (steps still to go, that Occ) at every row passed.  Every row lies on exactly one such walk.
+// -------------------------------------------------------------------------------------------------------
+template <bool WIDE>
+__device__ __forceinline__ u32 lf_row(const FmRef& f, const u64* C, u64 p, u64* next) {
+  const u32 c = fm_char(f, p);
+  const Cnt4 k = fm_rank<WIDE>(f, p);
+  if (c == 0) *next = p - (k.a + k.c + k.g + k.t);  // Occ('$', p - 1)
+  else *next = C[c] + (c == 1 ? k.a : c == 2 ? k.c : c == 3 ? k.g : k.t);
+  return c;
+}
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_rowend_build(FmStrand s, u64 n_strings, u64* out) {
+  const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_strings) return;
+  const FmRef f = fm_ref(s, 0);
+  const u64 C[5] = {s.C[0], s.C[1], s.C[2], s.C[3], s.C[4]};
+  u64 p = j, len = 0, ld = 0;
+  for (;;) {
+    u64 q;
+    if (lf_row<WIDE>(f, C, p, &q) == 0) { ld = q; break; }
+    p = q;
+    if (++len >= s.n) return;  // not a BWT of '$'-terminated reads: leave the rows unwritten (zero: "ends here" is never used then)
+  }
+  p = j;
+  for (u64 t = len;; --t) {
+    out[p] = (t << 32) | (ld & 0xFFFFFFFFull);
+    if (t == 0) break;
+    u64 q;
+    lf_row<WIDE>(f, C, p, &q);
+    p = q;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
 // k_find: one lane per (read, orientation) chain; the four waves of a workgroup are the four chains of 64 reads.  Per step: two rank granules on the chain's primary index
 // (positions lower-1 and upper of IntervalPair::updateL, src/overlap_builder.cpp:95-122); the '$' probe of
 // src/overlap_builder.cpp:861-871 reuses them.  Blocks go to the chain's slots of the candidate arena in
@@ -937,6 +974,7 @@ __global__ __launch_bounds__(256) void k_find_w(FindArgs A) {
 // -------------------------------------------------------------------------------------------------------
 // k_filter_extract (general form): one lane per read, literal list emulation in a per-lane pool.
 // -------------------------------------------------------------------------------------------------------
+#define FX_COUNTDOWN 0x80000000u  // E::len / group count of a lone single-row block that waits for the end of its read (GFx::round)
 struct Ent {  // a block whose capped pair may have been rewritten; raw/length/af live in the candidate arena
   u64 c0lo, c0hi, c1lo, c1hi;
   u32 src, len;
@@ -1212,7 +1250,22 @@ struct Fx {
       while (p != ng) {
         u32 off = D[p].x, cnt = D[p].y;
         bool eraseGroup = true;
-        if (cnt > 0) {
+        if (cnt & FX_COUNTDOWN) {
+          // a group of one single-row block waiting for the end of its read (GFx::round has the argument): c1lo = the
+          // final row, c1hi = rounds still to go
+          Ent& g = pool[off];
+          if (g.c1hi == 0 || ng == 1 || (ng == 2 && p == 0 && ni == 0)) {
+            nocc += 2 * (g.c1hi + 1);
+            Ent br = g;
+            br.c0hi = br.c0lo;
+            br.c1hi = br.c1lo;
+            emit(br);
+          } else {
+            g.c1hi -= 1;
+            nocc += 2;
+            eraseGroup = false;
+          }
+        } else if (cnt > 0) {
           u64 exts[5] = {0, 0, 0, 0, 0};
           u32 topLen = pool[off].len;
           u32 ntop = 0;
@@ -1250,6 +1303,15 @@ struct Fx {
                   if (!need(top + cnt) || ni >= GMAX) { overflow = true; return true; }
                   for (u32 j = 0; j < cnt; ++j) pool[top + j] = pool[off + j];
                   u32 c2 = updateR_list(top, cnt, (u32)k);
+                  if (c2 == 1 && pool[top].c1lo == pool[top].c1hi) {
+                    const u64* re = (pool[top].src / A.cap) < 2 ? A.rev.rowend : A.fwd.rowend;  // ext_index()
+                    if (re != nullptr) {
+                      const u64 v = re[pool[top].c1lo];
+                      pool[top].c1lo = v & 0xFFFFFFFFull;
+                      pool[top].c1hi = v >> 32;
+                      c2 |= FX_COUNTDOWN;
+                    }
+                  }
                   I[ni++] = make_uint2(top, c2);
                   top += cnt;
                 }
@@ -1477,11 +1539,16 @@ __device__ __forceinline__ void fm_rank5p(const FmRef& s, typename PosOf<WIDE>::
 // single-group rounds served by the two-step line are compiled in; an item that needs anything else (a branch, a range
 // across lines, the exhaustive output order) is queued for the 64-lane launch, which has everything.  Without the rarely
 // taken code the kernel needs no scratch (124 VGPRs, was 128 + 17 spilled) and runs 1.2-1.4x faster.
-// LEANP = 2: the same for indexes without two-step tables (64-bit positions): only the one-granule rounds.
+// LEANP = 2: the same for indexes without two-step tables: only the one-granule rounds.
+// LEANP = 3 / 4: LEANP 1 / 2 plus branches of single-row blocks (branch_inreg) and the group ring of extract(): what reads
+// with substitutions need.  The strict forms run first because the extra state costs them 17 VGPRs (89 -> 106) and, beside
+// the finder, 9 % of the error-free step; they hand a branching item to the next launch, which has these forms.
 template <bool WIDE, int W, int LEANP = 0>
 struct GFx {
   typedef typename PosOf<WIDE>::type P;
   static constexpr bool LEAN = LEANP != 0;
+  static constexpr bool BR = LEANP == 0 || LEANP >= 3;  // follows in-register branches
+  static constexpr bool TWO_ONLY = LEANP == 1 || LEANP == 3, ONE_ONLY = LEANP == 2 || LEANP == 4;
   struct E {  // a block's capped pair in registers
     P c0lo, c0hi, c1lo, c1hi;
     u32 src;  // bits 30-31: which find produced it (0..3); bits 0-29: slot in the read's candidate region
@@ -1582,11 +1649,51 @@ struct GFx {
   u64 gAlive;
   u32 gD, gI;
   bool inreg;     // this item's groups are disjoint lane sets: no pool traffic
+  bool toowide;   // body() gave up because the item has more blocks than the group has lanes
 #ifdef SIGAX_FX_PROFILE
   u32 dbg_round;
 #endif
 
   enum { RD_ENDED = 0, RD_UPDATED, RD_BRANCHED, RD_BAIL, RD_XERROR };
+
+  __device__ void to_countdown(E& e) const {
+    const u64* re = find_of(e.src) < 2 ? A.rev.rowend : A.fwd.rowend;
+    if (re != nullptr) {
+      const u64 v = re[(u64)e.c1lo];
+      e.c1lo = (P)(v & 0xFFFFFFFFull);
+      e.c1hi = (P)(v >> 32);
+      e.len |= FX_COUNTDOWN;
+    }
+  }
+
+  // A branch of a group of single-row blocks (inreg): every block follows the one symbol at its row, so the branch
+  // partitions the lanes by that symbol (complemented for QUERYCOMP blocks, :181-187) and each lane's update is the
+  // single-symbol one with ITS symbol -- `v` = C[c] + Occ(c, row), computed by the caller from the line it already holds.
+  // Groups go to the incomings in rank order A, C, G, T (:781-787).  Not for '$' below the top level (the caller checks).
+  __device__ int branch_inreg(E& e, u64 alive, bool mine, u32 cq, P v) {
+    const u32 NSLOT = W == 64 ? FX_NSLOT : 32 < FX_NSLOT ? 32 : FX_NSLOT;
+    const u64 m1 = gballot(mine && cq == 1u), m2 = gballot(mine && cq == 2u), m3 = gballot(mine && cq == 3u), m4 = gballot(mine && cq == 4u);
+    const u32 nb = (m1 != 0) + (m2 != 0) + (m3 != 0) + (m4 != 0);
+    if (nslot + nb > NSLOT || ni + nb > NSLOT) return RD_BAIL;
+    nocc += 2u * pop(alive);
+    if (mine) {
+      e.c1lo = v;
+      e.c1hi = v;
+    }
+    bool lonely = false;
+#pragma unroll
+    for (u32 sy = 1; sy <= 4; ++sy) {
+      const u64 m = sy == 1 ? m1 : sy == 2 ? m2 : sy == 3 ? m3 : m4;
+      if (!m) continue;
+      const u32 ns = nslot++;
+      if (gl == ns) gAlive = m;
+      if (gl == ni) gI = ns;
+      ++ni;
+      if (mine && cq == sy && (m & (m - 1ull)) == 0) lonely = true;
+    }
+    if (lonely) to_countdown(e);
+    return RD_BRANCHED;
+  }
 
   // One extension round of one group (the body of the loop at :728-802).  `alive` = the group's blocks, in lane order.
   // RD_UPDATED: the blocks were right-extended in place, *newAlive = those still valid.  RD_ENDED / RD_BRANCHED: the
@@ -1645,6 +1752,7 @@ struct GFx {
       return RD_UPDATED;
     }
     const E e0 = e;
+    bool lonely = false;
     for (u32 c = 0; c < 5; ++c) {
       u64 ak = c == 0 ? any0 : c == 1 ? any1 : c == 2 ? any2 : c == 3 ? any3 : any4;
       if (!ak) continue;
@@ -1661,10 +1769,15 @@ struct GFx {
         else pool_put(wpool + ns * 64 + lane, br);
       }
       u64 m = gballot(ok);
+      if (ok && (m & (m - 1ull)) == 0) lonely = true;
       if (gl == ns) gAlive = m;
       if (gl == ni) gI = ns;
       ++ni;
     }
+    // A group of ONE single-row block (the usual branch: an overlapping read with a substitution right of the overlap) has
+    // nothing left to decide: it follows its read to the end and is emitted there.  The row-end table says after how many
+    // rounds and with which final range; from here on the group is a countdown (extract()), not a walk of ~100 lookups.
+    if (inreg && lonely) to_countdown(e);
     return RD_BRANCHED;
   }
 
@@ -1685,7 +1798,7 @@ struct GFx {
     // blocks and neither of them '$': both rounds are then "usual" rounds (no top-level end, no branch), capped[0] and
     // the range size do not move, and capped[1].lower = C[e] + Occ(e, C[c]) + R2(e, c, lower).  If only the first
     // symbol is common, ONE round from the same line.  Anything else goes on to the one-step forms below.
-    if (LEANP != 2 && t2 != nullptr) {
+    if (!ONE_ONLY && t2 != nullptr) {
       const P q0 = (P)p0, q1 = (P)p1;
       const bool in2 = mine && q1 > q0 && ((q1 - 1u) >> 6) == (q0 >> 6) && p1 <= ix.n;
       if (gballot(mine && !in2) != 0) FXP(9);  // a range crosses a 64-row line: no two-step lookup
@@ -1801,9 +1914,18 @@ struct GFx {
           if (two) FXP(10);
           return RD_UPDATED;
         }
+        if (BR && inreg && gballot(mine && (diff1 || c == 0u)) == 0) {
+          P v = 0;
+          if (mine) {
+            v = (P)tb.C[ix.which][c] + (P)(gq[c - 1u] + __popc(~d10 & bl0) + __popc(~d11 & bl1));
+            if (WIDE) v += (P)sq[c - 1u];
+          }
+          FXP(5);
+          return branch_inreg(e, alive, mine, cq, v);
+        }
       }
     }
-    if (LEANP == 1) return RD_BAIL;  // not servable from one two-step line
+    if (TWO_ONLY) return RD_BAIL;  // not servable from one two-step line
     const u64 g0 = p0 >> 7;
     const bool inside = mine && p1 > p0 && ((p1 - 1) >> 7) == g0 && p1 <= ix.n;
     if (gballot(mine && !inside)) {
@@ -1858,6 +1980,17 @@ struct GFx {
         *newAlive = alive;
         FXP(2);
         return RD_UPDATED;
+      }
+      if (BR && inreg && gballot(mine && (diff != 0 || c == 0u)) == 0) {
+        P v = 0;
+        if (mine) {
+          const bool hb0 = ((c - 1u) & 1u) != 0, hb1 = ((c - 1u) & 2u) != 0;
+          const u32 hdr = hb1 ? (hb0 ? k[3].x : k[2].x) : (hb0 ? k[1].x : k[0].x);
+          v = (P)tb.C[ix.which][c] + (P)(hdr + cntb);
+          if (WIDE) v += (P)ix.super[(p0 >> SIGAX_SUPER_SHIFT) * 4 + (c - 1u)];
+        }
+        FXP(5);
+        return branch_inreg(e, alive, mine, cq, v);
       }
     }
     u32 lom[4], pa = 0, pc = 0, pg = 0, pt = 0, pd = 0;
@@ -1981,7 +2114,7 @@ struct GFx {
       }
     }
     if (ni == 0) return true;
-    if (LEAN) return false;
+    if (!BR || (LEAN && !inreg)) return false;
     // Phase 2: the group branched.  General form: groups in a list, walked as the reference's loop walks it.
     u32 cur = 0xFFFFFFFFu, ng = 0;
     for (u32 i = 0; i < ni; ++i) {
@@ -2005,9 +2138,35 @@ struct GFx {
           cur = slot;
         }
         bool eraseGroup = true;
-        if (alive) {
+        const u32 owner = alive ? ffs0(alive) : 0u;
+        // The loop steps two places on the ring [g0 .. g(ng-1), end] (the body's ++i and the header's): with one group,
+        // or at the head of two, the group at hand is visited again and again, and nothing else, until it is erased -- a
+        // pass that visits g0 of two ends right after it, and with no incomings to splice the next one starts there again.  Such a group may take two rounds
+        // at once, and a countdown group is emitted without counting down.
+        const bool alone = ng == 1 || (ng == 2 && p == 0 && ni == 0);
+        if (alive && inreg && (gshfl(e.len, owner) & FX_COUNTDOWN)) {
+          // a countdown group (round()): t more rounds of one lookup pair each, then the round that finds '$'.  Alone in
+          // the ring it runs to its end before anything else happens (the pass does not end while a group stays), so it
+          // is emitted at once.
+          const u32 t = gshfl((u32)e.c1hi, owner);
+          if (t == 0 || alone) {
+            nocc += 2u * (t + 1u);
+            if (nout + 1 > (W == 64 ? FX_OUTCAP : FX_OUTCAP / 2)) return false;
+            if (gl == owner) {
+              E br = e;
+              br.c0hi = br.c0lo;  // updateR('$') of a single row: one '$' row, capped[0] stays
+              br.c1hi = br.c1lo;
+              out_put(nout, br);
+            }
+            nout += 1;
+          } else {
+            if (gl == owner) e.c1hi -= 1;
+            nocc += 2u;
+            eraseGroup = false;
+          }
+        } else if (alive) {
           u64 na = 0;
-          int st = round_fast(e, alive, &na, ng == 1);  // a lone group may take two rounds at once, as in phase 1
+          int st = round_fast(e, alive, &na, alone);  // two rounds at once, as in phase 1
           if (st == RD_BAIL) return false;
           if (st == RD_XERROR) return true;
           if (st == RD_UPDATED) {
@@ -2042,6 +2201,7 @@ struct GFx {
     nout = 0;
     nocc = 0;
     xerror = false;
+    toowide = false;
     slots = reinterpret_cast<const Cand<WIDE>*>(A.arena) + (u64)r * 4 * A.cap;
     const u32 L = (u32)(A.offs[r + 1] - A.offs[r]);
     u32 cc[4];
@@ -2068,6 +2228,7 @@ struct GFx {
     const u32 nX = nA + c0 + c1, nY = nB + c2 + c3, T = nX + nY;
     if (T > (u32)W) {
       if (W == 64 && big != nullptr && T <= FX_BIGCAP && A.irreducible) return body_big(L, chA, chB, nA, nB, c0, c2, nX, T);
+      toowide = true;
       return false;
     }
     if (T == 0) return true;
@@ -2393,8 +2554,8 @@ struct GFx {
 };
 
 // W == 32: two (read, side) items per wave, one per half; items that do not fit (more than 32 blocks, branching beyond
-// the half's slots, output beyond its share) are queued for the W == 64 launch, which in turn queues what it cannot
-// finish for the general kernel.
+// the half's slots, output beyond its share) are queued for the next launch (launch_filter_extract_fast), the last of
+// which queues what it cannot finish for the general kernel.
 #ifndef SIGAX_FX_LEAN_WAVES
 #define SIGAX_FX_LEAN_WAVES 4  // register budget of the lean launch as waves per SIMD (4: up to 128, it takes 89; 6: 80 with 6 spilled)
 #endif
@@ -2420,36 +2581,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? (LEA
     fx.big = &bigsh[wid];
   }
   u64 nocc_total = 0, nerr = 0, nsub = 0;
-  if (W == 32) {
-    const u64 first = 2ull * A.read_begin, last = 2ull * A.read_end;
+  // Items come from this sub-batch's read range (the first launch) or from the queue the launch before filled; what a
+  // launch cannot finish goes to a later one's queue -- items with more blocks than the group has lanes to q_wide, the
+  // rest to q_out -- and from the last launch to the general kernel (by read).  Queue entries are collected per wave in
+  // LDS and appended 30 or more at a time: one atomic on the queue's counter per item serialises at ~6 ns each.
+  // The strict lean launch is always the first one (range input) and appends with one atomic per item: its register
+  // budget is what the error-free step time hangs on (89 VGPRs; 99 and scratch with the batching below: 9 % on the step),
+  // and its atomics hide behind its other work.
+  constexpr bool STRICT = LEAN == 1 || LEAN == 2;
+  const u64 first = 2ull * A.read_begin;
+  if constexpr (STRICT) {
+    const u64 last = 2ull * A.read_end;
     for (u64 w0 = first + wave * 2; w0 < last; w0 += nwaves * 2) {
       const u64 item = w0 + (lane >> 5);
       const bool has = item < last;
-      bool done = fx.run(has, (u32)(item >> 1), (u32)(item & 1));
+      const bool done = fx.run(has, (u32)(item >> 1), (u32)(item & 1));
       if (has && !done && fx.gl == 0) {
         A.fin_cnt[item] = 0;
         A.occ_side[item] = 0;
-        A.work64[atomicAdd(A.w64_counter, 1ull)] = (u32)item;
+        if (fx.toowide) A.q_wide[atomicAdd(A.q_wide_n, 1ull)] = (u32)item;
+        else A.q_out[atomicAdd(A.q_out_n, 1ull)] = (u32)item;
       }
       fx.account(has, done, item, nocc_total, nerr, nsub);
     }
   } else {
-    // the lean 64-lane launch takes what the 32-lane one queued and queues what it cannot finish for the full one,
-    // which queues reads for the general kernel
-    const u64 n = LEAN ? *A.w64_counter : *A.w64b_counter;
-    const u32* in = LEAN ? A.work64 : A.work64b;
-    for (u64 i = wave; i < n; i += nwaves) {
-      const u64 item = in[i];
-      bool done = fx.run(true, (u32)(item >> 1), (u32)(item & 1));
-      if (!done && lane == 0) {
-        const u32 r = (u32)(item >> 1);
+    const u32* qin = A.q_in;
+    const u64 nitems = qin ? *A.q_in_n : 2ull * A.read_end - first;
+    const u64 per = W == 32 ? 2u : 1u;
+    __shared__ u32 qbuf[4][2][32];  // items a wave hands on, waiting to be appended to the later launches' queues
+    u32 qn[2] = {0, 0};
+    auto flush = [&](int which) {
+      const u32 n = qn[which];
+      if (n == 0) return;
+      u64 b = 0;
+      if (lane == 0) b = atomicAdd(which ? A.q_wide_n : A.q_out_n, (u64)n);
+      b = readlane64(b, 0);
+      if (lane < n) (which ? A.q_wide : A.q_out)[b + lane] = qbuf[wid][which][lane];
+      wave_lds_sync();
+      qn[which] = 0;
+    };
+    auto push = [&](int which, bool p, u32 it) {
+      const u64 m = __ballot(p);
+      if (!m) return;
+      if (p) qbuf[wid][which][qn[which] + (u32)__popcll(m & ((1ull << lane) - 1ull))] = it;
+      wave_lds_sync();
+      qn[which] += (u32)__popcll(m);
+      if (qn[which] >= 30u) flush(which);
+    };
+    for (u64 i0 = wave * per; i0 < nitems; i0 += nwaves * per) {
+      const u64 idx = i0 + (W == 32 ? (lane >> 5) : 0u);
+      const bool has = idx < nitems;
+      const u64 item = !has ? 0ull : (qin ? (u64)qin[idx] : first + idx);
+      const bool done = fx.run(has, (u32)(item >> 1), (u32)(item & 1));
+      const bool bail = has && !done && fx.gl == 0;
+      if (bail) {
         A.fin_cnt[item] = 0;
         A.occ_side[item] = 0;
-        if (LEAN) A.work64b[atomicAdd(A.w64b_counter, 1ull)] = (u32)item;
-        else if (atomicExch(&A.slow_flag[r], 1u) == 0u) A.work_out[atomicAdd(A.slow_counter, 1ull)] = r;
       }
-      fx.account(true, done, item, nocc_total, nerr, nsub);
+      const bool wide_q = A.q_wide != nullptr && fx.toowide;
+      if (A.q_wide != nullptr) push(1, bail && wide_q, (u32)item);
+      if (A.q_out != nullptr) push(0, bail && !wide_q, (u32)item);
+      else if (bail && !wide_q) {
+        const u32 r = (u32)(item >> 1);
+        if (atomicExch(&A.slow_flag[r], 1u) == 0u) A.work_out[atomicAdd(A.slow_counter, 1ull)] = r;
+      }
+      fx.account(has, done, item, nocc_total, nerr, nsub);
     }
+    flush(0);
+    flush(1);
   }
   nocc_total = wave_sum(nocc_total); nerr = wave_sum(nerr); nsub = wave_sum(nsub);
   wave_lds_sync();
@@ -2853,41 +3052,59 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
   else hipLaunchKernelGGL(k_find_n, dim3(g), dim3(bs), lds, st, b);
 }
 
-void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid32, unsigned grid64, hipStream_t st) {
-  if (a.read_end <= a.read_begin) return;
+template <bool WIDE>
+static void launch_fx_stages(const FxArgs& a, unsigned grid32, unsigned grid64, const u64* qhint, hipStream_t st) {
   static const bool no_lean = getenv("SIGAX_FX_NO_LEAN") != nullptr;  // A/B aid
-  const bool lean = a.irreducible && !no_lean && !a.no_lean;
+  const bool lean = a.irreducible && !no_lean;
   const bool have2 = a.fwd.gran2 && a.rev.gran2;
-  // 32-lane launch -> lean 64-lane launch -> full 64-lane launch (-> general kernel, launched by the caller).  Without
-  // the lean stage the full launch reads the 32-lane launch's queue directly.
-  FxArgs full = a;
+  // Irreducible mode, a chain of launches, each taking what the one before could not finish:
+  //   strict lean 32 lanes (single-group rounds only; skipped when a.no_lean says most items branch)
+  //   -> branching lean 32 lanes -> branching lean 64 lanes (items of 33..64 blocks) -> full 64 lanes (everything else the
+  //   lane-group form can do, items of up to 256 blocks) -> general kernel (launched by the caller).
+  // Exhaustive mode: full 32 lanes -> full 64 lanes.
+  u32* q[3] = {a.work64, a.work64b, a.work64c};
+  u64* qn[3] = {a.w64_counter, a.w64b_counter, a.w64c_counter};
+  // stage(kernel, grid, in, out, wide): queue indices, -1 = the read range as input / the general kernel as output /
+  // no separate queue for items wider than the lane group
+  auto stage = [&](auto kernel, unsigned grid, int in, int out, int widei) {
+    FxArgs x = a;
+    if (in >= 0 && qhint && qhint[in] != ~0ull) {
+      // a queue that held few items in this batch object's previous run gets a small grid (any grid is correct: the
+      // waves loop over the queue; an empty 768-workgroup launch costs ~25 us beside the finder)
+      const u64 per_wg = grid == grid32 ? 8 : 4;
+      const u64 want = (qhint[in] + qhint[in] / 2 + per_wg - 1) / per_wg + 4;
+      if (want < grid) grid = (unsigned)want;
+    }
+    x.q_in = in < 0 ? nullptr : q[in];
+    x.q_in_n = in < 0 ? nullptr : qn[in];
+    x.q_out = out < 0 ? nullptr : q[out];
+    x.q_out_n = out < 0 ? nullptr : qn[out];
+    x.q_wide = widei < 0 ? nullptr : q[widei];
+    x.q_wide_n = widei < 0 ? nullptr : qn[widei];
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, st, x);
+  };
   if (!lean) {
-    full.work64b = a.work64;
-    full.w64b_counter = a.w64_counter;
+    stage(k_filter_extract_fast<WIDE, 32, 0>, grid32, -1, 2, -1);
+    stage(k_filter_extract_fast<WIDE, 64, 0>, grid64, 2, -1, -1);
+    return;
   }
-  if (wide) {
-    if (lean && have2) {
-      hipLaunchKernelGGL((k_filter_extract_fast<true, 32, 1>), dim3(grid32), dim3(256), 0, st, a);
-      hipLaunchKernelGGL((k_filter_extract_fast<true, 64, 1>), dim3(grid64), dim3(256), 0, st, a);
-    } else if (lean) {
-      hipLaunchKernelGGL((k_filter_extract_fast<true, 32, 2>), dim3(grid32), dim3(256), 0, st, a);
-      hipLaunchKernelGGL((k_filter_extract_fast<true, 64, 2>), dim3(grid64), dim3(256), 0, st, a);
-    } else {
-      hipLaunchKernelGGL((k_filter_extract_fast<true, 32>), dim3(grid32), dim3(256), 0, st, a);
-    }
-    hipLaunchKernelGGL((k_filter_extract_fast<true, 64>), dim3(grid64), dim3(256), 0, st, full);
+  // queue 0: items for the branching 32-lane launch; queue 1: for the branching 64-lane launch; queue 2: for the full one
+  if (have2) {
+    if (!a.no_lean) stage(k_filter_extract_fast<WIDE, 32, 1>, grid32, -1, 0, 1);
+    stage(k_filter_extract_fast<WIDE, 32, 3>, grid32, a.no_lean ? -1 : 0, 1, -1);
+    stage(k_filter_extract_fast<WIDE, 64, 3>, grid64, 1, 2, -1);
   } else {
-    if (lean && have2) {
-      hipLaunchKernelGGL((k_filter_extract_fast<false, 32, 1>), dim3(grid32), dim3(256), 0, st, a);
-      hipLaunchKernelGGL((k_filter_extract_fast<false, 64, 1>), dim3(grid64), dim3(256), 0, st, a);
-    } else if (lean) {
-      hipLaunchKernelGGL((k_filter_extract_fast<false, 32, 2>), dim3(grid32), dim3(256), 0, st, a);
-      hipLaunchKernelGGL((k_filter_extract_fast<false, 64, 2>), dim3(grid64), dim3(256), 0, st, a);
-    } else {
-      hipLaunchKernelGGL((k_filter_extract_fast<false, 32>), dim3(grid32), dim3(256), 0, st, a);
-    }
-    hipLaunchKernelGGL((k_filter_extract_fast<false, 64>), dim3(grid64), dim3(256), 0, st, full);
+    if (!a.no_lean) stage(k_filter_extract_fast<WIDE, 32, 2>, grid32, -1, 0, 1);
+    stage(k_filter_extract_fast<WIDE, 32, 4>, grid32, a.no_lean ? -1 : 0, 1, -1);
+    stage(k_filter_extract_fast<WIDE, 64, 4>, grid64, 1, 2, -1);
   }
+  stage(k_filter_extract_fast<WIDE, 64, 0>, grid64, 2, -1, -1);
+}
+
+void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid32, unsigned grid64, const u64* qhint, hipStream_t st) {
+  if (a.read_end <= a.read_begin) return;
+  if (wide) launch_fx_stages<true>(a, grid32, grid64, qhint, st);
+  else launch_fx_stages<false>(a, grid32, grid64, qhint, st);
 }
 
 unsigned long long fast_pool_entries_per_wave() { return FX_WPOOL; }
@@ -2917,6 +3134,12 @@ void launch_build2(const FmStrand& s, bool wide, u32* gran2, u64* super2, u32* c
     launch_scan(cnt + (u64)col * ng2, ng2, partial, offs, total, st);
     hipLaunchKernelGGL(k_build2_b, dim3(nblk(ng2, 256)), dim3(256), 0, st, (const u64*)offs, gran2, col, ng2, wide ? super2 : (u64*)nullptr);
   }
+}
+
+void launch_rowend_build(const FmStrand& s, bool wide, u64 n_strings, u64* out, hipStream_t st) {  // n_strings: rows of rank-0 suffixes
+  if (n_strings == 0) return;
+  if (wide) hipLaunchKernelGGL(k_rowend_build<true>, dim3(nblk(n_strings, 256)), dim3(256), 0, st, s, n_strings, out);
+  else hipLaunchKernelGGL(k_rowend_build<false>, dim3(nblk(n_strings, 256)), dim3(256), 0, st, s, n_strings, out);
 }
 
 u64 scan_partials_needed(u64 n) { return (n + 1 + SCAN_ITEMS - 1) / SCAN_ITEMS + 1; }

@@ -12,9 +12,13 @@ from tests.fixtures import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run_parity(env_extra, select):
+def _run_parity(env_extra, select, seeds=None):
     env = dict(os.environ, **env_extra)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-k", select],
+    if seeds:  # cases of the randomised suite by seed
+        what = [os.path.join(ROOT, "tests", "test_gpu_random.py") + "::test_random_case_bit_exact[%d]" % k for k in seeds]
+    else:
+        what = [os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k", select]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q"] + what,
                        cwd=ROOT, env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     return r.stdout
@@ -55,3 +59,11 @@ def test_cooperative_finder_bit_exact():
     """k_find_c2 (two-step lines fetched eight lanes per line through LDS; what indexes of 2^30 symbols and more run) forced
     on the small fixtures: same bytes as the oracle, ragged reads, non-ACGT bases, duplicates and deep coverage included."""
     _run_parity({"SIGAX_FIND_COOP": "1"}, "hits_and_asqg or non_acgt or duplicate or in_flight or deep or mid")
+
+
+def test_branch_walks_without_the_row_end_table():
+    """The row-end table (fm_layout.h) turns a lone single-row group's walk to the end of its read into a countdown; with
+    SIGAX_ROWEND=0 the extractor walks as the reference does.  Both forms give the oracle's bytes on read sets with
+    substitutions (the default form runs in test_gpu_random.py), 32- and 64-bit positions."""
+    _run_parity({"SIGAX_ROWEND": "0"}, None, seeds=(1, 2, 5, 8, 13))
+    _run_parity({"SIGAX_FORCE_WIDE": "1"}, None, seeds=(2, 3, 8, 21))

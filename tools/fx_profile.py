@@ -10,10 +10,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from siga_amd import _lib, host  # noqa: E402
 from siga_amd.overlap import FMIndexPair  # noqa: E402
-from tests.golden.make_reads import fast_reads, rank_of_r_names  # noqa: E402
+from tests.golden.make_reads import fast_reads, rank_of_r_names, substitute  # noqa: E402
 
 N, G, L = int(os.environ.get("FXP_N", 1000000)), int(os.environ.get("FXP_G", 5000000)), int(os.environ.get("FXP_L", 150))
 reads, _ = fast_reads(G, L, N, 1)
+if float(os.environ.get("FXP_ERR", 0)) > 0:
+    reads = substitute(reads, float(os.environ["FXP_ERR"]), 101)
 d = tempfile.mkdtemp()
 prefix = os.path.join(d, "reads")
 offs = np.arange(0, (N + 1) * L, L, dtype=np.uint64)
