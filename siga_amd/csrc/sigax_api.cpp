@@ -244,6 +244,44 @@ extern "C" void sigax_index_close(sigax_index* ix) {
   delete ix;
 }
 
+// Row-end tables for the irreducible extractor (8 bytes per symbol and strand, fm_layout.h): a branch that leaves ONE
+// single-row block in a group -- what a substitution in an overlapping read does -- is resolved by one lookup instead of a
+// walk to the end of that read (~100 dependent rounds).  An accelerator like the two-step tables: skipped when memory is
+// short or SIGAX_ROWEND=0, and the extractor then walks.  Built on the index's own device (a clone builds its own: 2 n LF
+// steps on the spot beat copying 16 n bytes between GPUs).
+static void build_rowend(sigax_index* ix) {
+  const char* envr = getenv("SIGAX_ROWEND");
+  const u64 n_symbols = ix->n_symbols;
+  size_t mfree = 0, mtotal = 0;
+  (void)hipMemGetInfo(&mfree, &mtotal);
+  const u64 need = 16ull * n_symbols;
+  if ((envr && envr[0] == '0') || ix->st[0].C[1] >= 0xFFFFFFFFull || n_symbols == 0 || need >= mfree / 2) return;
+  hipError_t e = hipSuccess;
+  for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+    e = hipMalloc(&ix->d_rowend[s], n_symbols * 8);
+    if (e != hipSuccess) break;
+    e = hipMemset(ix->d_rowend[s], 0, n_symbols * 8);
+    if (e != hipSuccess) break;
+    launch_rowend_build(ix->st[s], ix->wide, ix->st[s].C[1], (u64*)ix->d_rowend[s], nullptr);
+    e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipGetLastError();
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    for (int s = 0; s < 2; ++s) {
+      if (ix->d_rowend[s]) hipFree(ix->d_rowend[s]);
+      ix->d_rowend[s] = nullptr;
+      ix->st[s].rowend = nullptr;
+    }
+    if (getenv("SIGAX_VERBOSE")) fprintf(stderr, "[sigax] row-end tables not built (%s): the extractor walks\n", hipGetErrorString(e));
+    return;
+  }
+  for (int s = 0; s < 2; ++s) {
+    ix->st[s].rowend = (const u64*)ix->d_rowend[s];
+    ix->device_bytes += n_symbols * 8;
+  }
+}
+
 extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const uint8_t* rruns, uint64_t n_rruns,
                                     uint64_t n_symbols, uint64_t n_strings, const uint32_t* sai, const uint32_t* rsai,
                                     int device, sigax_index** out) {
@@ -360,41 +398,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
       }
     }
   }
-  // Row-end tables for the irreducible extractor (8 bytes per symbol and strand): a branch that leaves ONE single-row block
-  // in a group -- what a substitution in an overlapping read does -- is resolved by one lookup instead of a walk to the end
-  // of that read (~100 dependent rounds).  An accelerator like the two-step tables: skipped when memory is short or
-  // SIGAX_ROWEND=0, and the extractor then walks.
-  {
-    const char* envr = getenv("SIGAX_ROWEND");
-    size_t mfree = 0, mtotal = 0;
-    (void)hipMemGetInfo(&mfree, &mtotal);
-    const u64 need = 16ull * n_symbols;
-    if (!(envr && envr[0] == '0') && ix->st[0].C[1] < 0xFFFFFFFFull && n_symbols > 0 && need < mfree / 2) {
-      hipError_t e = hipSuccess;
-      for (int s = 0; s < 2 && e == hipSuccess; ++s) {
-        e = hipMalloc(&ix->d_rowend[s], n_symbols * 8);
-        if (e != hipSuccess) break;
-        e = hipMemset(ix->d_rowend[s], 0, n_symbols * 8);
-        if (e != hipSuccess) break;
-        launch_rowend_build(ix->st[s], ix->wide, ix->st[s].C[1], (u64*)ix->d_rowend[s], nullptr);
-        e = hipDeviceSynchronize();
-        if (e == hipSuccess) e = hipGetLastError();
-      }
-      if (e != hipSuccess) {
-        (void)hipGetLastError();
-        for (int s = 0; s < 2; ++s) {
-          if (ix->d_rowend[s]) hipFree(ix->d_rowend[s]);
-          ix->d_rowend[s] = nullptr;
-        }
-        if (getenv("SIGAX_VERBOSE")) fprintf(stderr, "[sigax] row-end tables not built (%s): the extractor walks\n", hipGetErrorString(e));
-      } else {
-        for (int s = 0; s < 2; ++s) {
-          ix->st[s].rowend = (const u64*)ix->d_rowend[s];
-          ix->device_bytes += n_symbols * 8;
-        }
-      }
-    }
-  }
+  build_rowend(ix);
   if (sai && rsai) {
     const uint32_t* ss[2] = {sai, rsai};
     for (int s = 0; s < 2; ++s)  // k_edges indexes the read tables with these ids
@@ -505,9 +509,8 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
     if (rc == SIGAX_OK) rc = copy(&ix->d_gran2[s], src->d_gran2[s], ng2 * SIGAX_GRAN2_WORDS * 4);
     if (rc == SIGAX_OK) rc = copy(&ix->d_super2[s], src->d_super2[s], (((ng2 - 1) >> (SIGAX_SUPER_SHIFT - 6)) + 1) * 20 * 8);
     if (rc == SIGAX_OK) rc = copy((void**)&ix->d_sai[s], src->d_sai[s], src->n_sai * 4);
-    if (rc == SIGAX_OK) rc = copy(&ix->d_rowend[s], src->d_rowend[s], src->n_symbols * 8);
     ix->st[s] = src->st[s];
-    ix->st[s].rowend = (const u64*)ix->d_rowend[s];
+    ix->st[s].rowend = nullptr;
     ix->st[s].granules = (const uint32_t*)ix->d_gran[s];
     ix->st[s].super = (const u64*)ix->d_super[s];
     ix->st[s].gran2 = (const uint32_t*)ix->d_gran2[s];
@@ -519,6 +522,7 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
     sigax_index_close(ix);
     return rc;
   }
+  if (src->d_rowend[0]) build_rowend(ix);
   *out = ix;
   return SIGAX_OK;
 }
