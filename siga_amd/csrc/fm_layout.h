@@ -55,9 +55,21 @@
  * and Occ('$') at that row (low word) -- what a single-row block's right extension to the end of its read arrives at
  * (IrreducibleBlockListExtractor::extract, src/overlap_builder.cpp:747-766), without walking there. */
 
+/* Look-ahead table (same walk, optional, indexes below 2^34 symbols): one u64 per BWT row p = the next ten symbols on the
+ * backward path from p -- BWT[p], BWT[LF(p)], ... 3 bits each, lowest first, rank 0 from the read's first base on -- and, in
+ * the upper 34 bits, the row ten steps on.  A single-row block's right extension IS this path (IntervalPair::updateR with the
+ * one symbol at its row = LF), so ten extension rounds of the irreducible extractor cost one 8-byte lookup and no rank
+ * arithmetic. */
+#define SIGAX_LA_SYMS 10
+#define SIGAX_LA_ROW_SHIFT 30
+#define SIGAX_LA_SYM_MASK 0x3FFFFFFFu
+
 struct FmStrand {
   const uint32_t* granules;  /* n_granules x 16 u32 */
-  const unsigned long long* rowend;  /* [n] (t << 32 | dollar rank), or NULL */
+  const unsigned long long* rowend;  /* row p at rowend[p * re_stride]: (t << 32 | dollar rank); or NULL */
+  const unsigned long long* la;      /* look-ahead entries, interleaved with the row-end ones: row p = { la[2 p], la[2 p + 1] =
+                                        its row-end entry } (then rowend = la + 1, re_stride = 2); or NULL (re_stride = 1) */
+  unsigned int re_stride;
   const uint32_t* gran2;     /* (n / 64 + 1) x 32 u32, or NULL */
   const unsigned long long* super2;  /* [n_super][20], wide mode with two-step tables; else NULL */
   const unsigned long long* super;    /* [n_super][4] absolute A,C,G,T counts at each superblock start (wide mode) */

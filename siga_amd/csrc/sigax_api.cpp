@@ -86,6 +86,7 @@ struct sigax_index {
   void* d_gran2[2];  // two-step tables (fm_layout.h) or NULL
   void* d_super2[2]; // ... their superblock bases (64-bit positions) or NULL
   void* d_rowend[2]; // row-end tables (fm_layout.h) or NULL
+  void* d_la[2];     // look-ahead tables (fm_layout.h) or NULL
   void* d_super[2];
   uint32_t* d_sai[2];
   u64 n_sai;
@@ -232,6 +233,7 @@ extern "C" void sigax_index_close(sigax_index* ix) {
     if (ix->d_gran2[s]) hipFree(ix->d_gran2[s]);
     if (ix->d_super2[s]) hipFree(ix->d_super2[s]);
     if (ix->d_rowend[s]) hipFree(ix->d_rowend[s]);
+    if (ix->d_la[s]) hipFree(ix->d_la[s]);
     if (ix->d_super[s]) hipFree(ix->d_super[s]);
     if (ix->d_sai[s]) hipFree(ix->d_sai[s]);
   }
@@ -251,18 +253,22 @@ extern "C" void sigax_index_close(sigax_index* ix) {
 // steps on the spot beat copying 16 n bytes between GPUs).
 static void build_rowend(sigax_index* ix) {
   const char* envr = getenv("SIGAX_ROWEND");
+  const char* envl = getenv("SIGAX_LOOKAHEAD");
   const u64 n_symbols = ix->n_symbols;
   size_t mfree = 0, mtotal = 0;
   (void)hipMemGetInfo(&mfree, &mtotal);
-  const u64 need = 16ull * n_symbols;
-  if ((envr && envr[0] == '0') || ix->st[0].C[1] >= 0xFFFFFFFFull || n_symbols == 0 || need >= mfree / 2) return;
+  if ((envr && envr[0] == '0') || ix->st[0].C[1] >= 0xFFFFFFFFull || n_symbols == 0 || 16ull * n_symbols >= mfree / 2) return;
+  // the look-ahead tables (another 8 bytes per symbol and strand) when both pairs fit in 60 % of the free memory
+  const bool want_la = !(envl && envl[0] == '0') && n_symbols < (1ull << (64 - SIGAX_LA_ROW_SHIFT)) && 32ull * n_symbols < mfree / 5 * 3;
   hipError_t e = hipSuccess;
+  const u64 bytes = n_symbols * (want_la ? 16 : 8);  // with look-ahead: one interleaved table {look-ahead, row-end} per row
   for (int s = 0; s < 2 && e == hipSuccess; ++s) {
-    e = hipMalloc(&ix->d_rowend[s], n_symbols * 8);
+    void** slot = want_la ? &ix->d_la[s] : &ix->d_rowend[s];
+    e = hipMalloc(slot, bytes);
+    if (e == hipSuccess) e = hipMemset(*slot, 0, bytes);
     if (e != hipSuccess) break;
-    e = hipMemset(ix->d_rowend[s], 0, n_symbols * 8);
-    if (e != hipSuccess) break;
-    launch_rowend_build(ix->st[s], ix->wide, ix->st[s].C[1], (u64*)ix->d_rowend[s], nullptr);
+    launch_rowend_build(ix->st[s], ix->wide, ix->st[s].C[1], want_la ? (u64*)ix->d_la[s] + 1 : (u64*)ix->d_rowend[s],
+                        want_la ? (u64*)ix->d_la[s] : nullptr, nullptr);
     e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipGetLastError();
   }
@@ -270,15 +276,18 @@ static void build_rowend(sigax_index* ix) {
     (void)hipGetLastError();
     for (int s = 0; s < 2; ++s) {
       if (ix->d_rowend[s]) hipFree(ix->d_rowend[s]);
-      ix->d_rowend[s] = nullptr;
-      ix->st[s].rowend = nullptr;
+      if (ix->d_la[s]) hipFree(ix->d_la[s]);
+      ix->d_rowend[s] = ix->d_la[s] = nullptr;
+      ix->st[s].rowend = ix->st[s].la = nullptr;
     }
     if (getenv("SIGAX_VERBOSE")) fprintf(stderr, "[sigax] row-end tables not built (%s): the extractor walks\n", hipGetErrorString(e));
     return;
   }
   for (int s = 0; s < 2; ++s) {
-    ix->st[s].rowend = (const u64*)ix->d_rowend[s];
-    ix->device_bytes += n_symbols * 8;
+    ix->st[s].la = (const u64*)ix->d_la[s];
+    ix->st[s].rowend = want_la ? (const u64*)ix->d_la[s] + 1 : (const u64*)ix->d_rowend[s];
+    ix->st[s].re_stride = want_la ? 2u : 1u;
+    ix->device_bytes += bytes;
   }
 }
 
@@ -511,6 +520,8 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
     if (rc == SIGAX_OK) rc = copy((void**)&ix->d_sai[s], src->d_sai[s], src->n_sai * 4);
     ix->st[s] = src->st[s];
     ix->st[s].rowend = nullptr;
+    ix->st[s].la = nullptr;
+    ix->st[s].re_stride = 1;
     ix->st[s].granules = (const uint32_t*)ix->d_gran[s];
     ix->st[s].super = (const u64*)ix->d_super[s];
     ix->st[s].gran2 = (const uint32_t*)ix->d_gran2[s];
@@ -522,7 +533,7 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
     sigax_index_close(ix);
     return rc;
   }
-  if (src->d_rowend[0]) build_rowend(ix);
+  if (src->d_rowend[0] || src->d_la[0]) build_rowend(ix);
   *out = ix;
   return SIGAX_OK;
 }

@@ -154,8 +154,9 @@ unsigned long long scan_partials_needed(unsigned long long n);
 // partial = scan_partials_needed(n/64+1) u64, total = 1 u64 of scratch.
 void launch_build2(const FmStrand& s, bool wide, uint32_t* gran2, unsigned long long* super2, uint32_t* cnt, unsigned long long* offs, unsigned long long* partial,
                    unsigned long long* total, hipStream_t st);
-// Row-end table of one strand (fm_layout.h): out = n u64, zeroed by the caller
-void launch_rowend_build(const FmStrand& s, bool wide, unsigned long long n_strings, unsigned long long* out, hipStream_t st);
+// Row-end table of one strand (fm_layout.h): out = n u64, zeroed by the caller; la = n u64 for the look-ahead table, or NULL
+void launch_rowend_build(const FmStrand& s, bool wide, unsigned long long n_strings, unsigned long long* out, unsigned long long* la,
+                         hipStream_t st);
 void launch_order_scatter(const OrderArgs& a, hipStream_t st);
 unsigned long long fast_fin_chunk();
 unsigned long long cand_bytes(bool wide);

@@ -362,8 +362,11 @@ __device__ __forceinline__ u32 lf_row(const FmRef& f, const u64* C, u64 p, u64* 
   else *next = C[c] + (c == 1 ? k.a : c == 2 ? k.c : c == 3 ? k.g : k.t);
   return c;
 }
+// With `la` the same walk also fills the look-ahead table (fm_layout.h): a window of the last ten (row, symbol) pairs
+// slides along; when the eleventh row arrives, the oldest one's entry = its ten symbols + that eleventh row is complete.
 template <bool WIDE>
-__global__ __launch_bounds__(256) void k_rowend_build(FmStrand s, u64 n_strings, u64* out) {
+__global__ __launch_bounds__(256) void k_rowend_build(FmStrand s, u64 n_strings, u64* out, u64* la) {  // la: interleaved, see fm_layout.h
+  const u64 stride = la != nullptr ? 2u : 1u;
   const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
   if (j >= n_strings) return;
   const FmRef f = fm_ref(s, 0);
@@ -376,13 +379,28 @@ __global__ __launch_bounds__(256) void k_rowend_build(FmStrand s, u64 n_strings,
     if (++len >= s.n) return;  // not a BWT of '$'-terminated reads: leave the rows unwritten (zero: "ends here" is never used then)
   }
   p = j;
+  u64 R[SIGAX_LA_SYMS];
+  u32 w = 0, vm = 0;  // symbols of R[0..9] (3 bits each, R[0] lowest); which of R[] hold rows of this walk
+#pragma unroll
+  for (int i = 0; i < SIGAX_LA_SYMS; ++i) R[i] = 0;
+  auto insert = [&](u64 row, u32 c, bool real) {
+    if (la != nullptr && (vm & 1u)) la[2 * R[0]] = (u64)w | (row << SIGAX_LA_ROW_SHIFT);
+#pragma unroll
+    for (int i = 0; i + 1 < SIGAX_LA_SYMS; ++i) R[i] = R[i + 1];
+    R[SIGAX_LA_SYMS - 1] = row;
+    w = (w >> 3) | (c << (3 * (SIGAX_LA_SYMS - 1)));
+    vm = (vm >> 1) | (real ? (1u << (SIGAX_LA_SYMS - 1)) : 0u);
+  };
   for (u64 t = len;; --t) {
-    out[p] = (t << 32) | (ld & 0xFFFFFFFFull);
-    if (t == 0) break;
+    out[p * stride] = (t << 32) | (ld & 0xFFFFFFFFull);
     u64 q;
-    lf_row<WIDE>(f, C, p, &q);
+    const u32 c = lf_row<WIDE>(f, C, p, &q);  // rank 0 exactly when t == 0
+    insert(p, c, true);
+    if (t == 0) break;
     p = q;
   }
+  if (la != nullptr)
+    for (int i = 0; i < SIGAX_LA_SYMS; ++i) insert(0, 0, false);
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -930,6 +948,9 @@ __global__ __launch_bounds__(256) void k_find_n2(FindArgs A) {
   const bool staged = find_stage_reads(A, &rd_base);
   find2_tables_load(t2, A.fwd, A.rev);
   fm_tables_load(tb, A.fwd, A.rev);
+#ifdef SIGAX_FIND_PRIO
+  __builtin_amdgcn_s_setprio(SIGAX_FIND_PRIO);  // A/B: issue priority over the filter/extract waves on the same SIMD
+#endif
   if (staged) find_body<false, true, true>(A, tb, sg, t2, find_dyn_lds, rd_base);
   else find_body<false, false, false>(A, tb, sg, t2, find_dyn_lds, rd_base);
 }
@@ -1306,7 +1327,7 @@ struct Fx {
                   if (c2 == 1 && pool[top].c1lo == pool[top].c1hi) {
                     const u64* re = (pool[top].src / A.cap) < 2 ? A.rev.rowend : A.fwd.rowend;  // ext_index()
                     if (re != nullptr) {
-                      const u64 v = re[pool[top].c1lo];
+                      const u64 v = re[pool[top].c1lo * A.fwd.re_stride];
                       pool[top].c1lo = v & 0xFFFFFFFFull;
                       pool[top].c1hi = v >> 32;
                       c2 |= FX_COUNTDOWN;
@@ -1540,6 +1561,8 @@ __device__ __forceinline__ void fm_rank5p(const FmRef& s, typename PosOf<WIDE>::
 // across lines, the exhaustive output order) is queued for the 64-lane launch, which has everything.  Without the rarely
 // taken code the kernel needs no scratch (124 VGPRs, was 128 + 17 spilled) and runs 1.2-1.4x faster.
 // LEANP = 2: the same for indexes without two-step tables: only the one-granule rounds.
+// LEANP = 5 / 6: strict / branching, with the rounds read off the look-ahead table (fm_layout.h) instead of computed from
+// rank lines: one 8-byte lookup per block and ten rounds; items with a block of more than one row go on to the full launch.
 // LEANP = 3 / 4: LEANP 1 / 2 plus branches of single-row blocks (branch_inreg) and the group ring of extract(): what reads
 // with substitutions need.  The strict forms run first because the extra state costs them 17 VGPRs (89 -> 106) and, beside
 // the finder, 9 % of the error-free step; they hand a branching item to the next launch, which has these forms.
@@ -1547,8 +1570,9 @@ template <bool WIDE, int W, int LEANP = 0>
 struct GFx {
   typedef typename PosOf<WIDE>::type P;
   static constexpr bool LEAN = LEANP != 0;
-  static constexpr bool BR = LEANP == 0 || LEANP >= 3;  // follows in-register branches
+  static constexpr bool BR = LEANP == 0 || LEANP == 3 || LEANP == 4 || LEANP == 6;  // follows in-register branches
   static constexpr bool TWO_ONLY = LEANP == 1 || LEANP == 3, ONE_ONLY = LEANP == 2 || LEANP == 4;
+  static constexpr bool TEXT = LEANP == 5 || LEANP == 6;  // rounds from the look-ahead table only (single-row blocks)
   struct E {  // a block's capped pair in registers
     P c0lo, c0hi, c1lo, c1hi;
     u32 src;  // bits 30-31: which find produced it (0..3); bits 0-29: slot in the read's candidate region
@@ -1650,6 +1674,10 @@ struct GFx {
   u32 gD, gI;
   bool inreg;     // this item's groups are disjoint lane sets: no pool traffic
   bool toowide;   // body() gave up because the item has more blocks than the group has lanes
+  // TEXT: this lane's block on its backward path: the symbols ahead, how many of them are used up, the row ten steps on,
+  // and from the row-end table Occ('$') at the path's end and the rounds until then
+  u32 tsyms, tk, tld, ttt;
+  u64 tjump;
 #ifdef SIGAX_FX_PROFILE
   u32 dbg_round;
 #endif
@@ -1659,7 +1687,7 @@ struct GFx {
   __device__ void to_countdown(E& e) const {
     const u64* re = find_of(e.src) < 2 ? A.rev.rowend : A.fwd.rowend;
     if (re != nullptr) {
-      const u64 v = re[(u64)e.c1lo];
+      const u64 v = re[(u64)e.c1lo * A.fwd.re_stride];
       e.c1lo = (P)(v & 0xFFFFFFFFull);
       e.c1hi = (P)(v >> 32);
       e.len |= FX_COUNTDOWN;
@@ -2084,6 +2112,87 @@ struct GFx {
     return RD_UPDATED;
   }
 
+  // One extension round of a group of single-row blocks from the look-ahead table: the symbol that follows a block is the
+  // next one on its path, the update is a step along it (nothing to compute: capped[0] keeps still, capped[1] is only
+  // needed at the end, where it is the row-end table's Occ('$')).  Same cases and return codes as round_fast().
+  __device__ int round_text(E& e, u64 alive, u64* newAlive) {
+    const u32 OUTCAP = W == 64 ? FX_OUTCAP : FX_OUTCAP / 2;
+    const u32 NSLOT = W == 64 ? FX_NSLOT : 32 < FX_NSLOT ? 32 : FX_NSLOT;
+    const bool mine = (alive >> gl) & 1ull;
+    const u32 first = ffs0(alive);
+    FXP(0);
+    if (gshfl(tk, first) >= (u32)SIGAX_LA_SYMS) {  // the group has used its ten symbols (all its lanes step together)
+      if (mine) {
+        const u64* la = find_of(e.src) < 2 ? A.rev.la : A.fwd.la;
+        const u64 v = la[2 * tjump];
+        tsyms = (u32)v & SIGAX_LA_SYM_MASK;
+        tjump = v >> SIGAX_LA_ROW_SHIFT;
+        tk = 0;
+      }
+      sec_add(pop(alive));
+    }
+    const u32 c = (tsyms >> (3u * tk)) & 7u;
+    const bool qcomp = (af_of(e.src) & 4u) != 0;
+    const u32 cq = (qcomp && c) ? 5u - c : c;
+    const bool x0 = mine && c == 0u;
+    const u32 topLen = gshfl(e.len, first);
+    const bool isTop = mine && e.len == topLen;
+    if (gballot(isTop && x0)) {
+      // the top-level block has ended (:747-766)
+      const u64 topMask = gballot(isTop);
+      const u64 bad = gballot(isTop && !x0);
+      u64 emitMask = topMask;
+      if (bad) emitMask &= (1ull << ffs0(bad)) - 1ull;
+      nocc += 2u * pop(topMask);
+      const u32 ne = pop(emitMask);
+      if (nout + ne > OUTCAP) return RD_BAIL;
+      if ((emitMask >> gl) & 1ull) {
+        E br = e;
+        br.c0hi = br.c0lo;
+        br.c1lo = (P)tld;
+        br.c1hi = (P)tld;
+        out_put(nout + pop(emitMask & glt), br);
+      }
+      nout += ne;
+      if (bad) {
+        xerror = true;
+        return RD_XERROR;
+      }
+      return RD_ENDED;
+    }
+    if (gballot(x0)) return RD_BAIL;  // '$' below the top level: the generic round's business
+    const u32 cfirst = gshfl(cq, first);
+    if (gballot(mine && cq != cfirst) == 0) {
+      nocc += 2u * pop(alive);
+      if (mine) { ++tk; --ttt; }
+      *newAlive = alive;
+      return RD_UPDATED;
+    }
+    if (!BR) return RD_BAIL;
+    // a branch: the lanes part by their next symbol, in rank order A, C, G, T (:781-787)
+    const u64 m1 = gballot(mine && cq == 1u), m2 = gballot(mine && cq == 2u), m3 = gballot(mine && cq == 3u), m4 = gballot(mine && cq == 4u);
+    const u32 nb = (m1 != 0) + (m2 != 0) + (m3 != 0) + (m4 != 0);
+    if (nslot + nb > NSLOT || ni + nb > NSLOT) return RD_BAIL;
+    nocc += 2u * pop(alive);
+    if (mine) { ++tk; --ttt; }
+    FXP(5);
+#pragma unroll
+    for (u32 sy = 1; sy <= 4; ++sy) {
+      const u64 m = sy == 1 ? m1 : sy == 2 ? m2 : sy == 3 ? m3 : m4;
+      if (!m) continue;
+      const u32 ns = nslot++;
+      if (gl == ns) gAlive = m;
+      if (gl == ni) gI = ns;
+      ++ni;
+      if (mine && cq == sy && (m & (m - 1ull)) == 0) {  // alone from here on: a countdown group (extract())
+        e.c1lo = (P)tld;
+        e.c1hi = (P)ttt;
+        e.len |= FX_COUNTDOWN;
+      }
+    }
+    return RD_BRANCHED;
+  }
+
   // extract() over the n entries held one per group lane, already sorted by length descending.  Returns false when
   // the item has to be redone by a wider kernel.
   __device__ bool extract(E e, u32 n) {
@@ -2095,6 +2204,21 @@ struct GFx {
     gD = 0;
     gI = 0;
     inreg = gballot(gl < n && e.c1hi != e.c1lo) == 0;  // every block a single row (ranges never grow)
+    if (TEXT) {
+      if (!inreg) return false;
+      u64 v = 0, w = 0;
+      if (gl < n) {
+        const ulonglong2 pr = reinterpret_cast<const ulonglong2*>(find_of(e.src) < 2 ? A.rev.la : A.fwd.la)[(u64)e.c1lo];
+        v = pr.x;  // look-ahead entry and row-end entry of a row sit side by side
+        w = pr.y;
+      }
+      tsyms = (u32)v & SIGAX_LA_SYM_MASK;
+      tjump = v >> SIGAX_LA_ROW_SHIFT;
+      tk = 0;
+      tld = (u32)w;
+      ttt = (u32)(w >> 32);
+      sec_add(n);
+    }
 #ifdef SIGAX_FX_PROFILE
     dbg_round = 0;
 #endif
@@ -2105,7 +2229,7 @@ struct GFx {
       u32 guard = 0;
       while (alive) {
         u64 na = 0;
-        int st = round_fast(e, alive, &na, true);
+        int st = TEXT ? round_text(e, alive, &na) : round_fast(e, alive, &na, true);
         if (st == RD_BAIL) return false;
         if (st == RD_XERROR) return true;
         if (st != RD_UPDATED) break;
@@ -2166,7 +2290,7 @@ struct GFx {
           }
         } else if (alive) {
           u64 na = 0;
-          int st = round_fast(e, alive, &na, alone);  // two rounds at once, as in phase 1
+          int st = TEXT ? round_text(e, alive, &na) : round_fast(e, alive, &na, alone);  // two rounds at once, as in phase 1
           if (st == RD_BAIL) return false;
           if (st == RD_XERROR) return true;
           if (st == RD_UPDATED) {
@@ -2227,7 +2351,7 @@ struct GFx {
     // list X = find A's blocks + containfwd {0,1}; list Y = find B's blocks + containrev {2,3} (:1137-1140)
     const u32 nX = nA + c0 + c1, nY = nB + c2 + c3, T = nX + nY;
     if (T > (u32)W) {
-      if (W == 64 && big != nullptr && T <= FX_BIGCAP && A.irreducible) return body_big(L, chA, chB, nA, nB, c0, c2, nX, T);
+      if (W == 64 && !LEAN && big != nullptr && T <= FX_BIGCAP && A.irreducible) return body_big(L, chA, chB, nA, nB, c0, c2, nX, T);
       toowide = true;
       return false;
     }
@@ -2556,6 +2680,30 @@ struct GFx {
 // W == 32: two (read, side) items per wave, one per half; items that do not fit (more than 32 blocks, branching beyond
 // the half's slots, output beyond its share) are queued for the next launch (launch_filter_extract_fast), the last of
 // which queues what it cannot finish for the general kernel.
+// Which (read, side) items of the sub-batch have more blocks than a 32-lane group holds?  They skip the 32-lane launches:
+// queued here for the 64-lane one, one atomic per wave of 64 items.  Same count as GFx::body(): the find's blocks plus the
+// containment copies of the list's two chains.
+__global__ __launch_bounds__(256) void k_fx_route(FxArgs A) {
+  const u64 first = 2ull * A.read_begin, last = 2ull * A.read_end;
+  const u64 item = first + (u64)blockIdx.x * 256 + threadIdx.x;
+  bool wide = false;
+  if (item < last) {
+    const u32 r = (u32)(item >> 1), sd = (u32)(item & 1);
+    const uint4 c4 = reinterpret_cast<const uint4*>(A.chain_cnt)[r];
+    const u32 nA = (sd == 0 ? c4.x : c4.y) & SIGAX_CC_COUNT_MASK, nB = (sd == 0 ? c4.w : c4.z) & SIGAX_CC_COUNT_MASK;
+    const u32 nc = ((c4.x & SIGAX_CC_CONTAIN) ? 1u : 0u) + ((c4.y & SIGAX_CC_CONTAIN) ? 1u : 0u) + ((c4.z & SIGAX_CC_CONTAIN) ? 1u : 0u) +
+                   ((c4.w & SIGAX_CC_CONTAIN) ? 1u : 0u);
+    wide = nA + nB + nc > 32u;
+  }
+  const u64 m = __ballot(wide);
+  if (!m) return;
+  const u32 lane = threadIdx.x & 63u;
+  u64 b = 0;
+  if (lane == 0) b = atomicAdd(A.q_wide_n, (u64)__popcll(m));
+  b = readlane64(b, 0);
+  if (wide) A.q_wide[b + (u32)__popcll(m & ((1ull << lane) - 1ull))] = (u32)item;
+}
+
 #ifndef SIGAX_FX_LEAN_WAVES
 #define SIGAX_FX_LEAN_WAVES 4  // register budget of the lean launch as waves per SIMD (4: up to 128, it takes 89; 6: 80 with 6 spilled)
 #endif
@@ -2576,7 +2724,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? (LEA
 #endif
   wave_lds_sync();
   GFx<WIDE, W, LEAN> fx(A, tb, shm[wid], A.wpool + wave * FX_WPOOL, have2 ? &t2 : nullptr);
-  if constexpr (W == 64) {
+  if constexpr (W == 64 && LEAN == 0) {
     __shared__ BigSh<WIDE> bigsh[4];
     fx.big = &bigsh[wid];
   }
@@ -2588,9 +2736,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? (LEA
   // The strict lean launch is always the first one (range input) and appends with one atomic per item: its register
   // budget is what the error-free step time hangs on (89 VGPRs; 99 and scratch with the batching below: 9 % on the step),
   // and its atomics hide behind its other work.
-  constexpr bool STRICT = LEAN == 1 || LEAN == 2;
+  constexpr bool STRICT = LEAN == 1 || LEAN == 2 || LEAN == 5;
   const u64 first = 2ull * A.read_begin;
   if constexpr (STRICT) {
+    // Items with more blocks than a 32-lane group holds were queued for the 64-lane launch by k_fx_route before this
+    // launch: one atomic per such item on the queue's counter serialises at 6-16 ns, and at the C5 shape, where most items
+    // are that wide, it alone took 12.8 ms of a 17.8 ms chain.  (Batching appends through LDS here costs the launch 10
+    // VGPRs and scratch whichever way it is written; the few branching items' atomics hide behind the other work.)
     const u64 last = 2ull * A.read_end;
     for (u64 w0 = first + wave * 2; w0 < last; w0 += nwaves * 2) {
       const u64 item = w0 + (lane >> 5);
@@ -2599,8 +2751,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? (LEA
       if (has && !done && fx.gl == 0) {
         A.fin_cnt[item] = 0;
         A.occ_side[item] = 0;
-        if (fx.toowide) A.q_wide[atomicAdd(A.q_wide_n, 1ull)] = (u32)item;
-        else A.q_out[atomicAdd(A.q_out_n, 1ull)] = (u32)item;
+        if (!fx.toowide) A.q_out[atomicAdd(A.q_out_n, 1ull)] = (u32)item;
       }
       fx.account(has, done, item, nocc_total, nerr, nsub);
     }
@@ -3083,18 +3234,29 @@ static void launch_fx_stages(const FxArgs& a, unsigned grid32, unsigned grid64, 
     x.q_wide_n = widei < 0 ? nullptr : qn[widei];
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, st, x);
   };
+  auto route = [&]() {  // wide items of the range straight into queue 1
+    FxArgs x = a;
+    x.q_wide = q[1];
+    x.q_wide_n = qn[1];
+    hipLaunchKernelGGL(k_fx_route, dim3(nblk(2ull * (a.read_end - a.read_begin), 256)), dim3(256), 0, st, x);
+  };
   if (!lean) {
     stage(k_filter_extract_fast<WIDE, 32, 0>, grid32, -1, 2, -1);
     stage(k_filter_extract_fast<WIDE, 64, 0>, grid64, 2, -1, -1);
     return;
   }
   // queue 0: items for the branching 32-lane launch; queue 1: for the branching 64-lane launch; queue 2: for the full one
-  if (have2) {
-    if (!a.no_lean) stage(k_filter_extract_fast<WIDE, 32, 1>, grid32, -1, 0, 1);
+  static const bool no_text = getenv("SIGAX_FX_NO_TEXT") != nullptr;  // A/B aid
+  if (a.fwd.la && a.rev.la && a.fwd.rowend && a.rev.rowend && !no_text) {
+    if (!a.no_lean) { route(); stage(k_filter_extract_fast<WIDE, 32, 5>, grid32, -1, 0, -1); }
+    stage(k_filter_extract_fast<WIDE, 32, 6>, grid32, a.no_lean ? -1 : 0, 1, -1);
+    stage(k_filter_extract_fast<WIDE, 64, 6>, grid64, 1, 2, -1);
+  } else if (have2) {
+    if (!a.no_lean) { route(); stage(k_filter_extract_fast<WIDE, 32, 1>, grid32, -1, 0, -1); }
     stage(k_filter_extract_fast<WIDE, 32, 3>, grid32, a.no_lean ? -1 : 0, 1, -1);
     stage(k_filter_extract_fast<WIDE, 64, 3>, grid64, 1, 2, -1);
   } else {
-    if (!a.no_lean) stage(k_filter_extract_fast<WIDE, 32, 2>, grid32, -1, 0, 1);
+    if (!a.no_lean) { route(); stage(k_filter_extract_fast<WIDE, 32, 2>, grid32, -1, 0, -1); }
     stage(k_filter_extract_fast<WIDE, 32, 4>, grid32, a.no_lean ? -1 : 0, 1, -1);
     stage(k_filter_extract_fast<WIDE, 64, 4>, grid64, 1, 2, -1);
   }
@@ -3136,10 +3298,10 @@ void launch_build2(const FmStrand& s, bool wide, u32* gran2, u64* super2, u32* c
   }
 }
 
-void launch_rowend_build(const FmStrand& s, bool wide, u64 n_strings, u64* out, hipStream_t st) {  // n_strings: rows of rank-0 suffixes
+void launch_rowend_build(const FmStrand& s, bool wide, u64 n_strings, u64* out, u64* la, hipStream_t st) {  // n_strings: rows of rank-0 suffixes
   if (n_strings == 0) return;
-  if (wide) hipLaunchKernelGGL(k_rowend_build<true>, dim3(nblk(n_strings, 256)), dim3(256), 0, st, s, n_strings, out);
-  else hipLaunchKernelGGL(k_rowend_build<false>, dim3(nblk(n_strings, 256)), dim3(256), 0, st, s, n_strings, out);
+  if (wide) hipLaunchKernelGGL(k_rowend_build<true>, dim3(nblk(n_strings, 256)), dim3(256), 0, st, s, n_strings, out, la);
+  else hipLaunchKernelGGL(k_rowend_build<false>, dim3(nblk(n_strings, 256)), dim3(256), 0, st, s, n_strings, out, la);
 }
 
 u64 scan_partials_needed(u64 n) { return (n + 1 + SCAN_ITEMS - 1) / SCAN_ITEMS + 1; }
