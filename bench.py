@@ -50,9 +50,10 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU restatement (0 = skip)")
     ap.add_argument("--workdir", default=None)
-    ap.add_argument("--subbatches", type=int, default=2,
+    ap.add_argument("--subbatches", type=int, default=1,
                     help="sub-batches per step (0 = library default for one batch at a time: 4 at this size); sub-batch i's "
-                         "filter/extract kernels run beside sub-batch i+1's finder")
+                         "filter/extract kernels run beside sub-batch i+1's finder.  With three batches in flight the overlap "
+                         "comes from the next batch and one launch chain per step is fastest (tools/sweep_pipeline.sh)")
     ap.add_argument("--depth", type=int, default=3,
                     help="batches in flight on the index (batch k+1's finder starts beside batch k's filter/extract tail; the third "
                          "hides batch k-1's scan / scatter / edge tail and its copy to the host)")
@@ -356,12 +357,13 @@ def bench_overlap(args):
                                           "frac": glines / GATHER_CEILING_GLINES,
                                           "note": "random line requests per second against what dependency-free random "
                                                   "reads sustain on this chip (tools/gather_probe*.hip)"},
-                         "note": "launch durations in the timed region, where sub-batch i+1's k_find runs beside "
-                                 "sub-batch i's filter/extract kernels" if launches > 1 else "kernels run back to back"},
-            "roofline_filter_extract": {"bound": "hbm", "kernel": "k_filter_extract_fast<32> + <64>", "achieved": ach_fx,
+                         "note": ("launch durations in the timed region, where a k_find launch runs beside the filter/extract "
+                                  "kernels of the previous sub-batch or batch" if (nsub_step > 1 or depth > 1)
+                                  else "kernels run back to back")},
+            "roofline_filter_extract": {"bound": "hbm", "kernel": "k_filter_extract_fast launch chain (k_fx_route + strict 32 + branching 32 + branching 64 + full 64)", "achieved": ach_fx,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_fx / HBM_PEAK_GBS, "traffic": fx_traffic,
                                         "algorithmic_bytes_per_launch": bytes_fx / nsub_step, "avg_launch_ms": fx_ms,
-                                        "note": "latency-bound: a chain of dependent rank lookups per (read, side)"},
+                                        "note": "latency-bound: a chain of dependent lookups per (read, side)"},
             "whole_path": {"achieved": bytes_step / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": bytes_step / step_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": bytes_step,
                            "traffic_find_plus_filter_extract": (launches * traffic + nsub_step * fx_traffic) if (traffic and fx_traffic) else None,

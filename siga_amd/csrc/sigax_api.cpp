@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -87,6 +88,16 @@ struct sigax_index {
   void* d_super2[2]; // ... their superblock bases (64-bit positions) or NULL
   void* d_rowend[2]; // row-end tables (fm_layout.h) or NULL
   void* d_la[2];     // look-ahead tables (fm_layout.h) or NULL
+  // The row tables of an index of 2^26 symbols and more are built by a side thread while the caller goes on (at BASELINE
+  // configs[1] 0.1 s: more than the whole one-batch `siga overlap` spends on the GPU); runs enqueued before they are ready
+  // use the forms without them -- same bytes out.  0 none / published, 1 being built, 2 built: tab_st waits for publishing.
+  // Nor are they started before the index sees its second run: a one-batch job (the CLI at configs[1]) would pay for
+  // tables it never uses.  tab_plan = bytes of the tables still to be allocated (sigax_batch_size_hint leaves them free).
+  std::thread* tab_thread;
+  std::atomic<int>* tab_state;
+  FmStrand tab_st[2];
+  u64 tab_bytes, tab_plan, n_runs;
+  bool tab_la;
   void* d_super[2];
   uint32_t* d_sai[2];
   u64 n_sai;
@@ -228,6 +239,11 @@ static int upload(const void* src, size_t bytes, void** dst, u64* acct) {
 extern "C" void sigax_index_close(sigax_index* ix) {
   if (!ix) return;
   hipSetDevice(ix->device);
+  if (ix->tab_thread) {
+    ix->tab_thread->join();
+    delete ix->tab_thread;
+  }
+  delete ix->tab_state;
   for (int s = 0; s < 2; ++s) {
     if (ix->d_gran[s]) hipFree(ix->d_gran[s]);
     if (ix->d_gran2[s]) hipFree(ix->d_gran2[s]);
@@ -251,44 +267,107 @@ extern "C" void sigax_index_close(sigax_index* ix) {
 // walk to the end of that read (~100 dependent rounds).  An accelerator like the two-step tables: skipped when memory is
 // short or SIGAX_ROWEND=0, and the extractor then walks.  Built on the index's own device (a clone builds its own: 2 n LF
 // steps on the spot beat copying 16 n bytes between GPUs).
-static void build_rowend(sigax_index* ix) {
+// Which tables does this index get?  Decided at open from the free memory of that moment.
+static void plan_row_tables(sigax_index* ix) {
   const char* envr = getenv("SIGAX_ROWEND");
   const char* envl = getenv("SIGAX_LOOKAHEAD");
   const u64 n_symbols = ix->n_symbols;
+  ix->tab_plan = 0;
   size_t mfree = 0, mtotal = 0;
   (void)hipMemGetInfo(&mfree, &mtotal);
   if ((envr && envr[0] == '0') || ix->st[0].C[1] >= 0xFFFFFFFFull || n_symbols == 0 || 16ull * n_symbols >= mfree / 2) return;
   // the look-ahead tables (another 8 bytes per symbol and strand) when both pairs fit in 60 % of the free memory
-  const bool want_la = !(envl && envl[0] == '0') && n_symbols < (1ull << (64 - SIGAX_LA_ROW_SHIFT)) && 32ull * n_symbols < mfree / 5 * 3;
+  ix->tab_la = !(envl && envl[0] == '0') && n_symbols < (1ull << (64 - SIGAX_LA_ROW_SHIFT)) && 32ull * n_symbols < mfree / 5 * 3;
+  ix->tab_plan = 2 * n_symbols * (ix->tab_la ? 16 : 8);  // with look-ahead: one interleaved table {look-ahead, row-end} per row
+}
+
+// Allocation, on the caller's thread ...
+static bool alloc_row_tables(sigax_index* ix) {
+  const bool want_la = ix->tab_la;
+  const u64 bytes = ix->tab_plan / 2;
+  ix->tab_plan = 0;
   hipError_t e = hipSuccess;
-  const u64 bytes = n_symbols * (want_la ? 16 : 8);  // with look-ahead: one interleaved table {look-ahead, row-end} per row
-  for (int s = 0; s < 2 && e == hipSuccess; ++s) {
-    void** slot = want_la ? &ix->d_la[s] : &ix->d_rowend[s];
-    e = hipMalloc(slot, bytes);
-    if (e == hipSuccess) e = hipMemset(*slot, 0, bytes);
-    if (e != hipSuccess) break;
-    launch_rowend_build(ix->st[s], ix->wide, ix->st[s].C[1], want_la ? (u64*)ix->d_la[s] + 1 : (u64*)ix->d_rowend[s],
-                        want_la ? (u64*)ix->d_la[s] : nullptr, nullptr);
-    e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipGetLastError();
-  }
+  for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipMalloc(want_la ? &ix->d_la[s] : &ix->d_rowend[s], bytes);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     for (int s = 0; s < 2; ++s) {
       if (ix->d_rowend[s]) hipFree(ix->d_rowend[s]);
       if (ix->d_la[s]) hipFree(ix->d_la[s]);
       ix->d_rowend[s] = ix->d_la[s] = nullptr;
-      ix->st[s].rowend = ix->st[s].la = nullptr;
     }
-    if (getenv("SIGAX_VERBOSE")) fprintf(stderr, "[sigax] row-end tables not built (%s): the extractor walks\n", hipGetErrorString(e));
-    return;
+    if (getenv("SIGAX_VERBOSE")) fprintf(stderr, "[sigax] row tables not allocated (%s): the extractor walks\n", hipGetErrorString(e));
+    return false;
+  }
+  return true;
+}
+
+// ... and the fill, on a stream of its own (possibly on a side thread)
+static void fill_row_tables(sigax_index* ix, bool want_la, u64 bytes, FmStrand out[2], u64* out_bytes) {
+  out[0] = ix->st[0];
+  out[1] = ix->st[1];
+  *out_bytes = 0;
+  hipStream_t sb = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
+  for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+    void* tab = want_la ? ix->d_la[s] : ix->d_rowend[s];
+    e = hipMemsetAsync(tab, 0, bytes, sb);
+    if (e != hipSuccess) break;
+    launch_rowend_build(ix->st[s], ix->wide, ix->st[s].C[1], want_la ? (u64*)tab + 1 : (u64*)tab, want_la ? (u64*)tab : nullptr, sb);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(sb);
+  if (sb) (void)hipStreamDestroy(sb);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (getenv("SIGAX_VERBOSE")) fprintf(stderr, "[sigax] row tables not built (%s): the extractor walks\n", hipGetErrorString(e));
+    return;  // the buffers are freed with the index
   }
   for (int s = 0; s < 2; ++s) {
-    ix->st[s].la = (const u64*)ix->d_la[s];
-    ix->st[s].rowend = want_la ? (const u64*)ix->d_la[s] + 1 : (const u64*)ix->d_rowend[s];
-    ix->st[s].re_stride = want_la ? 2u : 1u;
-    ix->device_bytes += bytes;
+    out[s].la = (const u64*)ix->d_la[s];
+    out[s].rowend = want_la ? (const u64*)ix->d_la[s] + 1 : (const u64*)ix->d_rowend[s];
+    out[s].re_stride = want_la ? 2u : 1u;
   }
+  *out_bytes = 2 * bytes;
+}
+
+// the tables of a finished build become visible to the runs enqueued from now on
+static void publish_tables(sigax_index* ix) {
+  if (!ix->tab_state || ix->tab_state->load(std::memory_order_acquire) != 2) return;
+  for (int s = 0; s < 2; ++s) {
+    ix->st[s].rowend = ix->tab_st[s].rowend;
+    ix->st[s].la = ix->tab_st[s].la;
+    ix->st[s].re_stride = ix->tab_st[s].re_stride;
+  }
+  ix->device_bytes += ix->tab_bytes;
+  ix->tab_state->store(0, std::memory_order_release);
+}
+
+// start (or do) the build: allocate here, fill on a side thread unless `sync`
+static void start_row_tables(sigax_index* ix, bool sync) {
+  if (ix->tab_plan == 0) return;
+  const bool want_la = ix->tab_la;
+  const u64 bytes = ix->tab_plan / 2;
+  if (!alloc_row_tables(ix)) return;
+  if (sync) {
+    fill_row_tables(ix, want_la, bytes, ix->tab_st, &ix->tab_bytes);
+    ix->tab_state->store(2);
+    publish_tables(ix);
+    return;
+  }
+  ix->tab_state->store(1);
+  ix->tab_thread = new std::thread([ix, want_la, bytes] {
+    (void)hipSetDevice(ix->device);
+    fill_row_tables(ix, want_la, bytes, ix->tab_st, &ix->tab_bytes);
+    ix->tab_state->store(2, std::memory_order_release);
+  });
+}
+
+static void build_rowend(sigax_index* ix) {
+  ix->tab_state = new std::atomic<int>(0);
+  for (int s = 0; s < 2; ++s) ix->st[s].re_stride = 1;
+  plan_row_tables(ix);
+  // small indexes (and SIGAX_TABLES_SYNC=1) at once; the others when the second run is enqueued (enqueue())
+  if (ix->n_symbols < (1ull << 26) || getenv("SIGAX_TABLES_SYNC") != nullptr) start_row_tables(ix, true);
 }
 
 extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const uint8_t* rruns, uint64_t n_rruns,
@@ -533,7 +612,7 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
     sigax_index_close(ix);
     return rc;
   }
-  if (src->d_rowend[0] || src->d_la[0]) build_rowend(ix);
+  build_rowend(ix);  // plans its own row tables; built on this device when its second run starts
   *out = ix;
   return SIGAX_OK;
 }
@@ -837,6 +916,8 @@ extern "C" int sigax_batch_set_device_reads(sigax_batch* b, const void* d_seqs, 
 static int enqueue(sigax_batch* b, hipStream_t st) {
   sigax_index* ix = b->ix;
   std::lock_guard<std::mutex> lock(*ix->enqueue_mu);  // one batch's launch sequence at a time on the shared streams
+  publish_tables(ix);
+  if (++ix->n_runs == 2) start_row_tables(ix, false);
   const uint32_t n = b->n_reads;
   const bool edges = (b->flags & SIGAX_EDGES) != 0;
   if (edges && (!ix->d_sai[0] || !ix->d_read_len))
@@ -1253,6 +1334,7 @@ extern "C" int sigax_batch_size_hint(sigax_index* ix, uint32_t max_read_len, uin
   HIP_TRY(hipSetDevice(ix->device));
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  free_b = free_b > ix->tab_plan ? free_b - ix->tab_plan : 0;  // the row tables are allocated when the second run starts
   const u64 mm = std::max<uint32_t>((flags & SIGAX_DUPLICATE) ? max_read_len : min_overlap, 1u);
   u64 cap = (max_read_len > mm ? max_read_len - mm : 0u) + 1u;
   cap = (cap + 1u) & ~1ull;

@@ -1195,6 +1195,9 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
         cleanup();
         return;
       }
+      // with two runs in flight per device the finder of one overlaps the filter/extract of the other: one launch chain
+      // per run is then faster than the library's sub-batches (bench.py: 112 vs 106 M reads/s at BASELINE configs[1])
+      if (nbatch >= 2 * devs.size() && !getenv("SIGAX_SUBBATCHES")) sigax_batch_set_subbatches(bt[k], 1);
     }
     const bool timing = getenv("SIGA_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };

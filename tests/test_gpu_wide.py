@@ -61,9 +61,17 @@ def test_cooperative_finder_bit_exact():
     _run_parity({"SIGAX_FIND_COOP": "1"}, "hits_and_asqg or non_acgt or duplicate or in_flight or deep or mid")
 
 
-def test_branch_walks_without_the_row_end_table():
-    """The row-end table (fm_layout.h) turns a lone single-row group's walk to the end of its read into a countdown; with
-    SIGAX_ROWEND=0 the extractor walks as the reference does.  Both forms give the oracle's bytes on read sets with
-    substitutions (the default form runs in test_gpu_random.py), 32- and 64-bit positions."""
+def test_extractor_forms_without_the_row_tables():
+    """The look-ahead and row-end tables (fm_layout.h) are accelerators: with both, filter/extract reads a block's next ten
+    symbols from one lookup and a lone single-row group is a countdown (what every other test runs); with
+    SIGAX_LOOKAHEAD=0 the rounds come from two-step lines (or one-step granules) and only the countdown uses the row-end
+    table; with SIGAX_ROWEND=0 neither exists and the extractor walks as the reference does.  Every form gives the oracle's
+    bytes on read sets with substitutions, duplicates and substrings, 32- and 64-bit positions."""
+    _run_parity({"SIGAX_LOOKAHEAD": "0"}, None, seeds=(1, 2, 5, 8, 13, 21))
+    _run_parity({"SIGAX_LOOKAHEAD": "0", "SIGAX_TWO_STEP": "0"}, None, seeds=(2, 3, 8))
     _run_parity({"SIGAX_ROWEND": "0"}, None, seeds=(1, 2, 5, 8, 13))
+    _run_parity({"SIGAX_ROWEND": "0", "SIGAX_TWO_STEP": "0"}, None, seeds=(3, 8, 21))
     _run_parity({"SIGAX_FORCE_WIDE": "1"}, None, seeds=(2, 3, 8, 21))
+    _run_parity({"SIGAX_FORCE_WIDE": "1", "SIGAX_LOOKAHEAD": "0"}, None, seeds=(2, 8))
+    _run_parity({"SIGAX_LOOKAHEAD": "0"}, "hits_and_asqg or non_acgt or duplicate or deep")
+    _run_parity({"SIGAX_ROWEND": "0"}, "hits_and_asqg or non_acgt or duplicate or deep")
