@@ -1012,7 +1012,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
       // from 2^31 symbols the per-lane finder's 32-bit byte offsets no longer reach the table; below, it is the faster one
       // (1.2e9 symbols, one rank's view of an 8-GPU job: 80 M reads/s per lane vs 66 M cooperative, gpurun_out/emu/)
       const u64 coop_min = env_cmin ? strtoull(env_cmin, nullptr, 10) : (1ull << 31);
-      const u64 need = 64ull * b->cur_max_len + 16;  // the workgroup's 64 reads, staged as bytes
+      const u64 need = (64ull * b->cur_max_len + 16) / 2 + 16;  // the workgroup's 64 reads, staged as 4-bit ranks
       const bool can = fa.two_step && need <= 32768;
       const bool want = env_coop ? env_coop[0] != '0' : (ix->wide || ix->n_symbols >= coop_min);
       fa.coop = (can && want) ? 1u : 0u;

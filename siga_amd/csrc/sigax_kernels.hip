@@ -619,6 +619,7 @@ __device__ __forceinline__ void find2_tables_load(Find2TablesT<WIDE>& t, const F
 // system counts requests, not bytes).  `tag` = destination byte address | number of 16-byte pieces to write - 1.
 template <int NT>
 struct FindStageT {  // a half-filled row waits here for the lane's next record, across steps
+  static constexpr bool direct = false;
   uint4 row_[NT][4];
   u64 tag_[NT];
   __device__ __forceinline__ uint4* row(u32 t) { return row_[t]; }
@@ -626,9 +627,19 @@ struct FindStageT {  // a half-filled row waits here for the lane's next record,
 };
 typedef FindStageT<256> FindStage;
 typedef FindStageT<128> FindStageC;
+// No parking: records go to the arena as they are made (two or four 16-byte stores).  For the cooperative finder, whose
+// residency is set by its LDS: without the 9 KB of rows a workgroup of 64 reads x 150 bp takes 31 KB, five fit a CU instead
+// of four, and at the C3 shape the finder follows its occupancy (tools/coop_occupancy.sh: 35.4 / 27.3 / 24.4 ms at 2 / 3 / 4).
+struct FindStageNone {
+  static constexpr bool direct = true;
+  __device__ __forceinline__ uint4* row(u32) { return nullptr; }
+  __device__ __forceinline__ u64& tag(u32) { return dummy; }
+  u64 dummy;
+};
 
 template <class SG>
 __device__ __forceinline__ void find_flush(SG& sg, bool want, u32 tid) {
+  if constexpr (SG::direct) return;
   const u32 lane = tid & 63u, q0 = tid & ~3u, piece = tid & 3u;
   __builtin_amdgcn_wave_barrier();
   u64 bal = __ballot(want);
@@ -646,6 +657,8 @@ __device__ __forceinline__ void find_flush(SG& sg, bool want, u32 tid) {
   }
   __builtin_amdgcn_wave_barrier();
 }
+
+__device__ __forceinline__ u32 rd_rank(const unsigned char* rd, u32 i) { return ((u32)rd[i >> 1] >> ((i & 1u) * 4u)) & 15u; }
 
 // STAGED: the workgroup's 64 reads (one contiguous byte range of the batch) are in LDS at `rd`, first byte = the
 // 4-byte-aligned address at or below the first read's first base; rd_base = that address's offset in A.seqs.
@@ -697,7 +710,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
 
   P lo0 = 0, sz = 0, lo1 = 0;
   if (live) {
-    u32 r = base_rank(STAGED ? rd[rdo + (fromStart ? 0 : L - 1)] : sq[fromStart ? 0 : L - 1]);
+    u32 r = (STAGED && COOP) ? rd_rank(rd, rdo + (fromStart ? 0 : L - 1)) : base_rank(STAGED ? rd[rdo + (fromStart ? 0 : L - 1)] : sq[fromStart ? 0 : L - 1]);
     if (comp) r = comp_rank(r);
     // IntervalPair::init (overlap_builder.cpp:91-94, fmindex.h:90-93)
     lo0 = (P)CP[r]; sz = (P)tb.T[PI.which][r]; lo1 = (P)CO[r];
@@ -710,6 +723,16 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
   // this lane's row; returns whether the row is now full (to be written by the quad)
   auto emit = [&](P c0lo, P d, P c1lo, P r0lo, P szv, u32 len) -> bool {
     bool fl = false;
+    if constexpr (SG::direct) {
+      if (nb < A.cap - 1 && !full) {
+        cand_store(reinterpret_cast<Cand<WIDE>*>(slot_addr(nb)), c0lo, d, c1lo, r0lo, c1lo, szv, len, af);
+      } else {
+        flagbits |= 1u;
+        full = true;
+      }
+      ++nb;
+      return false;
+    }
     if (nb < A.cap - 1 && !full) {
       if (WIDE) {
         cand_store(reinterpret_cast<Cand<WIDE>*>(sg.row(tid)), c0lo, d, c1lo, r0lo, c1lo, szv, len, af);
@@ -738,8 +761,13 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
       u32 c = 0, e = 0;
       const bool want2 = on && s + 1 < L;
       if (want2) {
-        c = base_rank(rd[rdo + (fromStart ? s : L - 1 - s)]);
-        e = base_rank(rd[rdo + (fromStart ? s + 1 : L - 2 - s)]);
+        if (COOP) {  // staged as ranks
+          c = rd_rank(rd, rdo + (fromStart ? s : L - 1 - s));
+          e = rd_rank(rd, rdo + (fromStart ? s + 1 : L - 2 - s));
+        } else {
+          c = base_rank(rd[rdo + (fromStart ? s : L - 1 - s)]);
+          e = base_rank(rd[rdo + (fromStart ? s + 1 : L - 2 - s)]);
+        }
         if (comp) { c = comp_rank(c); e = comp_rank(e); }
       }
       const bool ok2 = want2 && c != 0 && e != 0;
@@ -821,7 +849,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
       u32 ch;
       two_gran = (pl >> 7) != (pu >> 7);
       if (STAGED) {
-        ch = rd[rdo + (fromStart ? s : L - 1 - s)];
+        ch = COOP ? rd_rank(rd, rdo + (fromStart ? s : L - 1 - s)) : (u32)rd[rdo + (fromStart ? s : L - 1 - s)];
         if (WIDE) find_step_loads8(PI.g + (pl >> 7) * 4, PI.g + (pu >> 7) * 4, gl, gu);
         else find_step_loads8_s(PI.g, (u32)(pl >> 7) * 64u, (u32)(pu >> 7) * 64u, gl, gu);
       } else if (WIDE) {
@@ -831,7 +859,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
       }
       const Cnt4P<P> l = fm_rank4p_from<WIDE>(PI, pl, gl);
       const Cnt4P<P> u = fm_rank4p_from<WIDE>(PI, pu, gu);
-      u32 r = base_rank(ch & 0xFFu);
+      u32 r = (STAGED && COOP) ? ch : base_rank(ch & 0xFFu);
       if (comp) r = comp_rank(r);
       P da = u.a - l.a, dc = u.c - l.c, dg = u.g - l.g, dt = u.t - l.t;
       P dd = sz - (da + dc + dg + dt);  // '$' extensions
@@ -853,7 +881,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
   // a single record left in the row (u32 positions, odd count): 32 bytes = two pieces
   {
     const bool tail = !WIDE && live && !full && (nb & 1u);
-    if (tail) sg.tag(tid) = slot_addr(nb - 1) | 1u;
+    if (!SG::direct && tail) sg.tag(tid) = slot_addr(nb - 1) | 1u;
     find_flush(sg, tail, tid);
   }
   bool contain = false;
@@ -884,8 +912,12 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
       // range and probe.updateR('$') reuses the two positions of rext.
       P ld = lo0 - (l.a + l.c + l.g + l.t);
       P lpd = lo1 - (lp.a + lp.c + lp.g + lp.t);
-      cand_store(reinterpret_cast<Cand<WIDE>*>(sg.row(tid)), ld, sz, lpd, lo0, lo1, sz, L, af);
-      sg.tag(tid) = slot_addr(A.cap - 1) | (WIDE ? 3u : 1u);
+      if constexpr (SG::direct) {
+        cand_store(reinterpret_cast<Cand<WIDE>*>(slot_addr(A.cap - 1)), ld, sz, lpd, lo0, lo1, sz, L, af);
+      } else {
+        cand_store(reinterpret_cast<Cand<WIDE>*>(sg.row(tid)), ld, sz, lpd, lo0, lo1, sz, L, af);
+        sg.tag(tid) = slot_addr(A.cap - 1) | (WIDE ? 3u : 1u);
+      }
       flagbits |= SIGAX_CC_CONTAIN;
       contain = true;
     }
@@ -927,6 +959,29 @@ __device__ __forceinline__ bool find_stage_reads(const FindArgs& A, u64* rd_base
   return true;
 }
 
+// The cooperative finder stages its reads as 4-bit ranks, two per byte (its residency hangs on its LDS, and the rank is
+// what a step needs anyway): byte i of the staged range = nibble i.
+template <int NT>
+__device__ __forceinline__ bool find_stage_reads_packed(const FindArgs& A, u64* rd_base) {
+  const u32 per = (u32)NT / A.chains_per_wg;
+  const u32 r0 = A.read_begin + blockIdx.x * per;
+  const u32 r1 = r0 + per < A.read_end ? r0 + per : A.read_end;
+  const u64 lo = A.offs[r0], hi = A.offs[r1];
+  const u64 alo = (reinterpret_cast<u64>(A.seqs) + lo) & ~3ull;
+  const u64 nbytes = reinterpret_cast<u64>(A.seqs) + hi - alo;
+  *rd_base = alo - reinterpret_cast<u64>(A.seqs);
+  if ((nbytes + 3) / 2 + 4 > (u64)A.stage_bytes) return false;
+  const u32* src = reinterpret_cast<const u32*>(alo);
+  unsigned short* dst = reinterpret_cast<unsigned short*>(find_dyn_lds);
+  const u32 nw = (u32)((nbytes + 3) >> 2);
+  for (u32 w = threadIdx.x; w < nw; w += (u32)NT) {
+    const u32 v = src[w];
+    dst[w] = (unsigned short)(base_rank(v & 0xFFu) | (base_rank((v >> 8) & 0xFFu) << 4) | (base_rank((v >> 16) & 0xFFu) << 8) |
+                              (base_rank(v >> 24) << 12));
+  }
+  return true;
+}
+
 // u32 positions: held to 64 registers, so that two finder workgroups and three filter/extract waves per SIMD fit the
 // 512-entry register file together (2 x 64 + 3 x 128)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_find_n(FindArgs A) {
@@ -961,12 +1016,12 @@ __global__ __launch_bounds__(128) void k_find_c2(FindArgs A) {
   __shared__ Find2Tables t2;
   __shared__ __attribute__((aligned(16))) uint4 stage[2 * COOP_WAVE_U4];
   u64 rd_base = 0;
-  const bool staged = find_stage_reads<128>(A, &rd_base);
+  const bool staged = find_stage_reads_packed<128>(A, &rd_base);
   find2_tables_load(t2, A.fwd, A.rev);
   fm_tables_load(tb, A.fwd, A.rev);
-  __shared__ FindStageC sg;
-  if (staged) find_body<false, true, true, true, 128, FindStageC>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
-  else find_body<false, false, false, false, 128, FindStageC>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
+  FindStageNone sg;
+  if (staged) find_body<false, true, true, true, 128, FindStageNone>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
+  else find_body<false, false, false, false, 128, FindStageNone>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
 }
 // the same with 64-bit positions (indexes of 2^32 symbols and more: BASELINE configs[4])
 __global__ __launch_bounds__(128) void k_find_c2w(FindArgs A) {
@@ -974,12 +1029,12 @@ __global__ __launch_bounds__(128) void k_find_c2w(FindArgs A) {
   __shared__ Find2TablesT<true> t2;
   __shared__ __attribute__((aligned(16))) uint4 stage[2 * COOP_WAVE_U4];
   u64 rd_base = 0;
-  const bool staged = find_stage_reads<128>(A, &rd_base);
+  const bool staged = find_stage_reads_packed<128>(A, &rd_base);
   find2_tables_load<true>(t2, A.fwd, A.rev);
   fm_tables_load(tb, A.fwd, A.rev);
-  __shared__ FindStageC sg;
-  if (staged) find_body<true, true, true, true, 128, FindStageC>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
-  else find_body<true, false, false, false, 128, FindStageC>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
+  FindStageNone sg;
+  if (staged) find_body<true, true, true, true, 128, FindStageNone>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
+  else find_body<true, false, false, false, 128, FindStageNone>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
 }
 __global__ __launch_bounds__(256) void k_find_w(FindArgs A) {
   __shared__ FmTables tb;
@@ -3194,8 +3249,10 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
     // 64 reads per workgroup; the dynamic LDS holds exactly their bases (no residency padding: LDS is what limits it)
     const unsigned gc = nblk((u64)(a.read_end - a.read_begin), 64u);
     b.stage_bytes = a.coop_stage_bytes;
-    if (wide) hipLaunchKernelGGL(k_find_c2w, dim3(gc), dim3(128), a.coop_stage_bytes, st, b);
-    else hipLaunchKernelGGL(k_find_c2, dim3(gc), dim3(128), a.coop_stage_bytes, st, b);
+    static const char* env_pad = getenv("SIGAX_FIND_COOP_PAD");  // measurement aid: unused LDS = fewer workgroups per CU
+    const unsigned dyn = a.coop_stage_bytes + (env_pad ? (unsigned)atoi(env_pad) : 0u);
+    if (wide) hipLaunchKernelGGL(k_find_c2w, dim3(gc), dim3(128), dyn, st, b);
+    else hipLaunchKernelGGL(k_find_c2, dim3(gc), dim3(128), dyn, st, b);
     return;
   }
   if (wide) hipLaunchKernelGGL(k_find_w, dim3(g), dim3(bs), lds, st, b);
