@@ -1017,6 +1017,11 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
       const bool want = env_coop ? env_coop[0] != '0' : (ix->wide || ix->n_symbols >= coop_min);
       fa.coop = (can && want) ? 1u : 0u;
       fa.coop_stage_bytes = (uint32_t)((need + 15) & ~15ull);
+      // measurement aid: cap the grid at this many workgroups per CU (they then walk the tiles).  Not a way to set the
+      // residency: the dispatcher packs a CU before it moves on, so a grid of 4 per CU fills two CUs in three with 6 each
+      // (finder 10.3 ms per 1 M reads at C2 against 7.7 uncapped, tools/coop_c2.sh)
+      static const char* env_cwg = getenv("SIGAX_FIND_COOP_WGS");
+      fa.coop_grid = env_cwg ? (uint32_t)ix->n_cu * (uint32_t)atoi(env_cwg) : 0u;
       // per-lane gathers use 32-bit byte offsets into the two-step table: beyond 2^31 symbols only the cooperative form works
       if (fa.two_step && !fa.coop && ix->n_symbols >= (1ull << 31)) fa.two_step = 0;
     }

@@ -46,6 +46,7 @@ struct FindArgs {
   uint32_t stage_bytes;              // dynamic LDS per workgroup that may hold the workgroup's reads (set by launch_find)
   uint32_t two_step;                 // both strands carry the two-step table (u32 positions only)
   uint32_t coop, coop_stage_bytes;   // cooperative two-step finder (k_find_c2): lines staged through LDS; bytes for 64 reads
+  uint32_t coop_grid;                // ... its grid cap (persistent workgroups walk the tiles), 0 = one workgroup per tile
   uint32_t chain_base, chains_per_wg; // a workgroup walks chains [chain_base, chain_base + chains_per_wg) (4, or 2: one strand's
                                      // table per launch) of 256 / chains_per_wg reads; chains outside are another launch's
   void* arena;                       // [n_reads][4][cap] candidate records of cand_bytes(wide) each

@@ -665,14 +665,14 @@ __device__ __forceinline__ u32 rd_rank(const unsigned char* rd, u32 i) { return 
 // COOP: the double step's lines come through LDS (find_step2_dma); NT = threads of the workgroup
 template <bool WIDE, bool STAGED, bool TWO, bool COOP = false, int NT = 256, class SG = FindStage>
 __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& sg, const Find2TablesT<WIDE>& t2,
-                                          const unsigned char* rd, u64 rd_base, uint4* coop_stage = nullptr) {
+                                          const unsigned char* rd, u64 rd_base, uint4* coop_stage = nullptr, u32 tile = blockIdx.x) {
   // A workgroup = 64 reads; wave o of it walks chain o of each, so everything that depends on the chain (which index
   // is primary, complementing, the direction the read is consumed in) is wave-uniform and lives in scalar registers.
   // (With chains_per_wg == 2 a workgroup is 128 reads and two chains: the launch gathers from one strand's tables.)
   const u32 tid = threadIdx.x;
   const u32 wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const u32 o = A.chain_base + (wv & (A.chains_per_wg - 1u));
-  const u32 read = A.read_begin + blockIdx.x * ((u32)NT / A.chains_per_wg) + (wv / A.chains_per_wg) * 64u + (tid & 63u);
+  const u32 read = A.read_begin + tile * ((u32)NT / A.chains_per_wg) + (wv / A.chains_per_wg) * 64u + (tid & 63u);
   typedef typename PosOf<WIDE>::type P;
   u32 nocc = 0;
   u32 nsec = 0;  // wave total (scalar): distinct 64-byte sectors of the rank tables asked for (a two-step line is two)
@@ -962,9 +962,9 @@ __device__ __forceinline__ bool find_stage_reads(const FindArgs& A, u64* rd_base
 // The cooperative finder stages its reads as 4-bit ranks, two per byte (its residency hangs on its LDS, and the rank is
 // what a step needs anyway): byte i of the staged range = nibble i.
 template <int NT>
-__device__ __forceinline__ bool find_stage_reads_packed(const FindArgs& A, u64* rd_base) {
+__device__ __forceinline__ bool find_stage_reads_packed(const FindArgs& A, u64* rd_base, u32 tile) {
   const u32 per = (u32)NT / A.chains_per_wg;
-  const u32 r0 = A.read_begin + blockIdx.x * per;
+  const u32 r0 = A.read_begin + tile * per;
   const u32 r1 = r0 + per < A.read_end ? r0 + per : A.read_end;
   const u64 lo = A.offs[r0], hi = A.offs[r1];
   const u64 alo = (reinterpret_cast<u64>(A.seqs) + lo) & ~3ull;
@@ -1011,30 +1011,42 @@ __global__ __launch_bounds__(256) void k_find_n2(FindArgs A) {
 }
 // u32 positions, two-step table of any size below 2^32 symbols, lines fetched cooperatively through LDS: a workgroup =
 // 2 waves = the two chains of one strand for 64 reads (launched once per strand)
+// A workgroup walks tiles of 64 reads: tile = blockIdx.x, + gridDim.x, ...; normally the grid has one workgroup per tile
+// (FindArgs::coop_grid caps it for measurements).
 __global__ __launch_bounds__(128) void k_find_c2(FindArgs A) {
   __shared__ FmTables tb;
   __shared__ Find2Tables t2;
   __shared__ __attribute__((aligned(16))) uint4 stage[2 * COOP_WAVE_U4];
-  u64 rd_base = 0;
-  const bool staged = find_stage_reads_packed<128>(A, &rd_base);
   find2_tables_load(t2, A.fwd, A.rev);
   fm_tables_load(tb, A.fwd, A.rev);
-  FindStageNone sg;
-  if (staged) find_body<false, true, true, true, 128, FindStageNone>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
-  else find_body<false, false, false, false, 128, FindStageNone>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
+  const u32 ntiles = (A.read_end - A.read_begin + 63u) / 64u;
+  for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    u64 rd_base = 0;
+    const bool staged = find_stage_reads_packed<128>(A, &rd_base, tile);
+    __syncthreads();
+    FindStageNone sg;
+    if (staged) find_body<false, true, true, true, 128, FindStageNone>(A, tb, sg, t2, find_dyn_lds, rd_base, stage, tile);
+    else find_body<false, false, false, false, 128, FindStageNone>(A, tb, sg, t2, find_dyn_lds, rd_base, stage, tile);
+    __syncthreads();  // the staged reads are overwritten by the next tile's
+  }
 }
 // the same with 64-bit positions (indexes of 2^32 symbols and more: BASELINE configs[4])
 __global__ __launch_bounds__(128) void k_find_c2w(FindArgs A) {
   __shared__ FmTables tb;
   __shared__ Find2TablesT<true> t2;
   __shared__ __attribute__((aligned(16))) uint4 stage[2 * COOP_WAVE_U4];
-  u64 rd_base = 0;
-  const bool staged = find_stage_reads_packed<128>(A, &rd_base);
   find2_tables_load<true>(t2, A.fwd, A.rev);
   fm_tables_load(tb, A.fwd, A.rev);
-  FindStageNone sg;
-  if (staged) find_body<true, true, true, true, 128, FindStageNone>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
-  else find_body<true, false, false, false, 128, FindStageNone>(A, tb, sg, t2, find_dyn_lds, rd_base, stage);
+  const u32 ntiles = (A.read_end - A.read_begin + 63u) / 64u;
+  for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    u64 rd_base = 0;
+    const bool staged = find_stage_reads_packed<128>(A, &rd_base, tile);
+    __syncthreads();
+    FindStageNone sg;
+    if (staged) find_body<true, true, true, true, 128, FindStageNone>(A, tb, sg, t2, find_dyn_lds, rd_base, stage, tile);
+    else find_body<true, false, false, false, 128, FindStageNone>(A, tb, sg, t2, find_dyn_lds, rd_base, stage, tile);
+    __syncthreads();
+  }
 }
 __global__ __launch_bounds__(256) void k_find_w(FindArgs A) {
   __shared__ FmTables tb;
@@ -3251,8 +3263,9 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
     b.stage_bytes = a.coop_stage_bytes;
     static const char* env_pad = getenv("SIGAX_FIND_COOP_PAD");  // measurement aid: unused LDS = fewer workgroups per CU
     const unsigned dyn = a.coop_stage_bytes + (env_pad ? (unsigned)atoi(env_pad) : 0u);
-    if (wide) hipLaunchKernelGGL(k_find_c2w, dim3(gc), dim3(128), dyn, st, b);
-    else hipLaunchKernelGGL(k_find_c2, dim3(gc), dim3(128), dyn, st, b);
+    const unsigned gp = a.coop_grid ? std::min(gc, a.coop_grid) : gc;
+    if (wide) hipLaunchKernelGGL(k_find_c2w, dim3(gp), dim3(128), dyn, st, b);
+    else hipLaunchKernelGGL(k_find_c2, dim3(gp), dim3(128), dyn, st, b);
     return;
   }
   if (wide) hipLaunchKernelGGL(k_find_w, dim3(g), dim3(bs), lds, st, b);
