@@ -2901,16 +2901,48 @@ struct CorrectSh {
   u32 cnt[CORRECT_LMAX];              // occurrences of the window's k-mer (saturated)
 };
 
-// Interval::occurrences of the k-mer starting at `s` in sh.seq, with base `ovpos` replaced by rank `ovrank`
+// Interval::occurrences of the k-mer starting at `s` in sh.seq, with base `ovpos` replaced by rank `ovrank`.
+// With the two-step table (t2 != NULL) two backward steps at a time come from the two positions of the first one
+// (fm_layout.h: Occ(e, C[c] + Occ(c, p)) = Occ(e, C[c]) + R2(e, c, p)): half the dependent lookups and half the lines.  A
+// pair containing a non-ACGT base, and the last step of an odd count, take the one-step form.  An interval that the first
+// step of a pair would have emptied comes out empty after the pair (R2 over no rows), so the reference's early exit
+// (fmindex.h:67-86) and this give the same count: 0.
 template <bool WIDE>
-__device__ __forceinline__ u32 kmer_occ(const FmRef& f, const FmTables& tb, const unsigned char* seq, u32 s, u32 k, u32 ovpos,
-                                        u32 ovrank, u32& nsec) {
+__device__ __forceinline__ u32 kmer_occ(const FmRef& f, const FmTables& tb, const Find2TablesT<WIDE>* t2, const uint32_t* gran2,
+                                        const u64* super2, const unsigned char* seq, u32 s, u32 k, u32 ovpos, u32 ovrank, u32& nsec) {
   typedef typename PosOf<WIDE>::type P;
   u32 j = k;
   u32 r = (s + j - 1 == ovpos) ? ovrank : base_rank(seq[s + j - 1]);
   P lo = (P)tb.C[f.which][r], hi = lo + (P)tb.T[f.which][r] - 1;  // Interval::init (src/fmindex.h:90-93)
-  while (--j > 0 && hi != (P)~(P)0 && hi >= lo) {
+  --j;  // j = steps left; the next symbol is seq[s + j - 1]
+  while (j > 0 && hi != (P)~(P)0 && hi >= lo) {
     r = (s + j - 1 == ovpos) ? ovrank : base_rank(seq[s + j - 1]);
+    if (t2 != nullptr && j >= 2 && r != 0) {
+      const u32 e = (s + j - 2 == ovpos) ? ovrank : base_rank(seq[s + j - 2]);
+      const u64 pl = (u64)lo > f.n ? f.n : (u64)lo, pu0 = (u64)hi + 1ull, pu = pu0 > f.n ? f.n : pu0;
+      if (e != 0) {
+        const uint4* ql = reinterpret_cast<const uint4*>(gran2 + (pl >> 6) * SIGAX_GRAN2_WORDS);
+        const uint4* qu = reinterpret_cast<const uint4*>(gran2 + (pu >> 6) * SIGAX_GRAN2_WORDS);
+        auto ld = [](const uint4& v) { v4u w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; return w; };
+        Gran2 ga, gb;
+        ga.s = ld(ql[0]); ga.pc = ld(ql[r]); ga.p5 = ld(ql[5]); ga.p6 = ld(ql[6]); ga.p7 = ld(ql[7]);
+        gb.s = ld(qu[0]); gb.pc = ld(qu[r]); gb.p5 = ld(qu[5]); gb.p6 = ld(qu[6]); gb.p7 = ld(qu[7]);
+        nsec += (pl >> 6) != (pu >> 6) ? 4u : 2u;
+        const Rank2 rl = rank2_from(ga, (u32)pl & 63u, r), ru = rank2_from(gb, (u32)pu & 63u, r);
+        P l2 = (P)(e == 1 ? rl.pa : e == 2 ? rl.pc : e == 3 ? rl.pg : rl.pt);
+        P u2 = (P)(e == 1 ? ru.pa : e == 2 ? ru.pc : e == 3 ? ru.pg : ru.pt);
+        if (WIDE) {
+          const u32 col = 4u + (r - 1u) * 4u + (e - 1u);
+          l2 += (P)super2[(pl >> SIGAX_SUPER_SHIFT) * 20 + col];
+          u2 += (P)super2[(pu >> SIGAX_SUPER_SHIFT) * 20 + col];
+        }
+        const P pb = (P)tb.C[f.which][e] + t2->Cc[f.which][r - 1][e - 1];
+        lo = pb + l2;
+        hi = pb + u2 - 1;
+        j -= 2;
+        continue;
+      }
+    }
     P l[5], u[5];
     fm_rank5p<WIDE>(f, lo, l);            // getOcc(c, lower - 1)
     fm_rank5p<WIDE>(f, (P)(hi + 1), u);   // getOcc(c, upper)
@@ -2920,6 +2952,7 @@ __device__ __forceinline__ u32 kmer_occ(const FmRef& f, const FmTables& tb, cons
     P pb = (P)tb.C[f.which][r];
     lo = pb + lr;
     hi = pb + ur - 1;
+    --j;
   }
   if (!(hi != (P)~(P)0 && hi >= lo)) return 0u;
   u64 c = (u64)(hi - lo) + 1ull;
@@ -2930,6 +2963,10 @@ template <bool WIDE>
 __global__ __launch_bounds__(256) void k_correct(CorrectArgs A) {
   __shared__ FmTables tb;
   __shared__ CorrectSh shm[4];
+  __shared__ Find2TablesT<WIDE> t2s;
+  const bool have2 = A.fwd.gran2 != nullptr && (!WIDE || A.fwd.super2 != nullptr);
+  if (have2) find2_tables_load<WIDE>(t2s, A.fwd, A.fwd);
+  const Find2TablesT<WIDE>* t2 = have2 ? &t2s : nullptr;
   fm_tables_load(tb, A.fwd, A.fwd);
   const u32 wid = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const u64 lt = (1ull << lane) - 1ull;
@@ -2971,7 +3008,7 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs A) {
           bool good = false;
           if (s < nw) {
             if (sh.redo[s]) {
-              sh.cnt[s] = kmer_occ<WIDE>(F, tb, sh.seq, s, k, 0xFFFFFFFFu, 0u, nsec);
+              sh.cnt[s] = kmer_occ<WIDE>(F, tb, t2, A.fwd.gran2, A.fwd.super2, sh.seq, s, k, 0xFFFFFFFFu, 0u, nsec);
               ++nlook;
               sh.redo[s] = 0;
             }
@@ -3023,7 +3060,7 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs A) {
                 const u32 kidx = side ? (pos < n - k ? pos : n - k) : (pos + 1 >= k ? pos + 1 - k : 0u);
                 const u32 thr = sh.score[pos] >= A.cutoff ? A.high : A.low;
                 const u32 minCount = A.offset > thr ? A.offset : thr;  // max(countVector[..] (always 0) + offset, threshold)
-                cand = kmer_occ<WIDE>(F, tb, sh.seq, kidx, k, pos, brank, nsec) >= minCount;
+                cand = kmer_occ<WIDE>(F, tb, t2, A.fwd.gran2, A.fwd.super2, sh.seq, kidx, k, pos, brank, nsec) >= minCount;
                 ++nlook;
               }
             }
