@@ -6,6 +6,8 @@ what=${1:-all}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof; mkdir -p $O
+# the row tables at open rather than beside the second run: every profiled launch is then a steady-state one
+export SIGAX_TABLES_SYNC=1
 B="python3 bench.py --cpu-sample 0 --steps 20 --warmup 3"
 P="python3 bench.py --cpu-sample 0 --steps 3 --warmup 1"
 ISO="--subbatches 1 --depth 1"
