@@ -1,5 +1,6 @@
 #!/bin/bash
-# GPU box: s_setprio in the per-lane finder (builds with -DSIGAX_FIND_PRIO=n under build/), pipelined step at C2
+# GPU box: s_setprio in the per-lane finder, pipelined step at C2.  Needs build/libsigax_prio{1,2}.so, built here first with
+#   python -c "from siga_amd import build as b; [b.build_libsigax(force=True, out='build/libsigax_prio%d.so' % p, defines=('SIGAX_FIND_PRIO=%d' % p,)) for p in (1, 2)]"
 mkdir -p gpurun_out/grid
 run() { name=$1; shift
   env "$@" timeout -k 10 200 python bench.py --cpu-sample 0 --steps 150 --warmup 5 > gpurun_out/grid/$name.json 2> gpurun_out/grid/$name.err || exit 1
