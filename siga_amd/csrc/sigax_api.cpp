@@ -1094,7 +1094,9 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
       xa.work = nullptr;
       xa.n_work = 0;
       xa.n_work_ptr = nullptr;
-      launch_filter_extract_fast(xa, ix->wide, fast_grid, std::min(fast_grid, 512u), b->qhint_lean_off == b->lean_off ? b->qhint : nullptr, ix->s_fx);
+      static const char* env_g64 = getenv("SIGAX_FX_GRID64");  // grid of the 64-lane launches (they size themselves down by their queues)
+      const unsigned grid64 = env_g64 ? (unsigned)std::max(1, atoi(env_g64)) : 512u;
+      launch_filter_extract_fast(xa, ix->wide, fast_grid, std::min(fast_grid, grid64), b->qhint_lean_off == b->lean_off ? b->qhint : nullptr, ix->s_fx);
       xa.work = (const uint32_t*)b->work.p + rb;  // the general kernel redoes what the fast one queued
       xa.n_work = 0;
       xa.n_work_ptr = dstat + DS_SLOW_BASE + i;
