@@ -136,7 +136,11 @@ def bench_overlap(args):
 
     # ---- synthetic reads (every rank draws the same set) and the index (rank 0 builds on its GPU, everyone loads) ----
     t0 = time.time()
-    reads, _ = fast_reads(G, L, n_total, args.seed)  # uint8 [n_total, L]
+    by_pos = os.environ.get("SIGA_BENCH_BY_POSITION") == "1"  # measurement aid: reads in genome order
+    reads, _ = fast_reads(G, L, n_total, args.seed, by_position=by_pos)  # uint8 [n_total, L]
+    if by_pos:
+        workdir += "_bypos"
+        prefix = os.path.join(workdir, "reads")
     if args.error_rate:
         from tests.golden.make_reads import substitute
         reads = substitute(reads, args.error_rate, args.seed + 100)

@@ -81,8 +81,9 @@ def dup_reads():
     return out
 
 
-def fast_reads(G, L, N, seed):
-    """numpy generator for BASELINE-sized sets -> (uint8 array [N, L] of ASCII, genome array)."""
+def fast_reads(G, L, N, seed, by_position=False):
+    """numpy generator for BASELINE-sized sets -> (uint8 array [N, L] of ASCII, genome array).  by_position: the same reads
+    in genome order instead of random order (a measurement aid: what locality between neighbouring reads would be worth)."""
     rng = np.random.default_rng(seed)
     genome = rng.integers(0, 4, size=G, dtype=np.uint8)
     npos = G - L + 1
@@ -94,6 +95,8 @@ def fast_reads(G, L, N, seed):
         keys = np.unique(np.concatenate([keys, rng.integers(0, 2 * npos, size=N, dtype=np.int64)]))
     rng.shuffle(keys)
     keys = keys[:N]
+    if by_position:
+        keys = np.sort(keys)
     pos = (keys >> 1).astype(np.int64)
     strand = (keys & 1).astype(bool)
     codes = np.lib.stride_tricks.sliding_window_view(genome, L)[pos]  # [N, L] copy
