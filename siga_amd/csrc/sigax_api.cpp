@@ -783,7 +783,7 @@ struct sigax_batch {
   uint32_t read_base, minov, flags;
   bool ran;
   // arenas
-  DevBuf arena, chain_cnt, pool, wpool, work, work64, work64b, work64c, occ_side, slow_flag, offs2, item_base, fin, fin_cnt, substring, block_offs, outb, edge_cnt,
+  DevBuf arena, chain_cnt, pool, wpool, work, work64, work64b, work64c, perm, ord_keys, ord_tmp, occ_side, slow_flag, offs2, item_base, fin, fin_cnt, substring, block_offs, outb, edge_cnt,
       edge_offs, edges, partial, dstat;
   uint32_t cap;
   uint32_t pool_cap;
@@ -793,6 +793,9 @@ struct sigax_batch {
   hipEvent_t ev[EV_COUNT];
   hipEvent_t sev[SIGAX_MAX_SUB][SV_COUNT];
   unsigned nsub;
+  bool perm_valid;    // `perm_cur` (one half of `perm`) holds the locality order of the reads now set, for perm_nsub sub-batches
+  const uint32_t* perm_cur;
+  unsigned perm_nsub;
   u64 qhint[3];       // items per sub-batch in the three filter/extract queues in the previous run (~0: none yet)
   bool qhint_lean_off;  // ... measured with lean_off in this state
   bool lean_off;      // see sigax_batch_finish
@@ -807,7 +810,7 @@ struct sigax_batch {
 extern "C" void sigax_batch_destroy(sigax_batch* b) {
   if (!b) return;
   hipSetDevice(b->ix->device);
-  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->work64c, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin,
+  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->work64c, &b->perm, &b->ord_keys, &b->ord_tmp, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin,
                    &b->fin_cnt, &b->substring, &b->block_offs, &b->outb, &b->edge_cnt, &b->edge_offs, &b->edges,
                    &b->partial, &b->dstat};
   for (DevBuf* d : all)
@@ -852,6 +855,9 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
   b->lean_off_runs = 0;
   b->qhint[0] = b->qhint[1] = b->qhint[2] = ~0ull;
   b->qhint_lean_off = false;
+  b->perm_valid = false;
+  b->perm_cur = nullptr;
+  b->perm_nsub = 0;
   b->nsub_req = 0;
   b->find_per_sub = 1;
   {
@@ -897,6 +903,7 @@ extern "C" int sigax_batch_upload(sigax_batch* b, const char* seqs, const uint64
   b->n_reads = n_reads;
   b->n_bases = nb;
   b->cur_max_len = mx;
+  b->perm_valid = false;
   b->ran = b->finished = false;
   return SIGAX_OK;
 }
@@ -909,6 +916,7 @@ extern "C" int sigax_batch_set_device_reads(sigax_batch* b, const void* d_seqs, 
   b->n_reads = n_reads;
   b->n_bases = n_bases;
   b->cur_max_len = max_len;
+  b->perm_valid = false;
   b->ran = b->finished = false;
   return SIGAX_OK;
 }
@@ -979,8 +987,6 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   HIP_TRY(hipMemsetAsync(dstat, 0, DS_COUNT * 8, st));
   HIP_TRY(hipMemsetAsync(b->occ_side.p, 0, (2 * (size_t)n + 2) * 4, st));
   HIP_TRY(hipMemsetAsync(b->slow_flag.p, 0, ((size_t)n + 1) * 4, st));
-  HIP_TRY(hipEventRecord(b->ev[EV_START], st));
-
   // Sub-batches: the finder is bound by the memory system's request rate, filter/extract by VALU issue; running
   // sub-batch i's filter/extract while sub-batch i+1's finder runs overlaps the two.
   static const char* env_sub = getenv("SIGAX_SUBBATCHES");
@@ -988,6 +994,37 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   if (nsub < 1) nsub = 1;
   if (nsub > SIGAX_MAX_SUB) nsub = SIGAX_MAX_SUB;
   b->nsub = nsub;
+  // Locality order of the reads for the per-lane finder (sigax_order_reads): once per set of reads and sub-batch count,
+  // on the caller's stream behind the upload (no host wait: the pipeline streams start behind EV_START); only where the
+  // workgroup's reads are staged in LDS by slot (the longest read decides) and the finder is not the cooperative one.
+  // SIGAX_READ_ORDER=0 turns it off.
+  const uint32_t* d_perm = nullptr;
+  const uint32_t perm_stride = (b->cur_max_len + 3u) & ~3u;
+  {
+    static const bool order_on = !(getenv("SIGAX_READ_ORDER") && getenv("SIGAX_READ_ORDER")[0] == '0');
+    static const char* env_coop0 = getenv("SIGAX_FIND_COOP");
+    static const char* env_cmin0 = getenv("SIGAX_COOP_MIN_SYMBOLS");
+    const u64 coop_min0 = env_cmin0 ? strtoull(env_cmin0, nullptr, 10) : (1ull << 31);
+    const bool coop_would = (ix->st[0].gran2 && ix->st[1].gran2) && (env_coop0 ? env_coop0[0] != '0' : (ix->wide || ix->n_symbols >= coop_min0));
+    if (order_on && !coop_would && n >= 2 && 128ull * perm_stride + 8 <= find_stage_capacity()) {
+      if (!b->perm_valid || b->perm_nsub != nsub) {
+        const size_t tb = sigax_order_reads_tmp_bytes(n);
+        if ((rc = ensure(&b->ord_keys, (size_t)n * 16)) != SIGAX_OK) return rc;
+        if ((rc = ensure(&b->perm, (size_t)n * 8)) != SIGAX_OK) return rc;
+        if ((rc = ensure(&b->ord_tmp, tb)) != SIGAX_OK) return rc;
+        uint32_t bounds[SIGAX_MAX_SUB + 1];
+        for (unsigned i = 0; i <= nsub; ++i) bounds[i] = (uint32_t)((u64)n * i / nsub);
+        rc = sigax_order_reads(b->d_seqs, b->d_offs, n, bounds, nsub, (u64*)b->ord_keys.p, (uint32_t*)b->perm.p, b->ord_tmp.p, tb,
+                               &b->perm_cur, st);
+        if (rc != SIGAX_OK) return rc;
+        b->perm_valid = true;
+        b->perm_nsub = nsub;
+      }
+      d_perm = b->perm_cur;
+    }
+  }
+  HIP_TRY(hipEventRecord(b->ev[EV_START], st));
+
   static const bool only_general = getenv("SIGAX_GENERAL_ONLY") != nullptr;  // debugging aid: skip the fast kernel
   HIP_TRY(hipStreamWaitEvent(ix->s_find, b->ev[EV_START], 0));
   HIP_TRY(hipStreamWaitEvent(ix->s_fx, b->ev[EV_START], 0));
@@ -1028,6 +1065,8 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.arena = b->arena.p;
     fa.chain_cnt = (uint32_t*)b->chain_cnt.p;
     fa.dstat = dstat;
+    fa.perm = fa.coop ? nullptr : d_perm;
+    fa.stage_stride = perm_stride;
     HIP_TRY(hipEventRecord(b->sev[i][SV_F0], ix->s_find));
     fa.chain_base = 0;
     fa.chains_per_wg = 4;

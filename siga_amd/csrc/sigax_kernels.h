@@ -47,6 +47,8 @@ struct FindArgs {
   uint32_t two_step;                 // both strands carry the two-step table (u32 positions only)
   uint32_t coop, coop_stage_bytes;   // cooperative two-step finder (k_find_c2): lines staged through LDS; bytes for 64 reads
   uint32_t coop_grid;                // ... its grid cap (persistent workgroups walk the tiles), 0 = one workgroup per tile
+  const uint32_t* perm;              // locality order of the batch: slot -> read (a permutation inside every sub-batch), or NULL
+  uint32_t stage_stride;             // with perm: bytes per read in the LDS copy (>= the longest read, a multiple of 4)
   uint32_t chain_base, chains_per_wg; // a workgroup walks chains [chain_base, chain_base + chains_per_wg) (4, or 2: one strand's
                                      // table per launch) of 256 / chains_per_wg reads; chains outside are another launch's
   void* arena;                       // [n_reads][4][cap] candidate records of cand_bytes(wide) each
@@ -164,5 +166,11 @@ unsigned long long cand_bytes(bool wide);
 void launch_pick_read_offsets(const unsigned long long* offs2, unsigned long long n_reads, unsigned long long* block_offs,
                               hipStream_t st);
 void launch_edges(const EdgeArgs& a, bool fill, unsigned long long max_blocks, hipStream_t st);
+// sigax_index_build.hip: locality order of a batch's reads (a permutation inside each of the nsub slot ranges bounds[0..nsub]),
+// queued on `st` without a host wait.  keys = 2 n u64, vals = 2 n u32 of scratch; *result = the half of vals that will hold
+// the order once the stream gets there.
+size_t sigax_order_reads_tmp_bytes(uint32_t n);
+int sigax_order_reads(const unsigned char* d_seqs, const unsigned long long* d_offs, uint32_t n, const uint32_t* bounds, uint32_t nsub,
+                      unsigned long long* keys, uint32_t* vals, void* tmp, size_t tmp_bytes, const uint32_t** result, hipStream_t st);
 
 #endif

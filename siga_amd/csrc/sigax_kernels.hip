@@ -672,12 +672,16 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
   const u32 tid = threadIdx.x;
   const u32 wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const u32 o = A.chain_base + (wv & (A.chains_per_wg - 1u));
-  const u32 read = A.read_begin + tile * ((u32)NT / A.chains_per_wg) + (wv / A.chains_per_wg) * 64u + (tid & 63u);
+  // the slot this lane works on, and the read in it: the batch's locality order (FindArgs::perm) or the slot itself
+  const u32 wslot = (wv / A.chains_per_wg) * 64u + (tid & 63u);
+  const u32 slot = A.read_begin + tile * ((u32)NT / A.chains_per_wg) + wslot;
+  const bool inr = slot < A.read_end;
+  const u32 read = (A.perm != nullptr && inr) ? A.perm[slot] : slot;
   typedef typename PosOf<WIDE>::type P;
   u32 nocc = 0;
   u32 nsec = 0;  // wave total (scalar): distinct 64-byte sectors of the rank tables asked for (a two-step line is two)
   u32 nb = 0, flagbits = 0;
-  bool live = read < A.read_end && ((A.chain_mask >> o) & 1u);  // overlap: 0xF, or 0x5 without the opposite strand; duplicate: 0x9
+  bool live = inr && ((A.chain_mask >> o) & 1u);  // overlap: 0xF, or 0x5 without the opposite strand; duplicate: 0x9
   u64 b0 = 0;
   u32 L = 0;
   if (live) {
@@ -697,7 +701,8 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
   const bool fromStart = (o == 1 || o == 2);  // reversed strings are consumed from the read's first base
   const u32 af = o == 0 ? SIGAX_AF_CHAIN0 : o == 1 ? SIGAX_AF_CHAIN1 : o == 2 ? SIGAX_AF_CHAIN2 : SIGAX_AF_CHAIN3;
   const unsigned char* sq = A.seqs + b0;
-  const u32 rdo = (u32)(b0 - rd_base);  // this read's first base in the staged copy
+  // this read's first base in the staged copy (gathered by slot when the batch has a locality order)
+  const u32 rdo = A.perm != nullptr ? wslot * A.stage_stride : (u32)(b0 - rd_base);
   // wave-uniform base of the wave's reads (lane 0's read always exists) + this lane's distance from it
   const u64 b0w = ((u64)__builtin_amdgcn_readfirstlane((u32)(b0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)b0);
   const unsigned char* sq0 = A.seqs + b0w;
@@ -923,7 +928,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
     }
   }
   find_flush(sg, contain, tid);
-  if (read < A.read_end) {
+  if (inr) {
     u32 word = (nb & SIGAX_CC_COUNT_MASK) | (flagbits & (SIGAX_CC_SUBSTRING | SIGAX_CC_CONTAIN));
     A.chain_cnt[(u64)read * 4 + o] = word;
   }
@@ -959,6 +964,32 @@ __device__ __forceinline__ bool find_stage_reads(const FindArgs& A, u64* rd_base
   return true;
 }
 
+// With a locality order the workgroup's reads are not one byte range: read j of the workgroup goes to dst + j * stride
+// (a multiple of 4), copied by thread j in (unaligned) 4-byte words -- one dependent chain of perm -> offset -> bases per
+// thread, all reads of the workgroup at once.
+template <int NT>
+__device__ __forceinline__ bool find_stage_reads_perm(const FindArgs& A, u32 tile) {
+  const u32 per = (u32)NT / A.chains_per_wg;
+  if ((u64)per * A.stage_stride > (u64)A.stage_bytes) return false;
+  const u32 r0 = A.read_begin + tile * per;
+  const u32 j = threadIdx.x;
+  if (j < per && r0 + j < A.read_end) {
+    const u32 r = A.perm[r0 + j];
+    const u64 b = A.offs[r];
+    const u32 len = (u32)(A.offs[r + 1] - b);
+    const unsigned char* src = A.seqs + b;
+    unsigned char* d = find_dyn_lds + j * A.stage_stride;
+    const u32 nw = len >> 2;
+    for (u32 k = 0; k < nw; ++k) {
+      u32 w;
+      __builtin_memcpy(&w, src + 4u * k, 4);
+      reinterpret_cast<u32*>(d)[k] = w;
+    }
+    for (u32 i = nw << 2; i < len; ++i) d[i] = src[i];
+  }
+  return true;
+}
+
 // The cooperative finder stages its reads as 4-bit ranks, two per byte (its residency hangs on its LDS, and the rank is
 // what a step needs anyway): byte i of the staged range = nibble i.
 template <int NT>
@@ -989,7 +1020,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   __shared__ FindStage sg;
   __shared__ Find2Tables t2;  // unused here
   u64 rd_base = 0;
-  const bool staged = find_stage_reads(A, &rd_base);
+  const bool staged = A.perm != nullptr ? find_stage_reads_perm<256>(A, blockIdx.x) : find_stage_reads(A, &rd_base);
   fm_tables_load(tb, A.fwd, A.rev);  // ends with the workgroup barrier that also publishes the staged reads
   if (staged) find_body<false, true, false>(A, tb, sg, t2, find_dyn_lds, rd_base);
   else find_body<false, false, false>(A, tb, sg, t2, find_dyn_lds, rd_base);
@@ -1000,7 +1031,7 @@ __global__ __launch_bounds__(256) void k_find_n2(FindArgs A) {
   __shared__ FindStage sg;
   __shared__ Find2Tables t2;
   u64 rd_base = 0;
-  const bool staged = find_stage_reads(A, &rd_base);
+  const bool staged = A.perm != nullptr ? find_stage_reads_perm<256>(A, blockIdx.x) : find_stage_reads(A, &rd_base);
   find2_tables_load(t2, A.fwd, A.rev);
   fm_tables_load(tb, A.fwd, A.rev);
 #ifdef SIGAX_FIND_PRIO
@@ -1053,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_find_w(FindArgs A) {
   __shared__ FindStage sg;
   __shared__ Find2TablesT<true> t2;  // unused here
   u64 rd_base = 0;
-  const bool staged = find_stage_reads(A, &rd_base);
+  const bool staged = A.perm != nullptr ? find_stage_reads_perm<256>(A, blockIdx.x) : find_stage_reads(A, &rd_base);
   fm_tables_load(tb, A.fwd, A.rev);
   if (staged) find_body<true, true, false>(A, tb, sg, t2, find_dyn_lds, rd_base);
   else find_body<true, false, false>(A, tb, sg, t2, find_dyn_lds, rd_base);
