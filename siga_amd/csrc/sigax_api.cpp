@@ -996,7 +996,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   b->nsub = nsub;
   // Locality order of the reads for the per-lane finder (sigax_order_reads): once per set of reads and sub-batch count,
   // on the caller's stream behind the upload (no host wait: the pipeline streams start behind EV_START); only where the
-  // workgroup's reads are staged in LDS by slot (the longest read decides) and the finder is not the cooperative one.
+  // workgroup's reads are staged in LDS by slot (the longest read decides).
   // SIGAX_READ_ORDER=0 turns it off.
   const uint32_t* d_perm = nullptr;
   const uint32_t perm_stride = (b->cur_max_len + 3u) & ~3u;
@@ -1005,8 +1005,9 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     static const char* env_coop0 = getenv("SIGAX_FIND_COOP");
     static const char* env_cmin0 = getenv("SIGAX_COOP_MIN_SYMBOLS");
     const u64 coop_min0 = env_cmin0 ? strtoull(env_cmin0, nullptr, 10) : (1ull << 31);
-    const bool coop_would = (ix->st[0].gran2 && ix->st[1].gran2) && (env_coop0 ? env_coop0[0] != '0' : (ix->wide || ix->n_symbols >= coop_min0));
-    if (order_on && !coop_would && n >= 2 && 128ull * perm_stride + 8 <= find_stage_capacity()) {
+    const bool coop_would = (ix->st[0].gran2 && ix->st[1].gran2) && (env_coop0 ? env_coop0[0] != '0' : (ix->wide || ix->n_symbols >= coop_min0)) &&
+                            32ull * perm_stride + 32 <= 32768;
+    if (order_on && n >= 2 && (coop_would || 128ull * perm_stride + 8 <= find_stage_capacity())) {
       if (!b->perm_valid || b->perm_nsub != nsub) {
         const size_t tb = sigax_order_reads_tmp_bytes(n);
         if ((rc = ensure(&b->ord_keys, (size_t)n * 16)) != SIGAX_OK) return rc;
@@ -1049,7 +1050,8 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
       // from 2^31 symbols the per-lane finder's 32-bit byte offsets no longer reach the table; below, it is the faster one
       // (1.2e9 symbols, one rank's view of an 8-GPU job: 80 M reads/s per lane vs 66 M cooperative, gpurun_out/emu/)
       const u64 coop_min = env_cmin ? strtoull(env_cmin, nullptr, 10) : (1ull << 31);
-      const u64 need = (64ull * b->cur_max_len + 16) / 2 + 16;  // the workgroup's 64 reads, staged as 4-bit ranks
+      // the workgroup's 64 reads, staged as 4-bit ranks: one byte range, or by slot under the locality order
+      const u64 need = d_perm ? 32ull * perm_stride + 32 : (64ull * b->cur_max_len + 16) / 2 + 16;
       const bool can = fa.two_step && need <= 32768;
       const bool want = env_coop ? env_coop[0] != '0' : (ix->wide || ix->n_symbols >= coop_min);
       fa.coop = (can && want) ? 1u : 0u;
@@ -1065,7 +1067,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.arena = b->arena.p;
     fa.chain_cnt = (uint32_t*)b->chain_cnt.p;
     fa.dstat = dstat;
-    fa.perm = fa.coop ? nullptr : d_perm;
+    fa.perm = (fa.coop || 128ull * perm_stride + 8 <= find_stage_capacity()) ? d_perm : nullptr;
     fa.stage_stride = perm_stride;
     HIP_TRY(hipEventRecord(b->sev[i][SV_F0], ix->s_find));
     fa.chain_base = 0;

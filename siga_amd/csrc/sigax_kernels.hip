@@ -1013,6 +1013,35 @@ __device__ __forceinline__ bool find_stage_reads_packed(const FindArgs& A, u64* 
   return true;
 }
 
+// ... and with a locality order, gathered by slot like find_stage_reads_perm: read j's ranks start at nibble j * stride
+template <int NT>
+__device__ __forceinline__ bool find_stage_reads_packed_perm(const FindArgs& A, u32 tile) {
+  const u32 per = (u32)NT / A.chains_per_wg;
+  if ((u64)per * A.stage_stride / 2u > (u64)A.stage_bytes) return false;
+  const u32 r0 = A.read_begin + tile * per;
+  const u32 j = threadIdx.x;
+  if (j < per && r0 + j < A.read_end) {
+    const u32 r = A.perm[r0 + j];
+    const u64 b = A.offs[r];
+    const u32 len = (u32)(A.offs[r + 1] - b);
+    const unsigned char* src = A.seqs + b;
+    unsigned char* d = find_dyn_lds + j * (A.stage_stride / 2u);
+    const u32 nw = len >> 2;
+    for (u32 k = 0; k < nw; ++k) {
+      u32 v;
+      __builtin_memcpy(&v, src + 4u * k, 4);
+      reinterpret_cast<unsigned short*>(d)[k] = (unsigned short)(base_rank(v & 0xFFu) | (base_rank((v >> 8) & 0xFFu) << 4) |
+                                                                 (base_rank((v >> 16) & 0xFFu) << 8) | (base_rank(v >> 24) << 12));
+    }
+    for (u32 i = nw << 2; i < len; ++i) {
+      const u32 rk = base_rank(src[i]);
+      const u32 old = (i & 1u) ? d[i >> 1] : 0u;
+      d[i >> 1] = (unsigned char)((i & 1u) ? ((old & 0x0Fu) | (rk << 4)) : rk);
+    }
+  }
+  return true;
+}
+
 // u32 positions: held to 64 registers, so that two finder workgroups and three filter/extract waves per SIMD fit the
 // 512-entry register file together (2 x 64 + 3 x 128)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_find_n(FindArgs A) {
@@ -1053,7 +1082,7 @@ __global__ __launch_bounds__(128) void k_find_c2(FindArgs A) {
   const u32 ntiles = (A.read_end - A.read_begin + 63u) / 64u;
   for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     u64 rd_base = 0;
-    const bool staged = find_stage_reads_packed<128>(A, &rd_base, tile);
+    const bool staged = A.perm != nullptr ? find_stage_reads_packed_perm<128>(A, tile) : find_stage_reads_packed<128>(A, &rd_base, tile);
     __syncthreads();
     FindStageNone sg;
     if (staged) find_body<false, true, true, true, 128, FindStageNone>(A, tb, sg, t2, find_dyn_lds, rd_base, stage, tile);
@@ -1071,7 +1100,7 @@ __global__ __launch_bounds__(128) void k_find_c2w(FindArgs A) {
   const u32 ntiles = (A.read_end - A.read_begin + 63u) / 64u;
   for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     u64 rd_base = 0;
-    const bool staged = find_stage_reads_packed<128>(A, &rd_base, tile);
+    const bool staged = A.perm != nullptr ? find_stage_reads_packed_perm<128>(A, tile) : find_stage_reads_packed<128>(A, &rd_base, tile);
     __syncthreads();
     FindStageNone sg;
     if (staged) find_body<true, true, true, true, 128, FindStageNone>(A, tb, sg, t2, find_dyn_lds, rd_base, stage, tile);
