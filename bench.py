@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- reads/s overlapped by the MI355X-native `siga overlap` path (BASELINE.json metric).
 
-A "step" is one pass of the whole hot path (block finder -> sub-maximal filter / irreducible extraction -> ordered
-compaction -> edge records) over this rank's shard of reads, inputs already resident in HBM, ending with the edge
-records in pinned host memory on rank 0 (for N > 1 after the RCCL gather to rank 0).  Workload at N = 1: BASELINE
-configs[1], synthetic 1M x 150 bp reads from a 5 Mb genome, min-overlap 45, irreducible, both strands.  For N > 1 the
-per-GPU share is kept (weak scaling): N x 1M reads from an N x 5 Mb genome, index replicated on every GPU, reads sharded.
+A "step" is one pass of the whole hot path (locality order of the batch -> block finder -> sub-maximal filter /
+irreducible extraction -> ordered compaction -> edge records) over this rank's shard of reads, inputs already resident
+in HBM, ending with the edge records in pinned host memory on rank 0 (for N > 1 after the RCCL gather to rank 0).  Every
+step hands the batch object its reads anew, so everything a product batch pays per upload -- the ordering included -- is
+inside the timed region.  Workload at N = 1: BASELINE configs[1], synthetic 1M x 150 bp reads from a 5 Mb genome, seed 1,
+min-overlap 45, irreducible, both strands.  N = 8: BASELINE configs[2] exactly, 20M x 150 bp reads from a 100 Mb genome,
+seed 2, 2.5M reads per rank, index replicated on every GPU; N = 2, 4 keep that per-GPU share (weak scaling: N x 2.5M
+reads from an N x 12.5 Mb genome, seed 2).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]         (N > 1: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -29,6 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CACHE_ROWS_GBS = 7650.0     # random rows of a 151 MB table: 7.4-7.9 TB/s (MI355X_MICROARCH.md, "uniformly random rows"); midpoint
+INFINITY_CACHE_BYTES = 256 << 20
 GATHER_CEILING_GLINES = 55.0  # dependency-free random line reads this chip sustains (profiles/r01_gather_probe*.txt): 55-57 G lines/s
 KERNELS = ["k_find", "k_filter_extract_fast", "k_filter_extract", "k_order", "k_edges"]
 
@@ -43,11 +48,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="overlap", choices=["overlap", "correct"])
-    ap.add_argument("--reads-per-gpu", type=int, default=1000000)
-    ap.add_argument("--genome-per-gpu", type=int, default=5000000)
+    ap.add_argument("--reads-per-gpu", type=int, default=None, help="default: 1 000 000 at N = 1 (configs[1]), 2 500 000 at N > 1 (configs[2]'s share)")
+    ap.add_argument("--genome-per-gpu", type=int, default=None, help="default: 5 000 000 at N = 1, 12 500 000 at N > 1")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--min-overlap", type=int, default=45)
-    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=None, help="default: 1 at N = 1 (configs[1]), 2 at N > 1 (configs[2])")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU restatement (0 = skip)")
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--subbatches", type=int, default=1,
@@ -62,13 +67,26 @@ def parse_args():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="measurement aid: build the index of an N-GPU job (N x reads, N x genome) but run only rank 0's shard "
                          "in this single process, to see what one GPU of that job achieves")
+    ap.add_argument("--max-local-reads", type=int, default=0,
+                    help="with --emulate-world: run only the first so many reads of rank 0's shard per step (a shard of BASELINE "
+                         "configs[4] is 6.25 M reads of 250 bp: more than three batch objects in flight hold beside its index)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow on fewer GPUs than ranks (edge records gathered via host)")
+    ap.add_argument("--reuse-order", action="store_true",
+                    help="A/B aid: set the reads once, so that the locality order is computed in the warm-up only (what round 2 timed)")
     ap.add_argument("--kmer", type=int, default=31, help="--workload correct: k-mer size (31 = code default, 41 = example script)")
     ap.add_argument("--error-rate", type=float, default=None,
                     help="substitutions per base: --workload correct default 0.01; --workload overlap default 0 (the BASELINE configs are "
                          "error-free), > 0 shows what uncorrected reads cost (branches in the extraction)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    multi = args.gpus > 1 or args.emulate_world > 1
+    if args.reads_per_gpu is None:
+        args.reads_per_gpu = 2500000 if multi and args.workload == "overlap" else 1000000
+    if args.genome_per_gpu is None:
+        args.genome_per_gpu = 12500000 if multi and args.workload == "overlap" else 5000000
+    if args.seed is None:
+        args.seed = 2 if multi and args.workload == "overlap" else 1
+    return args
 
 
 def self_launch(args):
@@ -134,36 +152,47 @@ def bench_overlap(args):
     workdir = args.workdir or os.path.join(tempfile.gettempdir(), "siga_bench_%d_%d_%d_%d" % (n_total, G, L, args.seed))
     prefix = os.path.join(workdir, "reads")
 
-    # ---- synthetic reads (every rank draws the same set) and the index (rank 0 builds on its GPU, everyone loads) ----
+    # ---- synthetic reads (every rank draws from the same set: its own shard, and rank 0 all of them when the index has to
+    # be built) and the index (rank 0 builds on its GPU, everyone loads) ----
     t0 = time.time()
     by_pos = os.environ.get("SIGA_BENCH_BY_POSITION") == "1"  # measurement aid: reads in genome order
-    reads, _ = fast_reads(G, L, n_total, args.seed, by_position=by_pos)  # uint8 [n_total, L]
     if by_pos:
         workdir += "_bypos"
-        prefix = os.path.join(workdir, "reads")
     if args.error_rate:
-        from tests.golden.make_reads import substitute
-        reads = substitute(reads, args.error_rate, args.seed + 100)
         workdir += "_e%g" % args.error_rate
-        prefix = os.path.join(workdir, "reads")
+    prefix = os.path.join(workdir, "reads")
+    lo, hi = shard_range(n_total, rank, job_world)
+    if args.max_local_reads:
+        hi = min(hi, lo + args.max_local_reads)
+    have_index = all(os.path.exists(prefix + e) for e in (".bwt", ".rbwt", ".sai", ".rsai"))
+    whole = (rank == 0 and not have_index) or bool(args.error_rate) or (args.cpu_sample > 0 and world == 1)
+
+    def draw(subset):
+        r, _ = fast_reads(G, L, n_total, args.seed, by_position=by_pos, subset=subset)  # uint8 [., L]
+        if args.error_rate:
+            from tests.golden.make_reads import substitute
+            r = substitute(r, args.error_rate, args.seed + 100)
+        return r
+
+    reads = draw(None) if whole else None
     if rank == 0:
         sbuild.build_all()
         os.makedirs(workdir, exist_ok=True)
-        if not all(os.path.exists(prefix + e) for e in (".bwt", ".rbwt", ".sai", ".rsai")):
+        if not have_index:
             offs_all = np.arange(0, (n_total + 1) * L, L, dtype=np.uint64)
             host.index_build_gpu(reads.reshape(-1), offs_all, prefix, device=dev_index)
         log("reads + index ready in %.1f s (%d reads, %d symbols per strand)" % (time.time() - t0, n_total, n_total * (L + 1)))
     if world > 1:
         dist.barrier()
+    shard = reads[lo:hi] if whole else draw((lo, hi))
     pair = FMIndexPair.load(prefix, device=dev_index)
     info = pair.info()
     # ReadInfo{name,length}: names r<i>; rank of a name under std::string operator<
     pair.set_reads(np.full(n_total, L, dtype=np.uint32), rank_of_r_names(n_total))
     log("index on GPU: %.1f MB, wide=%d (%.1f s since start)" % (info["device_bytes"] / 1e6, info["wide"], time.time() - t0))
 
-    lo, hi = shard_range(n_total, rank, job_world)
     n_local = hi - lo
-    d_seqs = torch.from_numpy(reads[lo:hi].reshape(-1).copy()).to(dev)
+    d_seqs = torch.from_numpy(np.ascontiguousarray(shard).reshape(-1)).to(dev)
     d_offs = torch.arange(0, (n_local + 1) * L, L, dtype=torch.int64, device=dev)
     lib = _lib.lib()
     flags = _lib.SIGAX_IRREDUCIBLE | _lib.SIGAX_RC | _lib.SIGAX_EDGES
@@ -190,6 +219,8 @@ def bench_overlap(args):
             self.__cuda_array_interface__ = {"shape": (n, 4), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
     stats = _lib.Stats()
+    rinfo = _lib.RunInfo()
+    order_ms = [0.0]
     kms = (C.c_float * 5)()
     nsub = C.c_uint32(1)
     ksum = np.zeros(5)
@@ -231,6 +262,8 @@ def bench_overlap(args):
             raise SystemExit("overlap step failed: " + _lib.last_error())
         lib.sigax_batch_kernel_ms(batches[i], C.byref(kms), C.byref(nsub))  # HIP events on the streams the kernels run on
         ksum[:] += np.array(list(kms))
+        lib.sigax_batch_run_info(batches[i], C.byref(rinfo))
+        order_ms[0] += rinfo.order_ms
         last_edges[0] = int(stats.n_edges)
         d_edges = C.c_void_p()
         lib.sigax_batch_device_outputs(batches[i], None, None, None, C.byref(d_edges))
@@ -255,6 +288,10 @@ def bench_overlap(args):
     def submit(k):
         i = k % depth
         complete(i)  # the batch's previous run must be done before its workspace is reused
+        if not args.reuse_order:
+            # a new set of reads as far as the library knows: the step pays for its own locality order, like a product batch
+            rc = lib.sigax_batch_set_device_reads(batches[i], d_seqs.data_ptr(), d_offs.data_ptr(), n_local, n_local * L, L)
+            assert rc == 0, _lib.last_error()
         rc = lib.sigax_batch_run(batches[i], lo, args.min_overlap, flags, C.c_void_p(streams[i].cuda_stream))
         if rc != 0:
             raise SystemExit("overlap step failed: " + _lib.last_error())
@@ -272,6 +309,7 @@ def bench_overlap(args):
     run_steps(args.warmup, depth)
     drain()
     ksum[:] = 0
+    order_ms[0] = 0.0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -289,12 +327,12 @@ def bench_overlap(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kavg = ksum / max(args.steps, 1)  # per step, summed over the step's sub-batch launches
+    order_avg = order_ms[0] / max(args.steps, 1)
     st = stats.as_dict()
     launches = int(nsub.value)
-    # finder launches per sub-batch: two (one per strand's table) with the two-step tables and for big one-step indexes
-    two_step_on = (info["n_symbols"] < (1 << 30) + (1 << 29)) and not info["wide"] and os.environ.get("SIGAX_TWO_STEP", "1") != "0"
-    split = (two_step_on or info["n_symbols"] >= (1 << 30)) and 128 * L + 8 <= 41568
-    nsub_step = max(1, launches // (2 if split else 1))
+    # how the library ran the finder (sigax_batch_run_info): launches per sub-batch, two-step lines or granules, cooperative
+    ri = rinfo.as_dict()
+    nsub_step = max(1, ri["n_sub"])
 
     # the same kernels with sub-batching off (no overlap between find and filter/extract): untimed extra steps
     iso = None
@@ -309,9 +347,10 @@ def bench_overlap(args):
 
     out = None
     if rank == 0:
-        reads_per_s = (n_total if job_world == world else n_local) * args.steps / elapsed
+        done_per_step = n_total if (job_world == world and not args.max_local_reads) else n_local * world
+        reads_per_s = done_per_step * args.steps / elapsed
         step_s = elapsed / args.steps
-        two_step = 1 if (info["n_symbols"] < (1 << 30) + (1 << 29) and not info["wide"] and os.environ.get("SIGAX_TWO_STEP", "1") != "0") else 0
+        two_step = ri["two_step"]
         cand_rec = 64 if info["wide"] else 32
         # Algorithmic bytes of THIS formulation: the distinct 64-byte sectors of the rank tables each step /
         # round asks for, counted by the kernels themselves (a 128-byte line of the two-step table = 2 sectors), plus
@@ -333,29 +372,51 @@ def bench_overlap(args):
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = "%d/%d/%d/%d" % (args.reads_per_gpu, args.genome_per_gpu, L, launches)
+                key = "%d/%d/%d/%d" % (n_local, G, L, launches)
                 traffic = tj.get("k_find/" + key, {}).get("hbm_bytes_per_launch")
                 fx_traffic = tj.get("k_filter_extract_fast/" + key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = fx_traffic = None
+        # What bounds the finder's gathers: the table one launch gathers from (one strand's two-step lines, or both strands'
+        # granules) either stays in the 256 MiB Infinity Cache -- then the PMC "traffic" is L2-miss traffic and the ceiling
+        # is what random rows of a cache-resident table read at -- or it does not, and the ceiling is HBM.
+        per_strand = (info["n_symbols"] // 64 + 1) * 128 if two_step else (info["n_symbols"] // 128 + 1) * 64
+        table_bytes = per_strand * (1 if ri["find_per_sub"] == 2 else 2)
+        cache_resident = table_bytes <= INFINITY_CACHE_BYTES * 5 // 4
+        bound = "l2-miss (Infinity-Cache-resident table)" if cache_resident else "hbm"
+        peak = CACHE_ROWS_GBS if cache_resident else HBM_PEAK_GBS
+        if job_world == 8 and args.reads_per_gpu == 2500000 and args.genome_per_gpu == 12500000 and L == 150 and args.seed == 2:
+            named = "BASELINE configs[2]: "
+        elif job_world == 1 and n_total == 1000000 and G == 5000000 and L == 150 and args.seed == 1:
+            named = "BASELINE configs[1]: "
+        else:
+            named = ""
         out = {
             "metric": "reads/sec overlapped (ASQG bit-exact)", "value": reads_per_s, "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "synthetic %dx%d bp reads from %d bp genome, min-overlap %d, irreducible, both strands; "
-                                   "FM-index (both strands) resident in HBM, reads sharded over %d GPU(s), edge records to "
-                                   "pinned host memory on rank 0 inside the timed region" % (
-                                       n_total, L, G, args.min_overlap, world),
+            "config": {"workload": named + "synthetic %dx%d bp reads from %d bp genome, seed %d, min-overlap %d, irreducible, both strands; "
+                                   "FM-index (both strands) resident in HBM, reads sharded over %d GPU(s)%s, locality order of "
+                                   "the batch and edge records to pinned host memory on rank 0 inside the timed region" % (
+                                       n_total, L, G, args.seed, args.min_overlap, job_world,
+                                       " (this process: rank 0's shard only)" if job_world != world else ""),
                        "reads_per_gpu": n_local, "edges": total_edges, "blocks_per_read": st["n_blocks"] / max(n_local, 1),
                        "n_occ_min_per_read": (st["n_occ_find"] + st["n_occ_extract"]) / max(n_local, 1),
                        "sectors_per_read": {"find": sec_f / max(n_local, 1), "extract": sec_x / max(n_local, 1)},
                        "algorithmic_bytes_per_read": bytes_step / max(n_local, 1),
                        "reference_formulation_bytes_per_read": (64 * (st["n_occ_find"] + st["n_occ_extract"]) + n_local * L + 64 * st["n_blocks"]) / max(n_local, 1),
-                       "slow_path_reads": st["n_slow_reads"], "batches_in_flight": depth, "two_step_table": two_step},
-            "kernel_ms_per_step": {k: float(v) for k, v in zip(KERNELS, kavg)},
+                       "slow_path_reads": st["n_slow_reads"], "batches_in_flight": depth, "two_step_table": two_step,
+                       "finder": ("cooperative (lines through LDS)" if ri["coop"] else "per lane") + (", locality order" if ri["read_order"] else ""),
+                       "order_in_timed_region": not args.reuse_order,
+                       "candidate_slots_per_chain": ri["cap"], "worst_case_slots_per_chain": ri["worst_cap"],
+                       "candidate_arena_bytes": ri["arena_bytes"], "batch_workspace_bytes": ri["workspace_bytes"], "reruns": ri["reruns"],
+                       "row_table": {"bits_per_row": ri["row_bits"], "symbols_per_entry": ri["row_syms"], "text": bool(ri["row_text"])},
+                       "index_device_bytes": info["device_bytes"]},
+            "kernel_ms_per_step": dict({k: float(v) for k, v in zip(KERNELS, kavg)}, order_reads=order_avg),
             "launches_per_step": launches,
-            "roofline": {"bound": "hbm", "kernel": "k_find", "achieved": ach_find, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_find / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"bound": bound, "kernel": "k_find", "achieved": ach_find, "peak": peak, "unit": "GB/s",
+                         "frac": ach_find / peak, "traffic": traffic, "frac_of_hbm_spec_peak": ach_find / HBM_PEAK_GBS,
+                         "table_bytes_per_launch": table_bytes,
                          "algorithmic_bytes_per_launch": bytes_find / launches, "avg_launch_ms": find_ms,
                          "request_rate": {"achieved": glines, "ceiling": GATHER_CEILING_GLINES, "unit": "G lines/s",
                                           "frac": glines / GATHER_CEILING_GLINES,

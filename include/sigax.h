@@ -195,6 +195,26 @@ int  sigax_batch_size_hint(sigax_index*, uint32_t max_read_len, uint32_t min_ove
  * two when the finder runs once per strand's two-step table); the other kernels run once per sub-batch. */
 int  sigax_batch_kernel_ms(sigax_batch*, float ms[5], uint32_t* n_sub);
 
+/* How the last finished run of a batch object was carried out: what a caller needs to turn sigax_stats and
+ * sigax_batch_kernel_ms into requests and bytes per launch without re-deriving the library's choices. */
+typedef struct sigax_run_info {
+  uint32_t n_sub;         /* sub-batches of the run */
+  uint32_t find_per_sub;  /* finder launches per sub-batch (2: one per strand's table) */
+  uint32_t two_step;      /* the finder gathered 128-byte two-step lines (two backward steps each); 0: 64-byte granules */
+  uint32_t coop;          /* ... cooperatively through LDS (indexes of 2^31 symbols and more) */
+  uint32_t read_order;    /* the finder walked the batch in its locality order */
+  uint32_t cap;           /* candidate slots per chain of the run */
+  uint32_t worst_cap;     /* ... had they been sized for the worst case (one per overlap length + 1) */
+  uint32_t row_bits;      /* bits per entry of the index's row tables, 0 = none */
+  uint32_t row_syms;      /* symbols an entry carries */
+  uint32_t row_text;      /* the stretch text exists (extension rounds are read off it) */
+  uint64_t arena_bytes;   /* candidate arena of this batch object */
+  uint64_t workspace_bytes; /* all device buffers of this batch object */
+  uint64_t reruns;        /* runs of this batch object repeated so far because an arena was too small */
+  float    order_ms;      /* device time of the locality ordering inside this run (0: the order of an earlier run was reused) */
+} sigax_run_info;
+int  sigax_batch_run_info(sigax_batch*, sigax_run_info* out);
+
 #ifdef __cplusplus
 }
 #endif

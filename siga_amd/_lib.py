@@ -39,13 +39,22 @@ class IndexInfo(C.Structure):
                 ("pred", C.c_uint64 * 5), ("device", C.c_int), ("wide", C.c_int)]
 
 
+class RunInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("n_sub", "find_per_sub", "two_step", "coop", "read_order", "cap", "worst_cap", "row_bits",
+                                          "row_syms", "row_text")] + \
+               [("arena_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64), ("reruns", C.c_uint64), ("order_ms", C.c_float)]
+
+    def as_dict(self):
+        return {n: (float(getattr(self, n)) if n == "order_ms" else int(getattr(self, n))) for n, _ in self._fields_}
+
+
 # every symbol include/sigax.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "sigax_last_error", "sigax_device_count", "sigax_stream_create", "sigax_stream_destroy", "sigax_index_open", "sigax_index_open_mem", "sigax_index_clone", "sigax_index_close",
     "sigax_index_info_get", "sigax_index_set_reads", "sigax_occ_batch", "sigax_kmer_count_batch",
     "sigax_correct_batch", "sigax_correct_device", "sigax_overlap_batch", "sigax_result_free", "sigax_batch_create", "sigax_batch_destroy", "sigax_batch_upload",
     "sigax_batch_set_device_reads", "sigax_batch_set_subbatches", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
-    "sigax_batch_download", "sigax_batch_download_edges", "sigax_batch_size_hint", "sigax_batch_kernel_ms", "sigax_build_strand", "sigax_free",
+    "sigax_batch_download", "sigax_batch_download_edges", "sigax_batch_size_hint", "sigax_batch_kernel_ms", "sigax_batch_run_info", "sigax_build_strand", "sigax_free",
 ]
 
 _lib = None
@@ -95,6 +104,7 @@ def lib():
     L.sigax_batch_size_hint.argtypes = [vp, u32, u32, u32, u32, C.POINTER(u32)]
     L.sigax_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_float * 5), C.POINTER(C.c_uint32)]
     L.sigax_batch_set_subbatches.argtypes = [vp, u32]
+    L.sigax_batch_run_info.argtypes = [vp, C.POINTER(RunInfo)]
     L.sigax_build_strand.argtypes = [vp, vp, u64, ci, ci, pvp, C.POINTER(u64), pvp, C.POINTER(u64)]
     L.sigax_free.argtypes = [vp]
     L.sigax_free.restype = None

@@ -50,26 +50,31 @@
 /* 64-bit-position indexes: the 20 counters of a two-step line are relative to the line's superblock of 2^SIGAX_SUPER_SHIFT
  * rows; super2[sb][20] holds the absolute values at the superblock's first row (same order as the line's words 0..19). */
 
-/* Row-end table (built on the device at open time, one u64 per BWT row, optional): for the suffix at row p, how many
- * backward steps lead to the first symbol of its read (high word: t = its offset in the read, BWT[row] = '$' after t steps)
- * and Occ('$') at that row (low word) -- what a single-row block's right extension to the end of its read arrives at
- * (IrreducibleBlockListExtractor::extract, src/overlap_builder.cpp:747-766), without walking there. */
-
-/* Look-ahead table (same walk, optional, indexes below 2^34 symbols): one u64 per BWT row p = the next ten symbols on the
- * backward path from p -- BWT[p], BWT[LF(p)], ... 3 bits each, lowest first, rank 0 from the read's first base on -- and, in
- * the upper 34 bits, the row ten steps on.  A single-row block's right extension IS this path (IntervalPair::updateR with the
- * one symbol at its row = LF), so ten extension rounds of the irreducible extractor cost one 8-byte lookup and no rank
- * arithmetic. */
-#define SIGAX_LA_SYMS 10
-#define SIGAX_LA_ROW_SHIFT 30
-#define SIGAX_LA_SYM_MASK 0x3FFFFFFFu
+/* Row table (built on the device, optional): the suffix array of the index in the form the irreducible extractor needs it,
+ * bit-packed.  For BWT row p, whose suffix starts at offset t of its stretch (a read, or the piece of a read between two
+ * symbols of rank 0: terminators and non-ACGT bases, src/alphabet.h:19-39), the entry is (t << ld_bits) | ld with
+ * ld = Occ('$') at the row reached after t backward steps -- the row whose BWT symbol has rank 0, i.e. the index of the
+ * stretch among all stretches in suffix order (what the .sai table is indexed by).  ld_bits + t_bits (= bits of the longest
+ * stretch) per row: BASELINE configs[1] 28 bits, [2] 33, [4] 34 (the round-2 layout spent 128 bits per row on the same
+ * information and could not hold configs[4]).  When memory allows, an entry also carries the first K symbols on the backward
+ * path from its row, 2 bits each (rank - 1: inside a stretch only A, C, G, T occur, and t says where it ends), above those
+ * bits, first symbol highest, as many as keep the entry within 57 bits (at most 14): sa_bits = ld_bits + t_bits + 2 K --
+ * 56 bits with 14 symbols at configs[1], 57 with 12 at configs[2].  Entry p sits at bit p * sa_bits: one unaligned 8-byte
+ * load.
+ *
+ * Stretch text (same walk): for stretch ld its symbols as rank - 1, offset k at bits 2 k, 2 k + 1 of the row
+ * text + ld * text_stride.  A single-row block's right extension IS the backward path from its row (IntervalPair::updateR
+ * with the one symbol at its row = LF; capped[0] never moves): the symbols at offsets t-1, t-2, ..., 0 and then rank 0, and
+ * the block is emitted with Occ('$') = ld when its read ends (src/overlap_builder.cpp:747-766).  So the rounds of the
+ * extractor are one row-table lookup, one text load per 28 rounds (whose address depends on nothing but registers) and
+ * no rank arithmetic. */
+#define SIGAX_TEXT_WINDOW 28  /* symbols per text load that every lane can count on (an unaligned 8-byte load holds 57 to 64 bits of them) */
 
 struct FmStrand {
   const uint32_t* granules;  /* n_granules x 16 u32 */
-  const unsigned long long* rowend;  /* row p at rowend[p * re_stride]: (t << 32 | dollar rank); or NULL */
-  const unsigned long long* la;      /* look-ahead entries, interleaved with the row-end ones: row p = { la[2 p], la[2 p + 1] =
-                                        its row-end entry } (then rowend = la + 1, re_stride = 2); or NULL (re_stride = 1) */
-  unsigned int re_stride;
+  const unsigned char* sa;    /* row table: n entries of sa_bits bits (+ 8 bytes of padding), or NULL */
+  const unsigned char* text;  /* stretch text: C['A'] rows of text_stride bytes, or NULL (then only countdowns use `sa`) */
+  unsigned int sa_bits, ld_bits, t_bits, text_stride;  /* symbols per entry = (sa_bits - ld_bits - t_bits) / 2 */
   const uint32_t* gran2;     /* (n / 64 + 1) x 32 u32, or NULL */
   const unsigned long long* super2;  /* [n_super][20], wide mode with two-step tables; else NULL */
   const unsigned long long* super;    /* [n_super][4] absolute A,C,G,T counts at each superblock start (wide mode) */

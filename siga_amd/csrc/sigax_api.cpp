@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <mutex>
 #include <string>
@@ -86,8 +88,9 @@ struct sigax_index {
   void* d_gran[2];
   void* d_gran2[2];  // two-step tables (fm_layout.h) or NULL
   void* d_super2[2]; // ... their superblock bases (64-bit positions) or NULL
-  void* d_rowend[2]; // row-end tables (fm_layout.h) or NULL
-  void* d_la[2];     // look-ahead tables (fm_layout.h) or NULL
+  void* d_sa[2];     // row tables (fm_layout.h) or NULL
+  void* d_text[2];   // stretch texts (fm_layout.h) or NULL
+  u64 sa_alloc[2], text_alloc[2];  // bytes allocated for them
   // The row tables of an index of 2^26 symbols and more are built by a side thread while the caller goes on (at BASELINE
   // configs[1] 0.1 s: more than the whole one-batch `siga overlap` spends on the GPU); runs enqueued before they are ready
   // use the forms without them -- same bytes out.  0 none / published, 1 being built, 2 built: tab_st waits for publishing.
@@ -97,7 +100,9 @@ struct sigax_index {
   std::atomic<int>* tab_state;
   FmStrand tab_st[2];
   u64 tab_bytes, tab_plan, n_runs;
-  bool tab_la;
+  bool tab_text;
+  u32 tab_syms;      // symbols a row-table entry carries (plan)
+  u32 max_read_len;  // longest read of sigax_index_set_reads (0: not told yet), an upper bound of the longest stretch
   void* d_super[2];
   uint32_t* d_sai[2];
   u64 n_sai;
@@ -111,6 +116,11 @@ struct sigax_index {
   hipStream_t s_find, s_fx, s_tail;
   std::mutex* enqueue_mu;
   int n_cu;  // compute units of the device
+  // The longest chain of candidate blocks any run on this index has produced so far.  The candidate arena gives every chain
+  // that many slots plus headroom instead of the worst case (one per overlap length): BASELINE configs[1] 11 records per
+  // chain on average, 30-odd at most, 106 in the worst case.  A run whose chains outgrow their slots is repeated with what
+  // it reported (sigax_batch_finish).
+  std::atomic<uint32_t>* cap_seen;
   bool split_strands;  // two-step tables too large to gather from both at once: one finder launch per strand
 };
 
@@ -188,32 +198,68 @@ static int parse_sai(const std::vector<uint8_t>& buf, const char* path, std::vec
   return SIGAX_OK;
 }
 
-// Binary image of a parsed .sai beside the text file (<path>.bin: magic, size and mtime of the text, count, ids): parsing
-// 5e7 decimal lines takes seconds, reading 200 MB does not.  Stale or unreadable images are ignored and rewritten.
-static bool sai_cache_load(const char* path, std::vector<uint32_t>* out) {
+// Binary image of a parsed .sai beside the text file (<path>.bin: magic, size and mtime (ns) of the text, a checksum of its
+// first and last 64 KiB, count, ids): parsing 5e7 decimal lines takes seconds, reading 200 MB does not.  A .sai is a
+// permutation of 0..n-1, so every read set of n reads gives a text of the same size: the checksum is what tells a re-indexed
+// prefix from the one the image was made of.  Stale or unreadable images are ignored and rewritten.
+static const u64 SAI_IMAGE_MAGIC = 0x5349474153414932ull;  // "SIGASAI2"
+static bool sai_text_stamp(const char* path, u64 stamp[3]) {
   struct stat st;
   if (stat(path, &st) != 0) return false;
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  u64 h = 1469598103934665603ull;  // FNV-1a over the head and the tail
+  std::vector<unsigned char> buf(65536);
+  auto eat = [&](size_t n) {
+    for (size_t i = 0; i < n; ++i) h = (h ^ buf[i]) * 1099511628211ull;
+  };
+  eat(fread(buf.data(), 1, buf.size(), f));
+  if ((u64)st.st_size > buf.size() && fseek(f, -(long)std::min<u64>(buf.size(), (u64)st.st_size - buf.size()), SEEK_END) == 0)
+    eat(fread(buf.data(), 1, buf.size(), f));
+  fclose(f);
+  stamp[0] = (u64)st.st_size;
+  stamp[1] = (u64)st.st_mtim.tv_sec * 1000000000ull + (u64)st.st_mtim.tv_nsec;
+  stamp[2] = h;
+  return true;
+}
+static bool sai_cache_load(const char* path, std::vector<uint32_t>* out) {
+  u64 stamp[3];
+  if (!sai_text_stamp(path, stamp)) return false;
   std::string cp = std::string(path) + ".bin";
   FILE* f = fopen(cp.c_str(), "rb");
   if (!f) return false;
-  u64 hdr[4];
-  bool ok = fread(hdr, 8, 4, f) == 4 && hdr[0] == 0x5349474153414931ull && hdr[1] == (u64)st.st_size && hdr[2] == (u64)st.st_mtime;
+  struct stat ist;
+  u64 hdr[5];
+  bool ok = fstat(fileno(f), &ist) == 0 && fread(hdr, 8, 5, f) == 5 && hdr[0] == SAI_IMAGE_MAGIC && hdr[1] == stamp[0] && hdr[2] == stamp[1] &&
+            hdr[3] == stamp[2];
+  // the count must be what the image file holds (a corrupt header must not size a vector) and a text of that size can hold
+  // (every line is at least "0 0\n")
+  ok = ok && hdr[4] <= 0xFFFFFFFFull && (u64)ist.st_size == 40 + 4 * hdr[4] && 4 * hdr[4] <= stamp[0];
   if (ok) {
-    out->resize(hdr[3]);
-    ok = hdr[3] == 0 || fread(out->data(), 4, hdr[3], f) == hdr[3];
+    try {
+      out->resize(hdr[4]);
+      ok = hdr[4] == 0 || fread(out->data(), 4, hdr[4], f) == hdr[4];
+    } catch (...) {
+      ok = false;
+    }
   }
   fclose(f);
+  if (!ok) out->clear();
   return ok;
 }
 static void sai_cache_store(const char* path, const std::vector<uint32_t>& ids) {
   if (getenv("SIGAX_NO_SAI_CACHE")) return;
-  struct stat st;
-  if (stat(path, &st) != 0) return;
-  std::string cp = std::string(path) + ".bin", tmp = cp + ".tmp";
-  FILE* f = fopen(tmp.c_str(), "wb");
-  if (!f) return;  // read-only directory: no cache
-  u64 hdr[4] = {0x5349474153414931ull, (u64)st.st_size, (u64)st.st_mtime, (u64)ids.size()};
-  bool ok = fwrite(hdr, 8, 4, f) == 4 && (ids.empty() || fwrite(ids.data(), 4, ids.size(), f) == ids.size());
+  u64 stamp[3];
+  if (!sai_text_stamp(path, stamp)) return;
+  // a temporary name of this process and thread: ranks of one job, or two runs on one prefix, write their own file and the
+  // rename puts a complete one in place
+  char uniq[64];
+  snprintf(uniq, sizeof(uniq), ".tmp.%ld.%zx", (long)getpid(), std::hash<std::thread::id>()(std::this_thread::get_id()));
+  std::string cp = std::string(path) + ".bin", tmp = cp + uniq;
+  FILE* f = fopen(tmp.c_str(), "wbx");
+  if (!f) return;  // read-only directory (or a leftover of this very name): no cache
+  u64 hdr[5] = {SAI_IMAGE_MAGIC, stamp[0], stamp[1], stamp[2], (u64)ids.size()};
+  bool ok = fwrite(hdr, 8, 5, f) == 5 && (ids.empty() || fwrite(ids.data(), 4, ids.size(), f) == ids.size());
   ok = fclose(f) == 0 && ok;
   if (ok) ok = rename(tmp.c_str(), cp.c_str()) == 0;
   if (!ok) remove(tmp.c_str());
@@ -248,8 +294,8 @@ extern "C" void sigax_index_close(sigax_index* ix) {
     if (ix->d_gran[s]) hipFree(ix->d_gran[s]);
     if (ix->d_gran2[s]) hipFree(ix->d_gran2[s]);
     if (ix->d_super2[s]) hipFree(ix->d_super2[s]);
-    if (ix->d_rowend[s]) hipFree(ix->d_rowend[s]);
-    if (ix->d_la[s]) hipFree(ix->d_la[s]);
+    if (ix->d_sa[s]) hipFree(ix->d_sa[s]);
+    if (ix->d_text[s]) hipFree(ix->d_text[s]);
     if (ix->d_super[s]) hipFree(ix->d_super[s]);
     if (ix->d_sai[s]) hipFree(ix->d_sai[s]);
   }
@@ -259,84 +305,183 @@ extern "C" void sigax_index_close(sigax_index* ix) {
   if (ix->s_fx) hipStreamDestroy(ix->s_fx);
   if (ix->s_tail) hipStreamDestroy(ix->s_tail);
   delete ix->enqueue_mu;
+  delete ix->cap_seen;
   delete ix;
 }
 
-// Row-end tables for the irreducible extractor (8 bytes per symbol and strand, fm_layout.h): a branch that leaves ONE
-// single-row block in a group -- what a substitution in an overlapping read does -- is resolved by one lookup instead of a
-// walk to the end of that read (~100 dependent rounds).  An accelerator like the two-step tables: skipped when memory is
-// short or SIGAX_ROWEND=0, and the extractor then walks.  Built on the index's own device (a clone builds its own: 2 n LF
-// steps on the spot beat copying 16 n bytes between GPUs).
-// Which tables does this index get?  Decided at open from the free memory of that moment.
+// Row tables for the irreducible extractor (fm_layout.h: the suffix array as (stretch, offset), bit-packed, plus the
+// stretches' text): a single-row block's extension rounds are read off its read's text instead of computed from rank
+// lines, and a branch that leaves ONE single-row block in a group -- what a substitution in an overlapping read does -- is
+// resolved by one lookup instead of a walk to the end of that read (~100 dependent rounds).  An accelerator like the
+// two-step tables: skipped when memory is short or SIGAX_ROWEND=0 (SIGAX_LOOKAHEAD=0: no text, countdowns only), and the
+// extractor then walks.  Built on the index's own device (a clone builds its own: 2 n LF steps on the spot beat copying
+// the tables between GPUs).
+static u32 bits_for(u64 maxval) {  // bits that hold 0 .. maxval
+  u32 b = 1;
+  while (b < 64 && (maxval >> b) != 0) ++b;
+  return b;
+}
+struct RowTabGeom {
+  u32 sa_bits, ld_bits, t_bits, text_stride;
+  u64 sa_bytes, text_bytes;  // per strand
+};
+// syms = symbols an entry carries at most (as many as keep it within the 57 bits one unaligned 8-byte load delivers)
+static RowTabGeom row_tab_geom(const sigax_index* ix, u32 maxlen, u32 syms) {
+  RowTabGeom g;
+  const u64 n_stretch = ix->st[0].C[1];
+  g.ld_bits = bits_for(n_stretch ? n_stretch - 1 : 0);
+  g.t_bits = bits_for(maxlen);
+  g.sa_bits = g.ld_bits + g.t_bits;
+  if (g.sa_bits < 57) g.sa_bits += 2 * std::min<u32>(syms, std::min<u32>(14u, (57 - g.sa_bits) / 2));
+  g.text_stride = ((2 * maxlen + 7) / 8 + 8 + 7) & ~7u;  // 2 bits per symbol; the build ORs whole 8-byte words in
+  g.sa_bytes = ((ix->n_symbols * g.sa_bits + 63) / 64) * 8 + 16;
+  g.text_bytes = n_stretch * (u64)g.text_stride + 16;
+  return g;
+}
+// the longest stretch this index can hold, as far as the host knows: no stretch is longer than the longest read
+static u32 maxlen_bound(const sigax_index* ix) {
+  if (ix->max_read_len) return ix->max_read_len;
+  const u64 n_stretch = std::max<u64>(ix->st[0].C[1], 1);
+  const u64 avg = ix->n_symbols / n_stretch;
+  return (u32)std::min<u64>(std::max<u64>(2 * avg, avg + 64), (1u << 28) - 1);
+}
+// Which tables does this index get?  Decided from the free memory of that moment.
 static void plan_row_tables(sigax_index* ix) {
   const char* envr = getenv("SIGAX_ROWEND");
   const char* envl = getenv("SIGAX_LOOKAHEAD");
-  const u64 n_symbols = ix->n_symbols;
   ix->tab_plan = 0;
+  if ((envr && envr[0] == '0') || ix->st[0].C[1] >= 0xFFFFFFFFull || ix->n_symbols == 0) return;
   size_t mfree = 0, mtotal = 0;
   (void)hipMemGetInfo(&mfree, &mtotal);
-  if ((envr && envr[0] == '0') || ix->st[0].C[1] >= 0xFFFFFFFFull || n_symbols == 0 || 16ull * n_symbols >= mfree / 2) return;
-  // the look-ahead tables (another 8 bytes per symbol and strand) when both pairs fit in 60 % of the free memory
-  ix->tab_la = !(envl && envl[0] == '0') && n_symbols < (1ull << (64 - SIGAX_LA_ROW_SHIFT)) && 32ull * n_symbols < mfree / 5 * 3;
-  ix->tab_plan = 2 * n_symbols * (ix->tab_la ? 16 : 8);  // with look-ahead: one interleaved table {look-ahead, row-end} per row
+  ix->tab_text = !(envl && envl[0] == '0');
+  // entries with their first symbols when that fits 40 % of the free memory (one lookup then serves an item's first rounds:
+  // at BASELINE configs[1] 14 symbols, 56 bits per row), bare entries when those fit 70 %
+  static const char* envk = getenv("SIGAX_ROW_SYMS");
+  for (u32 syms = ix->tab_text ? (envk ? (u32)atoi(envk) : 14u) : 0u;; syms = 0) {
+    const RowTabGeom g = row_tab_geom(ix, maxlen_bound(ix), syms);
+    if (g.sa_bits > 57) return;
+    const u64 want = 2 * (g.sa_bytes + (ix->tab_text ? g.text_bytes : 0));
+    if (want < mfree / 10 * (syms ? 4 : 7)) {
+      ix->tab_plan = want;
+      ix->tab_syms = syms;
+      return;
+    }
+    if (syms == 0) return;
+  }
 }
 
-// Allocation, on the caller's thread ...
+static void free_row_tables(sigax_index* ix) {
+  for (int s = 0; s < 2; ++s) {
+    if (ix->d_sa[s]) hipFree(ix->d_sa[s]);
+    if (ix->d_text[s]) hipFree(ix->d_text[s]);
+    ix->d_sa[s] = ix->d_text[s] = nullptr;
+    ix->sa_alloc[s] = ix->text_alloc[s] = 0;
+  }
+}
+
+// Allocation, on the caller's thread (by the bound of the longest stretch) ...
 static bool alloc_row_tables(sigax_index* ix) {
-  const bool want_la = ix->tab_la;
-  const u64 bytes = ix->tab_plan / 2;
+  const RowTabGeom g = row_tab_geom(ix, maxlen_bound(ix), ix->tab_syms);
   ix->tab_plan = 0;
   hipError_t e = hipSuccess;
-  for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipMalloc(want_la ? &ix->d_la[s] : &ix->d_rowend[s], bytes);
+  for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+    e = hipMalloc(&ix->d_sa[s], g.sa_bytes);
+    if (e == hipSuccess) ix->sa_alloc[s] = g.sa_bytes;
+    if (e == hipSuccess && ix->tab_text) {
+      e = hipMalloc(&ix->d_text[s], g.text_bytes);
+      if (e == hipSuccess) ix->text_alloc[s] = g.text_bytes;
+    }
+  }
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    for (int s = 0; s < 2; ++s) {
-      if (ix->d_rowend[s]) hipFree(ix->d_rowend[s]);
-      if (ix->d_la[s]) hipFree(ix->d_la[s]);
-      ix->d_rowend[s] = ix->d_la[s] = nullptr;
-    }
+    free_row_tables(ix);
     if (getenv("SIGAX_VERBOSE")) fprintf(stderr, "[sigax] row tables not allocated (%s): the extractor walks\n", hipGetErrorString(e));
     return false;
   }
   return true;
 }
 
-// ... and the fill, on a stream of its own (possibly on a side thread)
-static void fill_row_tables(sigax_index* ix, bool want_la, u64 bytes, FmStrand out[2], u64* out_bytes) {
+// ... and the fill, on a stream of its own (possibly on a side thread): the first walk measures the longest stretch, which
+// fixes the entry width; buffers that turn out too small for it (the bound was an estimate) are allocated again here
+static void fill_row_tables(sigax_index* ix, FmStrand out[2], u64* out_bytes) {
   out[0] = ix->st[0];
   out[1] = ix->st[1];
   *out_bytes = 0;
+  const u64 n_stretch = ix->st[0].C[1];
   hipStream_t sb = nullptr;
+  void* info = nullptr;
+  u32* d_max = nullptr;
   hipError_t e = hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&info, std::max<u64>(n_stretch, 1) * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_max, 8);
+  u32 maxlen[2] = {0, 0};
+  RowTabGeom g[2];
   for (int s = 0; s < 2 && e == hipSuccess; ++s) {
-    void* tab = want_la ? ix->d_la[s] : ix->d_rowend[s];
-    e = hipMemsetAsync(tab, 0, bytes, sb);
+    e = hipMemsetAsync(d_max, 0, 8, sb);
     if (e != hipSuccess) break;
-    launch_rowend_build(ix->st[s], ix->wide, ix->st[s].C[1], want_la ? (u64*)tab + 1 : (u64*)tab, want_la ? (u64*)tab : nullptr, sb);
+    launch_stretch_scan(ix->st[s], ix->wide, n_stretch, (u64*)info, d_max, sb);
     e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&maxlen[s], d_max, 4, hipMemcpyDeviceToHost, sb);
+    if (e == hipSuccess) e = hipStreamSynchronize(sb);
+    if (e != hipSuccess) break;
+    g[s] = row_tab_geom(ix, maxlen[s], ix->tab_syms);
+    if (g[s].sa_bits > 57) { e = hipErrorInvalidValue; break; }
+    if (g[s].sa_bytes > ix->sa_alloc[s]) {
+      hipFree(ix->d_sa[s]);
+      ix->d_sa[s] = nullptr;
+      ix->sa_alloc[s] = 0;
+      e = hipMalloc(&ix->d_sa[s], g[s].sa_bytes);
+      if (e != hipSuccess) break;
+      ix->sa_alloc[s] = g[s].sa_bytes;
+    }
+    if (ix->tab_text && g[s].text_bytes > ix->text_alloc[s]) {
+      hipFree(ix->d_text[s]);
+      ix->d_text[s] = nullptr;
+      ix->text_alloc[s] = 0;
+      e = hipMalloc(&ix->d_text[s], g[s].text_bytes);
+      if (e != hipSuccess) break;
+      ix->text_alloc[s] = g[s].text_bytes;
+    }
+    e = hipMemsetAsync(ix->d_sa[s], 0, ix->sa_alloc[s], sb);
+    if (e == hipSuccess && ix->tab_text) e = hipMemsetAsync(ix->d_text[s], 0, ix->text_alloc[s], sb);
+    if (e != hipSuccess) break;
+    launch_rows_fill(ix->st[s], ix->wide, n_stretch, (const u64*)info, (unsigned char*)ix->d_sa[s], g[s].sa_bits, g[s].ld_bits, g[s].t_bits,
+                     ix->tab_text ? (unsigned char*)ix->d_text[s] : nullptr, g[s].text_stride, sb);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(sb);
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(sb);
   if (sb) (void)hipStreamDestroy(sb);
+  if (info) hipFree(info);
+  if (d_max) hipFree(d_max);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     if (getenv("SIGAX_VERBOSE")) fprintf(stderr, "[sigax] row tables not built (%s): the extractor walks\n", hipGetErrorString(e));
     return;  // the buffers are freed with the index
   }
   for (int s = 0; s < 2; ++s) {
-    out[s].la = (const u64*)ix->d_la[s];
-    out[s].rowend = want_la ? (const u64*)ix->d_la[s] + 1 : (const u64*)ix->d_rowend[s];
-    out[s].re_stride = want_la ? 2u : 1u;
+    out[s].sa = (const unsigned char*)ix->d_sa[s];
+    out[s].text = ix->tab_text ? (const unsigned char*)ix->d_text[s] : nullptr;
+    out[s].sa_bits = g[s].sa_bits;
+    out[s].ld_bits = g[s].ld_bits;
+    out[s].t_bits = g[s].t_bits;
+    out[s].text_stride = g[s].text_stride;
+    *out_bytes += ix->sa_alloc[s] + ix->text_alloc[s];
   }
-  *out_bytes = 2 * bytes;
+  if (getenv("SIGAX_VERBOSE"))
+    fprintf(stderr, "[sigax] row tables: %u bits per row (stretch %u + offset %u + %u symbols), text rows of %u bytes, %.2f GB\n", g[0].sa_bits,
+            g[0].ld_bits, g[0].t_bits, (g[0].sa_bits - g[0].ld_bits - g[0].t_bits) / 2, ix->tab_text ? g[0].text_stride : 0u, *out_bytes / 1e9);
 }
 
 // the tables of a finished build become visible to the runs enqueued from now on
 static void publish_tables(sigax_index* ix) {
   if (!ix->tab_state || ix->tab_state->load(std::memory_order_acquire) != 2) return;
   for (int s = 0; s < 2; ++s) {
-    ix->st[s].rowend = ix->tab_st[s].rowend;
-    ix->st[s].la = ix->tab_st[s].la;
-    ix->st[s].re_stride = ix->tab_st[s].re_stride;
+    ix->st[s].sa = ix->tab_st[s].sa;
+    ix->st[s].text = ix->tab_st[s].text;
+    ix->st[s].sa_bits = ix->tab_st[s].sa_bits;
+    ix->st[s].ld_bits = ix->tab_st[s].ld_bits;
+    ix->st[s].t_bits = ix->tab_st[s].t_bits;
+    ix->st[s].text_stride = ix->tab_st[s].text_stride;
   }
   ix->device_bytes += ix->tab_bytes;
   ix->tab_state->store(0, std::memory_order_release);
@@ -345,26 +490,23 @@ static void publish_tables(sigax_index* ix) {
 // start (or do) the build: allocate here, fill on a side thread unless `sync`
 static void start_row_tables(sigax_index* ix, bool sync) {
   if (ix->tab_plan == 0) return;
-  const bool want_la = ix->tab_la;
-  const u64 bytes = ix->tab_plan / 2;
   if (!alloc_row_tables(ix)) return;
   if (sync) {
-    fill_row_tables(ix, want_la, bytes, ix->tab_st, &ix->tab_bytes);
+    fill_row_tables(ix, ix->tab_st, &ix->tab_bytes);
     ix->tab_state->store(2);
     publish_tables(ix);
     return;
   }
   ix->tab_state->store(1);
-  ix->tab_thread = new std::thread([ix, want_la, bytes] {
+  ix->tab_thread = new std::thread([ix] {
     (void)hipSetDevice(ix->device);
-    fill_row_tables(ix, want_la, bytes, ix->tab_st, &ix->tab_bytes);
+    fill_row_tables(ix, ix->tab_st, &ix->tab_bytes);
     ix->tab_state->store(2, std::memory_order_release);
   });
 }
 
 static void build_rowend(sigax_index* ix) {
   ix->tab_state = new std::atomic<int>(0);
-  for (int s = 0; s < 2; ++s) ix->st[s].re_stride = 1;
   plan_row_tables(ix);
   // small indexes (and SIGAX_TABLES_SYNC=1) at once; the others when the second run is enqueued (enqueue())
   if (ix->n_symbols < (1ull << 26) || getenv("SIGAX_TABLES_SYNC") != nullptr) start_row_tables(ix, true);
@@ -384,6 +526,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
   memset(ix, 0, sizeof(*ix));
   ix->device = device;
   ix->enqueue_mu = new std::mutex();
+  ix->cap_seen = new std::atomic<uint32_t>(0);
   if (hipDeviceGetAttribute(&ix->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ix->n_cu <= 0) ix->n_cu = 256;
   {
     // the finder is the critical path of a step: its stream gets the higher priority
@@ -560,6 +703,7 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
   memset(ix, 0, sizeof(*ix));
   ix->device = device;
   ix->enqueue_mu = new std::mutex();
+  ix->cap_seen = new std::atomic<uint32_t>(src->cap_seen->load());
   ix->n_cu = src->n_cu;
   (void)hipDeviceGetAttribute(&ix->n_cu, hipDeviceAttributeMultiprocessorCount, device);
   {
@@ -578,6 +722,7 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
   ix->n_strings = src->n_strings;
   ix->n_sai = src->n_sai;
   ix->n_meta = src->n_meta;
+  ix->max_read_len = src->max_read_len;
   ix->split_strands = src->split_strands;
   const u64 ngran = src->n_symbols / SIGAX_GRANULE_SYMS + 1;
   const u64 nsuper = ((ngran - 1) >> (SIGAX_SUPER_SHIFT - 7)) + 1;
@@ -598,9 +743,8 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
     if (rc == SIGAX_OK) rc = copy(&ix->d_super2[s], src->d_super2[s], (((ng2 - 1) >> (SIGAX_SUPER_SHIFT - 6)) + 1) * 20 * 8);
     if (rc == SIGAX_OK) rc = copy((void**)&ix->d_sai[s], src->d_sai[s], src->n_sai * 4);
     ix->st[s] = src->st[s];
-    ix->st[s].rowend = nullptr;
-    ix->st[s].la = nullptr;
-    ix->st[s].re_stride = 1;
+    ix->st[s].sa = nullptr;
+    ix->st[s].text = nullptr;
     ix->st[s].granules = (const uint32_t*)ix->d_gran[s];
     ix->st[s].super = (const u64*)ix->d_super[s];
     ix->st[s].gran2 = (const uint32_t*)ix->d_gran2[s];
@@ -637,7 +781,13 @@ extern "C" int sigax_index_set_reads(sigax_index* ix, const uint32_t* lengths, c
   ix->d_read_len = ix->d_name_rank = nullptr;
   int rc = upload(lengths, n * 4, (void**)&ix->d_read_len, &ix->device_bytes);
   if (rc == SIGAX_OK) rc = upload(name_rank, n * 4, (void**)&ix->d_name_rank, &ix->device_bytes);
-  if (rc == SIGAX_OK) ix->n_meta = n;
+  if (rc == SIGAX_OK) {
+    ix->n_meta = n;
+    uint32_t mx = 0;
+    for (uint64_t i = 0; i < n; ++i) mx = std::max(mx, lengths[i]);
+    ix->max_read_len = mx;
+    if (ix->tab_plan) plan_row_tables(ix);  // planned with an estimate of the longest stretch, not started yet: now with the bound
+  }
   return rc;
 }
 
@@ -743,6 +893,26 @@ extern "C" int sigax_correct_batch(sigax_index* ix, const char* seqs, const char
   return SIGAX_OK;
 }
 
+// Slots per chain of the candidate arena for reads of up to max_len bases.  Worst case: overlaps of length max(m,1)..L-1,
+// plus one for the containment block.  Given: what the longest chain so far needed plus headroom -- or, before any run has
+// finished, a third of the worst case -- never more than the worst case, never less than `floor_slots` records.  Even:
+// each chain's slots start on a 64-byte line (k_find's quad stores write whole lines).
+static uint32_t worst_cap(uint32_t max_len, uint32_t minov) {
+  const uint32_t mm = std::max<uint32_t>(minov, 1u);
+  const uint32_t cap = (max_len > mm ? max_len - mm : 0u) + 1u;
+  return (cap + 1u) & ~1u;
+}
+static uint32_t chain_cap(const sigax_index* ix, uint32_t max_len, uint32_t minov, uint32_t floor_slots) {
+  const uint32_t worst = worst_cap(max_len, minov);
+  static const char* env = getenv("SIGAX_CAND_CAP");  // "worst" = the round-2 sizing; a number = slots of the first try (tests)
+  if (env && env[0] == 'w') return worst;
+  const uint32_t seen = ix->cap_seen->load();
+  uint32_t want = seen ? seen + seen / 8 + 3 : (env ? (uint32_t)atoi(env) : std::max<uint32_t>(worst / 3, 16u));
+  want = std::max(want, floor_slots + 1u);  // + the containment slot
+  want = (want + 1u) & ~1u;
+  return std::min(worst, std::max(want, 2u));
+}
+
 // ------------------------------------------------------------------------------------------------------
 // batch workspace
 // ------------------------------------------------------------------------------------------------------
@@ -764,7 +934,7 @@ static int ensure(DevBuf* b, size_t bytes) {
   return SIGAX_OK;
 }
 
-enum { EV_START = 0, EV_FX_DONE, EV_ORDER, EV_EDGES, EV_COUNT };
+enum { EV_START = 0, EV_FX_DONE, EV_ORDER, EV_EDGES, EV_ORD0, EV_ORD1, EV_COUNT };
 // per sub-batch: find begin/end on the find stream, fast begin/end and general end on the filter/extract stream
 enum { SV_F0 = 0, SV_F1, SV_X0, SV_X1, SV_G1, SV_COUNT };
 
@@ -786,10 +956,12 @@ struct sigax_batch {
   DevBuf arena, chain_cnt, pool, wpool, work, work64, work64b, work64c, perm, ord_keys, ord_tmp, occ_side, slow_flag, offs2, item_base, fin, fin_cnt, substring, block_offs, outb, edge_cnt,
       edge_offs, edges, partial, dstat;
   uint32_t cap;
+  uint32_t cap_floor;  // records the longest chain of this batch's last (overflowed) run needed
   uint32_t pool_cap;
   unsigned fx_grid;
   u64 fin_cap, edge_cap;
   bool fin_grown;
+  u64 n_reruns;  // runs repeated because an arena was too small
   hipEvent_t ev[EV_COUNT];
   hipEvent_t sev[SIGAX_MAX_SUB][SV_COUNT];
   unsigned nsub;
@@ -802,6 +974,7 @@ struct sigax_batch {
   unsigned lean_off_runs;
   unsigned nsub_req;  // 0 = automatic
   unsigned find_per_sub;  // finder launches per sub-batch (2 = one per strand's two-step table)
+  bool last_two_step, last_coop, last_perm, last_ordered;  // what the last enqueued run's finder did (sigax_batch_run_info)
   sigax_stats last;
   u64 last_total_blocks, last_total_edges;
   bool finished;
@@ -841,10 +1014,12 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
   b->read_base = b->minov = b->flags = 0;
   b->ran = b->finished = false;
   b->cap = 0;
+  b->cap_floor = 0;
   b->pool_cap = 0;
   b->fx_grid = 0;
   b->fin_cap = b->edge_cap = 0;
   b->fin_grown = false;
+  b->n_reruns = 0;
   memset(&b->last, 0, sizeof(b->last));
   b->last_total_blocks = b->last_total_edges = 0;
   for (int i = 0; i < EV_COUNT; ++i) b->ev[i] = nullptr;
@@ -860,6 +1035,7 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
   b->perm_nsub = 0;
   b->nsub_req = 0;
   b->find_per_sub = 1;
+  b->last_two_step = b->last_coop = b->last_perm = b->last_ordered = false;
   {
     hipError_t e = hipSuccess;
     for (int i = 0; i < EV_COUNT && e == hipSuccess; ++i) e = hipEventCreate(&b->ev[i]);
@@ -932,10 +1108,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     return fail(SIGAX_E_STATE, "SIGAX_EDGES needs the .sai tables and sigax_index_set_reads()");
   if (edges && (u64)b->read_base + n > ix->n_strings)
     return fail(SIGAX_E_ARG, "read_base + n_reads exceeds the indexed read set");
-  // slots per chain: overlaps of length max(m,1)..L-1, plus one for the containment block
-  uint32_t mm = std::max<uint32_t>(b->minov, 1u);
-  b->cap = (b->cur_max_len > mm ? b->cur_max_len - mm : 0u) + 1u;
-  b->cap = (b->cap + 1u) & ~1u;  // even: each chain's slots start on a 64-byte line (k_find's quad stores write whole lines)
+  b->cap = chain_cap(ix, b->cur_max_len, b->minov, b->cap_floor);
   int rc;
   if ((rc = ensure(&b->arena, (size_t)n * 4 * b->cap * cand_bytes(ix->wide))) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->chain_cnt, (size_t)n * 4 * 4)) != SIGAX_OK) return rc;
@@ -979,8 +1152,8 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   if ((rc = ensure(&b->partial, scan_partials_needed(scan_n) * 8)) != SIGAX_OK) return rc;
   if (edges) {
     if (b->edge_cap == 0) b->edge_cap = t_edge ? std::max<u64>(strtoull(t_edge, nullptr, 10), 1) : b->fin_cap * 2 + 1024;
-    if ((rc = ensure(&b->edge_cnt, (b->fin_cap + 1) * 4)) != SIGAX_OK) return rc;
-    if ((rc = ensure(&b->edge_offs, (b->fin_cap + 2) * 8)) != SIGAX_OK) return rc;
+    if ((rc = ensure(&b->edge_cnt, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
+    if ((rc = ensure(&b->edge_offs, (2 * (size_t)n + 4) * 8)) != SIGAX_OK) return rc;
     if ((rc = ensure(&b->edges, b->edge_cap * sizeof(sigax_edge))) != SIGAX_OK) return rc;
   }
   u64* dstat = (u64*)b->dstat.p;
@@ -999,9 +1172,15 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   // workgroup's reads are staged in LDS by slot (the longest read decides).
   // SIGAX_READ_ORDER=0 turns it off.
   const uint32_t* d_perm = nullptr;
+  b->last_ordered = false;
   const uint32_t perm_stride = (b->cur_max_len + 3u) & ~3u;
   {
-    static const bool order_on = !(getenv("SIGAX_READ_ORDER") && getenv("SIGAX_READ_ORDER")[0] == '0');
+    // Off by default below 2^30 symbols: measured at BASELINE configs[1] with the ordering inside the timed step (as every
+    // product batch pays it), 105.0 M reads/s with it against 110.5 M without -- the table is cache-resident there and the
+    // order buys the finder 1 %.  On for the big indexes, where what it saves is page translations.  SIGAX_READ_ORDER=0/1.
+    static const char* env_ord = getenv("SIGAX_READ_ORDER");
+    static const char* env_omin = getenv("SIGAX_ORDER_MIN_SYMBOLS");
+    const bool order_on = env_ord ? env_ord[0] != '0' : ix->n_symbols >= (env_omin ? strtoull(env_omin, nullptr, 10) : (1ull << 30));
     static const char* env_coop0 = getenv("SIGAX_FIND_COOP");
     static const char* env_cmin0 = getenv("SIGAX_COOP_MIN_SYMBOLS");
     const u64 coop_min0 = env_cmin0 ? strtoull(env_cmin0, nullptr, 10) : (1ull << 31);
@@ -1009,15 +1188,18 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
                             32ull * perm_stride + 32 <= 32768;
     if (order_on && n >= 2 && (coop_would || 128ull * perm_stride + 8 <= find_stage_capacity())) {
       if (!b->perm_valid || b->perm_nsub != nsub) {
+        HIP_TRY(hipEventRecord(b->ev[EV_ORD0], st));
+        b->last_ordered = true;
         const size_t tb = sigax_order_reads_tmp_bytes(n);
-        if ((rc = ensure(&b->ord_keys, (size_t)n * 16)) != SIGAX_OK) return rc;
+        if ((rc = ensure(&b->ord_keys, (size_t)n * 8)) != SIGAX_OK) return rc;
         if ((rc = ensure(&b->perm, (size_t)n * 8)) != SIGAX_OK) return rc;
         if ((rc = ensure(&b->ord_tmp, tb)) != SIGAX_OK) return rc;
         uint32_t bounds[SIGAX_MAX_SUB + 1];
         for (unsigned i = 0; i <= nsub; ++i) bounds[i] = (uint32_t)((u64)n * i / nsub);
-        rc = sigax_order_reads(b->d_seqs, b->d_offs, n, bounds, nsub, (u64*)b->ord_keys.p, (uint32_t*)b->perm.p, b->ord_tmp.p, tb,
+        rc = sigax_order_reads(b->d_seqs, b->d_offs, n, bounds, nsub, (uint32_t*)b->ord_keys.p, (uint32_t*)b->perm.p, b->ord_tmp.p, tb,
                                &b->perm_cur, st);
         if (rc != SIGAX_OK) return rc;
+        HIP_TRY(hipEventRecord(b->ev[EV_ORD1], st));
         b->perm_valid = true;
         b->perm_nsub = nsub;
       }
@@ -1040,6 +1222,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.minov = b->minov;
     fa.chain_mask = (b->flags & SIGAX_DUPLICATE) ? 0x9u : (b->flags & SIGAX_RC) ? 0xFu : 0x5u;
     fa.cap = b->cap;
+    fa.max_seen = ix->cap_seen->load();
     fa.read_begin = rb;
     fa.read_end = re;
     fa.stage_bytes = 0;  // set by launch_find
@@ -1069,6 +1252,9 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.dstat = dstat;
     fa.perm = (fa.coop || 128ull * perm_stride + 8 <= find_stage_capacity()) ? d_perm : nullptr;
     fa.stage_stride = perm_stride;
+    b->last_two_step = fa.two_step != 0;
+    b->last_coop = fa.coop != 0;
+    b->last_perm = fa.perm != nullptr;
     HIP_TRY(hipEventRecord(b->sev[i][SV_F0], ix->s_find));
     fa.chain_base = 0;
     fa.chains_per_wg = 4;
@@ -1176,29 +1362,34 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   oa.arena = b->arena.p;
   oa.cap = b->cap;
   oa.wide = ix->wide ? 1u : 0u;
+  oa.item_edges = edges ? (uint32_t*)b->edge_cnt.p : nullptr;
+  oa.read_base = b->read_base;
+  oa.sai = ix->d_sai[0];
+  oa.rsai = ix->d_sai[1];
+  oa.n_sai = ix->n_sai;
+  oa.read_len = ix->d_read_len;
+  oa.name_rank = ix->d_name_rank;
   launch_order_scatter(oa, ts);
   HIP_TRY(hipEventRecord(b->ev[EV_ORDER], ts));
 
   if (edges) {
     EdgeArgs ea;
     ea.blocks = (const sigax_block*)b->outb.p;
-    ea.block_offs = (const u64*)b->block_offs.p;
-    ea.n_reads = n;
+    ea.blocks_cap = b->fin_cap;
+    ea.offs2 = (const u64*)b->offs2.p;
+    ea.fin_cnt = (const uint32_t*)b->fin_cnt.p;
+    ea.n_items = 2 * (u64)n;
     ea.read_base = b->read_base;
     ea.sai = ix->d_sai[0];
     ea.rsai = ix->d_sai[1];
     ea.n_sai = ix->n_sai;
     ea.read_len = ix->d_read_len;
     ea.name_rank = ix->d_name_rank;
-    ea.edge_cnt = (uint32_t*)b->edge_cnt.p;
-    ea.cnt_cap = b->fin_cap;
     ea.edge_offs = (const u64*)b->edge_offs.p;
     ea.edges = (sigax_edge*)b->edges.p;
     ea.edge_cap = b->edge_cap;
-    launch_edges(ea, false, b->fin_cap, ts);
-    launch_scan((const uint32_t*)b->edge_cnt.p, b->fin_cap, (u64*)b->partial.p, (u64*)b->edge_offs.p,
-                dstat + DS_TOTAL_EDGES, ts);
-    launch_edges(ea, true, b->fin_cap, ts);
+    launch_scan((const uint32_t*)b->edge_cnt.p, 2 * (u64)n, (u64*)b->partial.p, (u64*)b->edge_offs.p, dstat + DS_TOTAL_EDGES, ts);
+    launch_edges_fill(ea, ts);
   }
   HIP_TRY(hipEventRecord(b->ev[EV_EDGES], ts));
   HIP_TRY(hipStreamWaitEvent(st, b->ev[EV_EDGES], 0));
@@ -1232,8 +1423,19 @@ extern "C" int sigax_batch_finish(sigax_batch* b, void* stream, sigax_stats* sta
     u64 ds[DS_COUNT];
     HIP_TRY(hipMemcpyAsync(ds, b->dstat.p, sizeof(ds), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (ds[DS_FIND_OVERFLOW]) return fail(SIGAX_E_CAPACITY, "candidate arena overflow (max read length given too small?)");
     bool again = false;
+    {
+      // what the longest chain needed becomes the index's knowledge (later runs and other batch objects size by it)
+      uint32_t seen = b->ix->cap_seen->load();
+      const uint32_t got = (uint32_t)std::min<u64>(ds[DS_MAX_CHAIN], 0x0FFFFFFFull);
+      while (got > seen && !b->ix->cap_seen->compare_exchange_weak(seen, got)) {}
+    }
+    if (ds[DS_FIND_OVERFLOW]) {
+      if (b->cap >= worst_cap(b->cur_max_len, b->minov))
+        return fail(SIGAX_E_CAPACITY, "candidate arena overflow (max read length given too small?)");
+      b->cap_floor = (uint32_t)std::min<u64>(ds[DS_MAX_CHAIN], 0x0FFFFFFFull);  // the chains ran out of slots: once more with what they need
+      again = true;
+    }
     if (ds[DS_POOL_OVERFLOW]) {
       if (b->pool_cap > (1u << 22)) return fail(SIGAX_E_CAPACITY, "%llu reads overflow the filter/extract pool", ds[DS_POOL_OVERFLOW]);
       b->pool_cap *= 4;
@@ -1250,6 +1452,7 @@ extern "C" int sigax_batch_finish(sigax_batch* b, void* stream, sigax_stats* sta
       again = true;
     }
     if (again) {
+      ++b->n_reruns;
       int rc = enqueue(b, st);
       if (rc != SIGAX_OK) return rc;
       continue;
@@ -1383,10 +1586,12 @@ extern "C" int sigax_batch_size_hint(sigax_index* ix, uint32_t max_read_len, uin
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   free_b = free_b > ix->tab_plan ? free_b - ix->tab_plan : 0;  // the row tables are allocated when the second run starts
-  const u64 mm = std::max<uint32_t>((flags & SIGAX_DUPLICATE) ? max_read_len : min_overlap, 1u);
-  u64 cap = (max_read_len > mm ? max_read_len - mm : 0u) + 1u;
-  cap = (cap + 1u) & ~1ull;
-  const u64 per_read = 4 * cap * cand_bytes(ix->wide) + max_read_len + ((flags & SIGAX_IRREDUCIBLE) ? 8 : 64) * (2 * 80 + 2 * 16 + 12) + 128;
+  // slots per chain as the runs will size them; before any run has finished, half the worst case (the first runs try a
+  // third and repeat themselves with what their chains needed)
+  const uint32_t mo = (flags & SIGAX_DUPLICATE) ? max_read_len : min_overlap;
+  const u64 cap = ix->cap_seen->load() ? chain_cap(ix, max_read_len, mo, 0) : std::max<uint32_t>(chain_cap(ix, max_read_len, mo, 0), worst_cap(max_read_len, mo) / 2);
+  // + the locality order's keys, values and sort space (40 bytes per read), the per-read queues and counters (~70)
+  const u64 per_read = 4 * cap * cand_bytes(ix->wide) + max_read_len + ((flags & SIGAX_IRREDUCIBLE) ? 8 : 64) * (2 * 80 + 2 * 16 + 12) + 256;
   const u64 fixed = (2ull << 30) + (u64)32768 * (4 * (cap + 2) + 128) * SIGAX_ENT_BYTES;  // pools of the lane-group and general kernels
   const u64 share = (u64)(free_b * 0.85) / std::max<uint32_t>(in_flight, 1u);
   u64 n = share > fixed ? (share - fixed) / per_read : 0;
@@ -1422,16 +1627,117 @@ extern "C" int sigax_batch_kernel_ms(sigax_batch* b, float ms[5], uint32_t* n_su
   return SIGAX_OK;
 }
 
+extern "C" int sigax_batch_run_info(sigax_batch* b, sigax_run_info* out) {
+  if (!b || !out) return fail(SIGAX_E_ARG, "NULL argument");
+  if (!b->finished) return fail(SIGAX_E_STATE, "batch not finished");
+  HIP_TRY(hipSetDevice(b->ix->device));
+  memset(out, 0, sizeof(*out));
+  out->n_sub = b->nsub;
+  out->find_per_sub = b->find_per_sub;
+  out->two_step = b->last_two_step ? 1u : 0u;
+  out->coop = b->last_coop ? 1u : 0u;
+  out->read_order = b->last_perm ? 1u : 0u;
+  out->cap = b->cap;
+  out->worst_cap = worst_cap(b->cur_max_len, b->minov);
+  const FmStrand& f = b->ix->st[0];
+  out->row_bits = f.sa ? f.sa_bits : 0u;
+  out->row_syms = f.sa ? (f.sa_bits - f.ld_bits - f.t_bits) / 2u : 0u;
+  out->row_text = f.text ? 1u : 0u;
+  out->arena_bytes = b->arena.bytes;
+  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->work64c, &b->perm,
+                   &b->ord_keys, &b->ord_tmp, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin, &b->fin_cnt, &b->substring, &b->block_offs,
+                   &b->outb, &b->edge_cnt, &b->edge_offs, &b->edges, &b->partial, &b->dstat};
+  for (DevBuf* d : all) out->workspace_bytes += d->bytes;
+  out->reruns = b->n_reruns;
+  if (b->last_ordered) HIP_TRY(hipEventElapsedTime(&out->order_ms, b->ev[EV_ORD0], b->ev[EV_ORD1]));
+  return SIGAX_OK;
+}
+
+// One call = OverlapBuilder::overlap for any number of reads: what does not fit one device workspace beside the index goes
+// through it in pieces (sized by sigax_batch_size_hint) and the pieces' results are joined in read order.
 extern "C" int sigax_overlap_batch(sigax_index* ix, const char* seqs, const uint64_t* offs, uint32_t n_reads,
                                    uint32_t read_base, uint32_t min_overlap, uint32_t flags, sigax_result* out) {
-  if (!ix || !out) return fail(SIGAX_E_ARG, "NULL argument");
+  if (!ix || !out || (n_reads && (!seqs || !offs))) return fail(SIGAX_E_ARG, "NULL argument");
+  memset(out, 0, sizeof(*out));
+  uint32_t max_len = 0;
+  for (uint32_t i = 0; i < n_reads; ++i) {
+    if (offs[i + 1] < offs[i] || offs[i + 1] - offs[i] > 0x0FFFFFFFull) return fail(SIGAX_E_ARG, "bad offsets at read %u", i);
+    max_len = std::max<uint32_t>(max_len, (uint32_t)(offs[i + 1] - offs[i]));
+  }
+  uint32_t piece = n_reads;
+  if (n_reads > 65536) {
+    uint32_t hint = 0;
+    int rc = sigax_batch_size_hint(ix, max_len, min_overlap, flags, 1, &hint);
+    if (rc != SIGAX_OK) return rc;
+    static const char* env = getenv("SIGAX_TEST_PIECE");  // tests: force several pieces on small inputs
+    if (env) hint = std::max<uint32_t>(1u, (uint32_t)atoi(env));
+    piece = std::min(n_reads, hint);
+  } else if (const char* env = getenv("SIGAX_TEST_PIECE")) {
+    piece = std::min<uint32_t>(n_reads, std::max<uint32_t>(1u, (uint32_t)atoi(env)));
+  }
   sigax_batch* b = nullptr;
-  int rc = sigax_batch_create(ix, n_reads, n_reads ? offs[n_reads] : 0, 0, &b);
+  int rc = sigax_batch_create(ix, piece, 0, max_len, &b);
   if (rc != SIGAX_OK) return rc;
-  rc = sigax_batch_upload(b, seqs, offs, n_reads, nullptr);
-  if (rc == SIGAX_OK) rc = sigax_batch_run(b, read_base, min_overlap, flags, nullptr);
-  if (rc == SIGAX_OK) rc = sigax_batch_finish(b, nullptr, nullptr);
-  if (rc == SIGAX_OK) rc = sigax_batch_download(b, out);
+  if (piece == n_reads) {
+    rc = sigax_batch_upload(b, seqs, offs, n_reads, nullptr);
+    if (rc == SIGAX_OK) rc = sigax_batch_run(b, read_base, min_overlap, flags, nullptr);
+    if (rc == SIGAX_OK) rc = sigax_batch_finish(b, nullptr, nullptr);
+    if (rc == SIGAX_OK) rc = sigax_batch_download(b, out);
+    sigax_batch_destroy(b);
+    return rc;
+  }
+  out->n_reads = n_reads;
+  out->block_offs = (uint64_t*)malloc(((size_t)n_reads + 1) * 8);
+  out->substring = (uint8_t*)malloc(std::max<size_t>(1, n_reads));
+  size_t blk_cap = 0, edge_cap = 0;
+  u64 nblk = 0, nedge = 0;
+  if (!out->block_offs || !out->substring) rc = fail(SIGAX_E_ARG, "host allocation failed");
+  std::vector<uint64_t> po;
+  for (uint32_t lo = 0; rc == SIGAX_OK && lo < n_reads; lo += piece) {
+    const uint32_t n = std::min(piece, n_reads - lo);
+    po.resize((size_t)n + 1);
+    for (uint32_t i = 0; i <= n; ++i) po[i] = offs[lo + i] - offs[lo];
+    sigax_result part;
+    memset(&part, 0, sizeof(part));
+    rc = sigax_batch_upload(b, seqs + offs[lo], po.data(), n, nullptr);
+    if (rc == SIGAX_OK) rc = sigax_batch_run(b, read_base + lo, min_overlap, flags, nullptr);
+    if (rc == SIGAX_OK) rc = sigax_batch_finish(b, nullptr, nullptr);
+    if (rc == SIGAX_OK) rc = sigax_batch_download(b, &part);
+    if (rc != SIGAX_OK) break;
+    const u64 pb = part.block_offs[n], pe = part.n_edges;
+    if (nblk + pb > blk_cap) {
+      blk_cap = std::max<size_t>((size_t)(nblk + pb), blk_cap + blk_cap / 2);
+      void* q = realloc(out->blocks, std::max<size_t>(1, blk_cap) * sizeof(sigax_block));
+      if (!q) rc = fail(SIGAX_E_ARG, "host allocation failed");
+      else out->blocks = (sigax_block*)q;
+    }
+    if (rc == SIGAX_OK && nedge + pe > edge_cap) {
+      edge_cap = std::max<size_t>((size_t)(nedge + pe), edge_cap + edge_cap / 2);
+      void* q = realloc(out->edges, std::max<size_t>(1, edge_cap) * sizeof(sigax_edge));
+      if (!q) rc = fail(SIGAX_E_ARG, "host allocation failed");
+      else out->edges = (sigax_edge*)q;
+    }
+    if (rc == SIGAX_OK) {
+      for (uint32_t i = 0; i < n; ++i) out->block_offs[lo + i] = nblk + part.block_offs[i];
+      if (pb) memcpy(out->blocks + nblk, part.blocks, pb * sizeof(sigax_block));
+      if (pe) memcpy(out->edges + nedge, part.edges, pe * sizeof(sigax_edge));
+      memcpy(out->substring + lo, part.substring, n);
+      nblk += pb;
+      nedge += pe;
+      uint64_t* acc = (uint64_t*)&out->stats;
+      const uint64_t* add = (const uint64_t*)&part.stats;
+      for (size_t k = 0; k < sizeof(sigax_stats) / 8; ++k) acc[k] += add[k];
+    }
+    sigax_result_free(&part);
+  }
   sigax_batch_destroy(b);
-  return rc;
+  if (rc != SIGAX_OK) {
+    sigax_result_free(out);
+    return rc;
+  }
+  out->block_offs[n_reads] = nblk;
+  out->n_edges = nedge;
+  if (!out->blocks) out->blocks = (sigax_block*)malloc(sizeof(sigax_block));
+  if (!out->edges) out->edges = (sigax_edge*)malloc(sizeof(sigax_edge));
+  return SIGAX_OK;
 }

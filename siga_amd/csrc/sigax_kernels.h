@@ -27,6 +27,7 @@ enum {
   DS_W64_BASE = DS_SLOW_BASE + 8,  // [DS_W64_BASE + i]: (read, side) items sub-batch i queued for the 64-lane launch
   DS_SEC_FIND = DS_W64_BASE + 8,   // distinct 64-byte sectors of the rank tables the finder asked for, step by step
   DS_SEC_EXTRACT,                  // ... filter/extract, round by round
+  DS_MAX_CHAIN,                    // most candidate blocks any chain of the run pushed (also when its slots ran out)
   DS_PROF_BASE = 32,               // 32 diagnostic counters (builds with -DSIGAX_FX_PROFILE only)
   DS_W64B_BASE = 64,               // [DS_W64B_BASE + i], [DS_W64C_BASE + i]: items in the second and third queue between
   DS_W64C_BASE = 72,               // sub-batch i's filter/extract launches
@@ -42,6 +43,7 @@ struct FindArgs {
   const unsigned char* seqs;
   const unsigned long long* offs;
   uint32_t n_reads, minov, chain_mask, cap;  // chain_mask bit o = find o runs; cap = slots per chain, last = containment
+  uint32_t max_seen;                 // chains no longer than this need not report their length (DS_MAX_CHAIN)
   uint32_t read_begin, read_end;     // this launch's sub-batch
   uint32_t stage_bytes;              // dynamic LDS per workgroup that may hold the workgroup's reads (set by launch_find)
   uint32_t two_step;                 // both strands carry the two-step table (u32 positions only)
@@ -109,20 +111,29 @@ struct OrderArgs {
   unsigned long long out_cap;
   const void* arena;   // candidate records: a block whose `reserved` has bit 63 set carries (chain, slot) there instead
   uint32_t cap, wide;  // of its raw intervals, length and flags, which the scatter then takes from the candidate record
-};
-
-struct EdgeArgs {
-  const sigax_block* blocks;
-  const unsigned long long* block_offs;  // [n_reads+1]
-  uint32_t n_reads, read_base;
+  // edge records are counted on the way (per item), unless item_edges is NULL
+  uint32_t* item_edges;  // [n_items]
+  uint32_t read_base;
   const uint32_t* sai;
   const uint32_t* rsai;
   unsigned long long n_sai;
   const uint32_t* read_len;
   const uint32_t* name_rank;
-  uint32_t* edge_cnt;                    // per block (count pass); entries past the last block are zeroed
-  unsigned long long cnt_cap;
-  const unsigned long long* edge_offs;   // per block (fill pass)
+};
+
+struct EdgeArgs {
+  const sigax_block* blocks;             // ordered output
+  unsigned long long blocks_cap;
+  const unsigned long long* offs2;       // [n_items+1] first block of each (read, side) item
+  const uint32_t* fin_cnt;               // [n_items] its blocks
+  unsigned long long n_items;
+  uint32_t read_base;
+  const uint32_t* sai;
+  const uint32_t* rsai;
+  unsigned long long n_sai;
+  const uint32_t* read_len;
+  const uint32_t* name_rank;
+  const unsigned long long* edge_offs;   // [n_items+1] scan of the per-item counts of k_order_scatter
   sigax_edge* edges;
   unsigned long long edge_cap;
 };
@@ -157,20 +168,24 @@ unsigned long long scan_partials_needed(unsigned long long n);
 // partial = scan_partials_needed(n/64+1) u64, total = 1 u64 of scratch.
 void launch_build2(const FmStrand& s, bool wide, uint32_t* gran2, unsigned long long* super2, uint32_t* cnt, unsigned long long* offs, unsigned long long* partial,
                    unsigned long long* total, hipStream_t st);
-// Row-end table of one strand (fm_layout.h): out = n u64, zeroed by the caller; la = n u64 for the look-ahead table, or NULL
-void launch_rowend_build(const FmStrand& s, bool wide, unsigned long long n_strings, unsigned long long* out, unsigned long long* la,
-                         hipStream_t st);
+// Row table + stretch text of one strand (fm_layout.h), two walks over every stretch (n_stretch = C['A'] of them):
+// launch_stretch_scan fills info[n_stretch] and *maxlen (zeroed by the caller) = the longest stretch, from which the caller
+// sizes the entries; launch_rows_fill writes the table (zeroed by the caller, n * sa_bits bits + 16 bytes) and, unless NULL,
+// the text rows.
+void launch_stretch_scan(const FmStrand& s, bool wide, unsigned long long n_stretch, unsigned long long* info, uint32_t* maxlen, hipStream_t st);
+void launch_rows_fill(const FmStrand& s, bool wide, unsigned long long n_stretch, const unsigned long long* info, unsigned char* sa,
+                      uint32_t sa_bits, uint32_t ld_bits, uint32_t t_bits, unsigned char* text, uint32_t text_stride, hipStream_t st);
 void launch_order_scatter(const OrderArgs& a, hipStream_t st);
 unsigned long long fast_fin_chunk();
 unsigned long long cand_bytes(bool wide);
 void launch_pick_read_offsets(const unsigned long long* offs2, unsigned long long n_reads, unsigned long long* block_offs,
                               hipStream_t st);
-void launch_edges(const EdgeArgs& a, bool fill, unsigned long long max_blocks, hipStream_t st);
+void launch_edges_fill(const EdgeArgs& a, hipStream_t st);
 // sigax_index_build.hip: locality order of a batch's reads (a permutation inside each of the nsub slot ranges bounds[0..nsub]),
-// queued on `st` without a host wait.  keys = 2 n u64, vals = 2 n u32 of scratch; *result = the half of vals that will hold
+// queued on `st` without a host wait.  keys = 2 n u32, vals = 2 n u32 of scratch; *result = the half of vals that will hold
 // the order once the stream gets there.
 size_t sigax_order_reads_tmp_bytes(uint32_t n);
 int sigax_order_reads(const unsigned char* d_seqs, const unsigned long long* d_offs, uint32_t n, const uint32_t* bounds, uint32_t nsub,
-                      unsigned long long* keys, uint32_t* vals, void* tmp, size_t tmp_bytes, const uint32_t** result, hipStream_t st);
+                      uint32_t* keys, uint32_t* vals, void* tmp, size_t tmp_bytes, const uint32_t** result, hipStream_t st);
 
 #endif

@@ -349,10 +349,12 @@ __global__ __launch_bounds__(256) void k_kmer_count(FmStrand s, const unsigned c
 }
 
 // -------------------------------------------------------------------------------------------------------
-// k_rowend_build: the row-end table of fm_layout.h.  One lane per symbol of rank 0 in the text (a read's terminator, or a
-// non-ACGT base, which the index stores as rank 0 too: alphabet.h:19-39): from the row of the suffix that starts there (rows
-// 0 .. C['A']-1) walk backwards (LF) to the row whose BWT symbol has rank 0, once to learn the distance and Occ('$') there,
-// once more to write (steps still to go, that Occ) at every row passed.  Every row lies on exactly one such walk.
+// Row table + stretch text of fm_layout.h.  One lane per symbol of rank 0 in the text (a read's terminator, or a non-ACGT
+// base, which the index stores as rank 0 too: alphabet.h:19-39): from the row of the suffix that starts there (rows
+// 0 .. C['A']-1) walk backwards (LF) to the row whose BWT symbol has rank 0.  k_stretch_scan learns the distance and
+// Occ('$') there (and the longest distance of the index, which sizes the entries); k_rows_fill walks again and writes
+// (steps still to go, that Occ) at every row passed and the symbols passed into the stretch's text row.  Every row lies on
+// exactly one such walk.
 // -------------------------------------------------------------------------------------------------------
 template <bool WIDE>
 __device__ __forceinline__ u32 lf_row(const FmRef& f, const u64* C, u64 p, u64* next) {
@@ -362,45 +364,106 @@ __device__ __forceinline__ u32 lf_row(const FmRef& f, const u64* C, u64 p, u64* 
   else *next = C[c] + (c == 1 ? k.a : c == 2 ? k.c : c == 3 ? k.g : k.t);
   return c;
 }
-// With `la` the same walk also fills the look-ahead table (fm_layout.h): a window of the last ten (row, symbol) pairs
-// slides along; when the eleventh row arrives, the oldest one's entry = its ten symbols + that eleventh row is complete.
+#define STRETCH_BAD (~0ull)  // not a BWT of '$'-terminated reads: the walk did not end
 template <bool WIDE>
-__global__ __launch_bounds__(256) void k_rowend_build(FmStrand s, u64 n_strings, u64* out, u64* la) {  // la: interleaved, see fm_layout.h
-  const u64 stride = la != nullptr ? 2u : 1u;
+__global__ __launch_bounds__(256) void k_stretch_scan(FmStrand s, u64 n_stretch, u64* info, u32* maxlen) {
   const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
-  if (j >= n_strings) return;
+  u32 mine = 0;
+  if (j < n_stretch) {
+    const FmRef f = fm_ref(s, 0);
+    const u64 C[5] = {s.C[0], s.C[1], s.C[2], s.C[3], s.C[4]};
+    u64 p = j, len = 0, v = STRETCH_BAD;
+    for (;;) {
+      u64 q;
+      if (lf_row<WIDE>(f, C, p, &q) == 0) { v = (len << 32) | (q & 0xFFFFFFFFull); break; }
+      p = q;
+      if (++len >= s.n || len >= (1ull << 28)) { len = 0; break; }
+    }
+    info[j] = v;
+    mine = (u32)len;
+  }
+  for (int off = 32; off > 0; off >>= 1) mine = max(mine, (u32)__shfl_xor((int)mine, off, 64));
+  if ((threadIdx.x & 63u) == 0 && mine) atomicMax(maxlen, mine);
+}
+// entry p of a bit-packed table of `bits`-bit values (zeroed before): set / get
+__device__ __forceinline__ void packed_or(unsigned char* tab, u64 p, u32 bits, u64 v) {
+  const u64 B = p * bits;
+  u64* w = reinterpret_cast<u64*>(tab) + (B >> 6);
+  const u32 sh = (u32)B & 63u;
+  atomicOr(w, v << sh);
+  if (sh + bits > 64u) atomicOr(w + 1, v >> (64u - sh));
+}
+__device__ __forceinline__ u64 packed_get(const unsigned char* tab, u64 p, u32 bits) {
+  const u64 B = p * bits;
+  u64 v;
+  __builtin_memcpy(&v, tab + (B >> 3), 8);  // one unaligned 8-byte load (the table is padded by 8 bytes)
+  return (v >> ((u32)B & 7u)) & ((1ull << bits) - 1ull);
+}
+// (stretch, offset) of the suffix at `row` of a strand that has the row table; returns the entry's symbols (fm_layout.h)
+__device__ __forceinline__ u64 row_lookup(const FmStrand& st, u64 row, u32& ld, u32& t) {
+  const u64 v = packed_get(st.sa, row < st.n ? row : 0ull, st.sa_bits);  // never leave the table, whatever a block holds
+  ld = (u32)(v & ((1ull << st.ld_bits) - 1ull));
+  t = (u32)(v >> st.ld_bits) & ((1u << st.t_bits) - 1u);
+  return v >> (st.ld_bits + st.t_bits);
+}
+// The symbols on the backward path from offset t of stretch ld, 2 bits each (rank - 1), next one in the top two bits:
+// offsets t-1, t-2, ... -- at least SIGAX_TEXT_WINDOW of them, or all t (the caller knows from t where the read ends).
+__device__ __forceinline__ u64 text_window(const FmStrand& st, u32 ld, u32 t) {
+  if (t == 0) return 0ull;
+  const u32 end = 2u * t;                                  // the row's bits [0, end) hold offsets 0 .. t-1
+  const u32 b = end > 64u ? (end - 64u + 7u) >> 3 : 0u;  // first byte of the 8 that end at or past bit `end`
+  u64 w;
+  __builtin_memcpy(&w, st.text + (u64)ld * st.text_stride + b, 8);  // rows are padded (fm_layout.h)
+  return w << (64u - (end - 8u * b));
+}
+#define ROWS_KMAX 14  // most symbols an entry can carry (fm_layout.h)
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_rows_fill(FmStrand s, u64 n_stretch, const u64* info, unsigned char* sa, u32 sa_bits, u32 ld_bits, u32 t_bits,
+                                                   unsigned char* text, u32 text_stride) {
+  const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_stretch) return;
+  const u64 v = info[j];
+  if (v == STRETCH_BAD) return;  // rows of such a walk keep entry 0: "ends here, stretch 0" is never consulted then
   const FmRef f = fm_ref(s, 0);
   const u64 C[5] = {s.C[0], s.C[1], s.C[2], s.C[3], s.C[4]};
-  u64 p = j, len = 0, ld = 0;
-  for (;;) {
-    u64 q;
-    if (lf_row<WIDE>(f, C, p, &q) == 0) { ld = q; break; }
-    p = q;
-    if (++len >= s.n) return;  // not a BWT of '$'-terminated reads: leave the rows unwritten (zero: "ends here" is never used then)
-  }
-  p = j;
-  u64 R[SIGAX_LA_SYMS];
-  u32 w = 0, vm = 0;  // symbols of R[0..9] (3 bits each, R[0] lowest); which of R[] hold rows of this walk
+  const u64 ld = v & 0xFFFFFFFFull;
+  const u32 K = (sa_bits - ld_bits - t_bits) >> 1;  // symbols carried by an entry
+  u64 p = j;
+  unsigned char* trow = text ? text + ld * text_stride : nullptr;
+  // A window of the last ROWS_KMAX rows slides along: when the K-th symbol after a row has been seen its entry is complete
+  // (R[ROWS_KMAX - 1] = the newest row; wsym = the symbols seen as rank - 1, newest in the lowest two bits, so the K
+  // symbols that follow the row K places back read first-symbol-highest: the order text_window() hands them out in).
+  u64 R[ROWS_KMAX];
+  u32 wsym = 0, vm = 0;
 #pragma unroll
-  for (int i = 0; i < SIGAX_LA_SYMS; ++i) R[i] = 0;
-  auto insert = [&](u64 row, u32 c, bool real) {
-    if (la != nullptr && (vm & 1u)) la[2 * R[0]] = (u64)w | (row << SIGAX_LA_ROW_SHIFT);
+  for (int i = 0; i < ROWS_KMAX; ++i) R[i] = 0;
+  auto insert = [&](u64 row, u32 c, bool real, u64 t_of_row) {
 #pragma unroll
-    for (int i = 0; i + 1 < SIGAX_LA_SYMS; ++i) R[i] = R[i + 1];
-    R[SIGAX_LA_SYMS - 1] = row;
-    w = (w >> 3) | (c << (3 * (SIGAX_LA_SYMS - 1)));
-    vm = (vm >> 1) | (real ? (1u << (SIGAX_LA_SYMS - 1)) : 0u);
+    for (int i = 0; i + 1 < ROWS_KMAX; ++i) R[i] = R[i + 1];
+    R[ROWS_KMAX - 1] = row;
+    wsym = (wsym << 2) | ((c - 1u) & 3u);
+    vm = (vm << 1) | (real ? 1u : 0u);
+    if (K == 0) return;
+    u64 r0 = R[0];
+#pragma unroll
+    for (int i = 1; i < ROWS_KMAX; ++i)
+      if ((u32)(ROWS_KMAX - i) == K) r0 = R[i];
+    if ((vm >> (K - 1u)) & 1u) {
+      const u64 syms = (u64)wsym & ((1ull << (2u * K)) - 1ull);
+      packed_or(sa, r0, sa_bits, (syms << (ld_bits + t_bits)) | ((t_of_row + (K - 1u)) << ld_bits) | ld);
+    }
   };
-  for (u64 t = len;; --t) {
-    out[p * stride] = (t << 32) | (ld & 0xFFFFFFFFull);
+  for (u64 t = v >> 32;; --t) {
+    if (K == 0) packed_or(sa, p, sa_bits, (t << ld_bits) | ld);
     u64 q;
-    const u32 c = lf_row<WIDE>(f, C, p, &q);  // rank 0 exactly when t == 0
-    insert(p, c, true);
+    const u32 c = lf_row<WIDE>(f, C, p, &q);  // the symbol at offset t - 1; rank 0 exactly when t == 0
+    insert(p, c, true, t);
     if (t == 0) break;
+    if (trow) packed_or(trow, t - 1, 2u, (u64)((c - 1u) & 3u));  // offset t - 1 at bits 2 (t - 1) .. of the stretch's own (zeroed) row
     p = q;
   }
-  if (la != nullptr)
-    for (int i = 0; i < SIGAX_LA_SYMS; ++i) insert(0, 0, false);
+  // the rows whose K symbols run past the read's first base: rank 0 from there on (t counts on below zero for the formula)
+  for (u32 i = 1; i < K; ++i) insert(0, 0, false, 0ull - i);
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -929,14 +992,20 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
   }
   find_flush(sg, contain, tid);
   if (inr) {
-    u32 word = (nb & SIGAX_CC_COUNT_MASK) | (flagbits & (SIGAX_CC_SUBSTRING | SIGAX_CC_CONTAIN));
+    // a chain that ran out of slots (the host repeats the run with more) has records parked and never written: its
+    // readers get an empty chain
+    const u32 nbw = (flagbits & 1u) ? 0u : nb;
+    u32 word = (nbw & SIGAX_CC_COUNT_MASK) | (flagbits & (SIGAX_CC_SUBSTRING | SIGAX_CC_CONTAIN));
     A.chain_cnt[(u64)read * 4 + o] = word;
   }
   u64 tot_occ = wave_sum((u64)nocc);
   u64 tot_blk = wave_sum((u64)nb + ((flagbits & SIGAX_CC_CONTAIN) ? 1u : 0u));
   u64 tot_err = wave_sum((u64)(flagbits & 1u));
   u64 tot_sec = (u64)nsec + wave_sum((u64)tail_sec);
+  u32 mx = nb;  // the longest chain of the launch: what the host sizes the next run's slots by (sigax_api.cpp)
+  for (int off = 32; off > 0; off >>= 1) mx = max(mx, (u32)__shfl_xor((int)mx, off, 64));
   if ((threadIdx.x & 63) == 0) {
+    if (mx > A.max_seen) atomicMax(&A.dstat[DS_MAX_CHAIN], (u64)mx);
     if (tot_sec) atomicAdd(&A.dstat[DS_SEC_FIND], tot_sec);
     if (tot_occ) atomicAdd(&A.dstat[DS_OCC_FIND], tot_occ);
     if (tot_blk) atomicAdd(&A.dstat[DS_CAND_BLOCKS], tot_blk);
@@ -1452,11 +1521,12 @@ struct Fx {
                   for (u32 j = 0; j < cnt; ++j) pool[top + j] = pool[off + j];
                   u32 c2 = updateR_list(top, cnt, (u32)k);
                   if (c2 == 1 && pool[top].c1lo == pool[top].c1hi) {
-                    const u64* re = (pool[top].src / A.cap) < 2 ? A.rev.rowend : A.fwd.rowend;  // ext_index()
-                    if (re != nullptr) {
-                      const u64 v = re[pool[top].c1lo * A.fwd.re_stride];
-                      pool[top].c1lo = v & 0xFFFFFFFFull;
-                      pool[top].c1hi = v >> 32;
+                    const FmStrand& xs = (pool[top].src / A.cap) < 2 ? A.rev : A.fwd;  // ext_index()
+                    if (xs.sa != nullptr) {
+                      u32 ld, t;
+                      row_lookup(xs, pool[top].c1lo, ld, t);
+                      pool[top].c1lo = ld;
+                      pool[top].c1hi = t;
                       c2 |= FX_COUNTDOWN;
                     }
                   }
@@ -1801,10 +1871,10 @@ struct GFx {
   u32 gD, gI;
   bool inreg;     // this item's groups are disjoint lane sets: no pool traffic
   bool toowide;   // body() gave up because the item has more blocks than the group has lanes
-  // TEXT: this lane's block on its backward path: the symbols ahead, how many of them are used up, the row ten steps on,
-  // and from the row-end table Occ('$') at the path's end and the rounds until then
-  u32 tsyms, tk, tld, ttt;
-  u64 tjump;
+  // TEXT: this lane's block on its backward path: the symbols ahead (next one in the top nibble), how many of the window
+  // are used up, and from the row table its stretch = Occ('$') at the path's end and the rounds until then
+  u64 tw;
+  u32 tk, tld, ttt;
 #ifdef SIGAX_FX_PROFILE
   u32 dbg_round;
 #endif
@@ -1812,11 +1882,12 @@ struct GFx {
   enum { RD_ENDED = 0, RD_UPDATED, RD_BRANCHED, RD_BAIL, RD_XERROR };
 
   __device__ void to_countdown(E& e) const {
-    const u64* re = find_of(e.src) < 2 ? A.rev.rowend : A.fwd.rowend;
-    if (re != nullptr) {
-      const u64 v = re[(u64)e.c1lo * A.fwd.re_stride];
-      e.c1lo = (P)(v & 0xFFFFFFFFull);
-      e.c1hi = (P)(v >> 32);
+    const FmStrand& xs = find_of(e.src) < 2 ? A.rev : A.fwd;
+    if (xs.sa != nullptr) {
+      u32 ld, t;
+      row_lookup(xs, (u64)e.c1lo, ld, t);
+      e.c1lo = (P)ld;
+      e.c1hi = (P)t;
       e.len |= FX_COUNTDOWN;
     }
   }
@@ -2248,17 +2319,14 @@ struct GFx {
     const bool mine = (alive >> gl) & 1ull;
     const u32 first = ffs0(alive);
     FXP(0);
-    if (gshfl(tk, first) >= (u32)SIGAX_LA_SYMS) {  // the group has used its ten symbols (all its lanes step together)
+    if (gshfl(tk, first) >= (u32)SIGAX_TEXT_WINDOW) {  // the group has used its window (all its lanes step together)
       if (mine) {
-        const u64* la = find_of(e.src) < 2 ? A.rev.la : A.fwd.la;
-        const u64 v = la[2 * tjump];
-        tsyms = (u32)v & SIGAX_LA_SYM_MASK;
-        tjump = v >> SIGAX_LA_ROW_SHIFT;
+        tw = text_window(find_of(e.src) < 2 ? A.rev : A.fwd, tld, ttt);
         tk = 0;
       }
       sec_add(pop(alive));
     }
-    const u32 c = (tsyms >> (3u * tk)) & 7u;
+    const u32 c = ttt ? 1u + (u32)(tw >> 62) : 0u;  // the read's bases hold no rank 0; past its first base everything is
     const bool qcomp = (af_of(e.src) & 4u) != 0;
     const u32 cq = (qcomp && c) ? 5u - c : c;
     const bool x0 = mine && c == 0u;
@@ -2291,7 +2359,7 @@ struct GFx {
     const u32 cfirst = gshfl(cq, first);
     if (gballot(mine && cq != cfirst) == 0) {
       nocc += 2u * pop(alive);
-      if (mine) { ++tk; --ttt; }
+      if (mine) { tw <<= 2; ++tk; --ttt; }
       *newAlive = alive;
       return RD_UPDATED;
     }
@@ -2301,7 +2369,7 @@ struct GFx {
     const u32 nb = (m1 != 0) + (m2 != 0) + (m3 != 0) + (m4 != 0);
     if (nslot + nb > NSLOT || ni + nb > NSLOT) return RD_BAIL;
     nocc += 2u * pop(alive);
-    if (mine) { ++tk; --ttt; }
+    if (mine) { tw <<= 2; ++tk; --ttt; }
     FXP(5);
 #pragma unroll
     for (u32 sy = 1; sy <= 4; ++sy) {
@@ -2333,18 +2401,20 @@ struct GFx {
     inreg = gballot(gl < n && e.c1hi != e.c1lo) == 0;  // every block a single row (ranges never grow)
     if (TEXT) {
       if (!inreg) return false;
-      u64 v = 0, w = 0;
-      if (gl < n) {
-        const ulonglong2 pr = reinterpret_cast<const ulonglong2*>(find_of(e.src) < 2 ? A.rev.la : A.fwd.la)[(u64)e.c1lo];
-        v = pr.x;  // look-ahead entry and row-end entry of a row sit side by side
-        w = pr.y;
+      tw = 0;
+      tk = tld = ttt = 0;
+      {
+        // the entry's own symbols serve the first rounds (a window that is used up after that many); without them the
+        // first text window is loaded at once
+        const FmStrand& xs = find_of(e.src) < 2 ? A.rev : A.fwd;
+        const u32 K = (xs.sa_bits - xs.ld_bits - xs.t_bits) >> 1;
+        if (gl < n) {
+          const u64 syms = row_lookup(xs, (u64)e.c1lo, tld, ttt);
+          tw = K ? syms << (64u - 2u * K) : text_window(xs, tld, ttt);
+        }
+        tk = K ? (u32)SIGAX_TEXT_WINDOW - K : 0u;
+        sec_add(K ? n : 2u * n);
       }
-      tsyms = (u32)v & SIGAX_LA_SYM_MASK;
-      tjump = v >> SIGAX_LA_ROW_SHIFT;
-      tk = 0;
-      tld = (u32)w;
-      ttt = (u32)(w >> 32);
-      sec_add(n);
     }
 #ifdef SIGAX_FX_PROFILE
     dbg_round = 0;
@@ -3236,76 +3306,80 @@ __device__ __forceinline__ void order_fill_from_cand(const OrderArgs& A, u64 ite
   v3 = make_ulonglong2((u64)b.r1lo, (u64)b.r1lo + b.sz - 1);
   v4 = make_ulonglong2((u64)b.len | ((u64)b.af << 32), 0ull);
 }
+// Hit2OverlapConverter::convert's test for one (query, target) pair (src/overlap_builder.cpp:358,365)
+__device__ __forceinline__ bool edge_kept(const uint32_t* name_rank, const uint32_t* read_len, u32 q, u32 t, u32 len, u32 af) {
+  u32 nq = name_rank[q], nt = name_rank[t];
+  if (nq == nt) return false;                       // query.name != target.name (:358)
+  bool contained = (len == read_len[q]) || (len == read_len[t]);  // Match::isContainment (coord.h:150-152)
+  if (nq < nt || (contained && (af & 1u))) return false;              // dedup rule (:365)
+  return true;
+}
+// While a block is on its way to its place, its edge records are counted (the block and its .sai range are in registers;
+// the item knows its read): the item's total goes to item_edges, whose scan gives k_edges_fill the item's place in the
+// edge list.  Round 2 counted per block in a pass of its own that found each block's read by binary search.
 __global__ __launch_bounds__(256) void k_order_scatter(OrderArgs A) {
   u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
   if (w >= A.n_items) return;
   u32 cnt = A.fin_cnt[w];
-  if (!cnt) return;
-  u64 srcb = A.item_base[w], dstb = A.offs2[w];
-  for (u32 i = 0; i < cnt; ++i) {
-    if (srcb + i >= A.fin_cap || dstb + i >= A.out_cap) return;  // only after an overflow, whose results the host discards
-    const ulonglong2* s = reinterpret_cast<const ulonglong2*>(A.fin + srcb + i);
-    ulonglong2* d = reinterpret_cast<ulonglong2*>(A.out + dstb + i);
-    ulonglong2 v0 = s[0], v1 = s[1], v4 = s[4];
-    ulonglong2 v2, v3;
-    if (v4.y >> 63) {
-      if (A.wide) order_fill_from_cand<true>(A, w, (u32)v4.y, v2, v3, v4);
-      else order_fill_from_cand<false>(A, w, (u32)v4.y, v2, v3, v4);
-    } else {
-      v2 = s[2]; v3 = s[3];
-    }
-    d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3; d[4] = v4;
-  }
-}
-
-// -------------------------------------------------------------------------------------------------------
-// edges: Hit2OverlapConverter::convert (overlap_builder.cpp:345-375), one lane per final block
-// -------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool edge_kept(const EdgeArgs& A, u32 q, u32 t, u32 len, u32 af) {
-  u32 nq = A.name_rank[q], nt = A.name_rank[t];
-  if (nq == nt) return false;                       // query.name != target.name (:358)
-  bool contained = (len == A.read_len[q]) || (len == A.read_len[t]);  // Match::isContainment (coord.h:150-152)
-  if (nq < nt || (contained && (af & 1u))) return false;              // dedup rule (:365)
-  return true;
-}
-
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_edges(EdgeArgs A) {
-  u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-  u64 nblocks = A.block_offs[A.n_reads];
-  // after an overflow of the final-block arena the scanned total exceeds what `blocks`, `edge_cnt` and `edge_offs` hold
-  // (the host discards that run and repeats it with larger arenas): stay inside them
-  if (nblocks > A.cnt_cap) nblocks = A.cnt_cap;
-  if (i >= nblocks) {
-    if (!FILL && i < A.cnt_cap) A.edge_cnt[i] = 0;
-    return;
-  }
-  // which read owns block i: binary search in block_offs
-  u32 lo = 0, hi = A.n_reads;
-  while (hi - lo > 1) {
-    u32 mid = lo + (hi - lo) / 2;
-    if (A.block_offs[mid] <= i) lo = mid; else hi = mid;
-  }
-  u32 q = A.read_base + lo;
-  const sigax_block& b = A.blocks[i];
-  const u32* sa = (b.af & 2u) ? A.rsai : A.sai;
-  u64 w = FILL ? A.edge_offs[i] : 0;
   u32 kept = 0;
-  for (u64 j = b.capped0_lo; j <= b.capped0_hi && j < A.n_sai; ++j) {
-    u32 t = sa[j];
-    if (edge_kept(A, q, t, b.length, b.af)) {
-      if (FILL) {
-        if (w < A.edge_cap) {
-          sigax_edge e;
-          e.query = q; e.target = t; e.length = b.length; e.af = b.af;
-          A.edges[w] = e;
-        }
-        ++w;
+  if (cnt) {
+    u64 srcb = A.item_base[w], dstb = A.offs2[w];
+    const u32 q = A.read_base + (u32)(w >> 1);
+    for (u32 i = 0; i < cnt; ++i) {
+      if (srcb + i >= A.fin_cap || dstb + i >= A.out_cap) break;  // only after an overflow, whose results the host discards
+      const ulonglong2* s = reinterpret_cast<const ulonglong2*>(A.fin + srcb + i);
+      ulonglong2* d = reinterpret_cast<ulonglong2*>(A.out + dstb + i);
+      ulonglong2 v0 = s[0], v1 = s[1], v4 = s[4];
+      ulonglong2 v2, v3;
+      if (v4.y >> 63) {
+        if (A.wide) order_fill_from_cand<true>(A, w, (u32)v4.y, v2, v3, v4);
+        else order_fill_from_cand<false>(A, w, (u32)v4.y, v2, v3, v4);
+      } else {
+        v2 = s[2]; v3 = s[3];
       }
-      ++kept;
+      d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3; d[4] = v4;
+      if (A.item_edges != nullptr) {
+        const u32 len = (u32)v4.x, af = (u32)(v4.x >> 32);
+        const u32* sa = (af & 2u) ? A.rsai : A.sai;
+        for (u64 j = v0.x; j <= v0.y && j < A.n_sai; ++j)
+          if (edge_kept(A.name_rank, A.read_len, q, sa[j], len, af)) ++kept;
+      }
     }
   }
-  if (!FILL) A.edge_cnt[i] = kept;
+  if (A.item_edges != nullptr) A.item_edges[w] = kept;
+}
+
+// -------------------------------------------------------------------------------------------------------
+// edges: Hit2OverlapConverter::convert (overlap_builder.cpp:345-375), one lane per (read, side) item: its blocks are
+// consecutive in the ordered output, its records consecutive in the edge list (hits order = the ED order at -t 1)
+// -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_edges_fill(EdgeArgs A) {
+  const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (w >= A.n_items) return;
+  const u32 cnt = A.fin_cnt[w];
+  if (!cnt) return;
+  u64 e = A.edge_offs[w];
+  if (A.edge_offs[w + 1] == e) return;  // no record from this item (most items: the self-containment blocks)
+  const u64 first = A.offs2[w];
+  const u32 q = A.read_base + (u32)(w >> 1);
+  for (u32 i = 0; i < cnt; ++i) {
+    if (first + i >= A.blocks_cap) return;  // only after an overflow, whose results the host discards
+    const ulonglong2* s = reinterpret_cast<const ulonglong2*>(A.blocks + first + i);
+    const ulonglong2 v0 = s[0], v4 = s[4];
+    const u32 len = (u32)v4.x, af = (u32)(v4.x >> 32);
+    const u32* sa = (af & 2u) ? A.rsai : A.sai;
+    for (u64 j = v0.x; j <= v0.y && j < A.n_sai; ++j) {
+      const u32 t = sa[j];
+      if (edge_kept(A.name_rank, A.read_len, q, t, len, af)) {
+        if (e < A.edge_cap) {
+          sigax_edge rec;
+          rec.query = q; rec.target = t; rec.length = len; rec.af = af;
+          A.edges[e] = rec;
+        }
+        ++e;
+      }
+    }
+  }
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -3414,7 +3488,7 @@ static void launch_fx_stages(const FxArgs& a, unsigned grid32, unsigned grid64, 
   }
   // queue 0: items for the branching 32-lane launch; queue 1: for the branching 64-lane launch; queue 2: for the full one
   static const bool no_text = getenv("SIGAX_FX_NO_TEXT") != nullptr;  // A/B aid
-  if (a.fwd.la && a.rev.la && a.fwd.rowend && a.rev.rowend && !no_text) {
+  if (a.fwd.text && a.rev.text && a.fwd.sa && a.rev.sa && !no_text) {
     if (!a.no_lean) { route(); stage(k_filter_extract_fast<WIDE, 32, 5>, grid32, -1, 0, -1); }
     stage(k_filter_extract_fast<WIDE, 32, 6>, grid32, a.no_lean ? -1 : 0, 1, -1);
     stage(k_filter_extract_fast<WIDE, 64, 6>, grid64, 1, 2, -1);
@@ -3465,10 +3539,16 @@ void launch_build2(const FmStrand& s, bool wide, u32* gran2, u64* super2, u32* c
   }
 }
 
-void launch_rowend_build(const FmStrand& s, bool wide, u64 n_strings, u64* out, u64* la, hipStream_t st) {  // n_strings: rows of rank-0 suffixes
-  if (n_strings == 0) return;
-  if (wide) hipLaunchKernelGGL(k_rowend_build<true>, dim3(nblk(n_strings, 256)), dim3(256), 0, st, s, n_strings, out, la);
-  else hipLaunchKernelGGL(k_rowend_build<false>, dim3(nblk(n_strings, 256)), dim3(256), 0, st, s, n_strings, out, la);
+void launch_stretch_scan(const FmStrand& s, bool wide, u64 n_stretch, u64* info, u32* maxlen, hipStream_t st) {
+  if (n_stretch == 0) return;
+  if (wide) hipLaunchKernelGGL(k_stretch_scan<true>, dim3(nblk(n_stretch, 256)), dim3(256), 0, st, s, n_stretch, info, maxlen);
+  else hipLaunchKernelGGL(k_stretch_scan<false>, dim3(nblk(n_stretch, 256)), dim3(256), 0, st, s, n_stretch, info, maxlen);
+}
+void launch_rows_fill(const FmStrand& s, bool wide, u64 n_stretch, const u64* info, unsigned char* sa, u32 sa_bits, u32 ld_bits, u32 t_bits,
+                      unsigned char* text, u32 text_stride, hipStream_t st) {
+  if (n_stretch == 0) return;
+  if (wide) hipLaunchKernelGGL(k_rows_fill<true>, dim3(nblk(n_stretch, 256)), dim3(256), 0, st, s, n_stretch, info, sa, sa_bits, ld_bits, t_bits, text, text_stride);
+  else hipLaunchKernelGGL(k_rows_fill<false>, dim3(nblk(n_stretch, 256)), dim3(256), 0, st, s, n_stretch, info, sa, sa_bits, ld_bits, t_bits, text, text_stride);
 }
 
 u64 scan_partials_needed(u64 n) { return (n + 1 + SCAN_ITEMS - 1) / SCAN_ITEMS + 1; }
@@ -3482,8 +3562,7 @@ void launch_order_scatter(const OrderArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_order_scatter, dim3(nblk(a.n_items, 256)), dim3(256), 0, st, a);
 }
 
-void launch_edges(const EdgeArgs& a, bool fill, u64 max_blocks, hipStream_t st) {
-  if (max_blocks == 0) return;
-  if (fill) hipLaunchKernelGGL(k_edges<true>, dim3(nblk(max_blocks, 256)), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k_edges<false>, dim3(nblk(max_blocks, 256)), dim3(256), 0, st, a);
+void launch_edges_fill(const EdgeArgs& a, hipStream_t st) {
+  if (a.n_items == 0) return;
+  hipLaunchKernelGGL(k_edges_fill, dim3(nblk(a.n_items, 256)), dim3(256), 0, st, a);
 }

@@ -90,6 +90,15 @@ def read_sequences(path):
     return out
 
 
+def _copy_records(ptr, n, dtype):
+    """n records of `dtype` at the C pointer `ptr` -> an owned numpy array (ctypes.string_at stops at 2 GiB: one rank's shard
+    of BASELINE configs[4] returns 27 M blocks of 80 bytes)"""
+    out = np.empty(n, dtype=dtype)
+    if n:
+        C.memmove(out.ctypes.data, ptr, n * dtype.itemsize)
+    return out
+
+
 class FMIndexPair:
     """Both FM-indexes (+ .sai tables) resident on one GPU."""
 
@@ -190,10 +199,10 @@ class OverlapBuilder:
             n = res.n_reads
             block_offs = np.ctypeslib.as_array(res.block_offs, shape=(n + 1,)).copy()
             nb = int(block_offs[-1])
-            blocks = np.frombuffer(C.string_at(res.blocks, nb * BLOCK_DTYPE.itemsize), dtype=BLOCK_DTYPE).copy()
+            blocks = _copy_records(res.blocks, nb, BLOCK_DTYPE)
             substring = np.ctypeslib.as_array(res.substring, shape=(max(n, 1),))[:n].copy()
             ne = int(res.n_edges)
-            eds = np.frombuffer(C.string_at(res.edges, ne * EDGE_DTYPE.itemsize), dtype=EDGE_DTYPE).copy()
+            eds = _copy_records(res.edges, ne, EDGE_DTYPE)
             stats = res.stats.as_dict()
         finally:
             _lib.lib().sigax_result_free(C.byref(res))

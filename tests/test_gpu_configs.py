@@ -5,9 +5,10 @@ C1  E. coli MiSeq shape: `siga index` -> `siga overlap -m 85` through the CLI on
     (real MiSeq data is not available offline), ASQG bytes == the oracle's.
 C3  20 M x 150 bp from a 100 Mb genome: the 8-GPU job's index (3.02e9 symbols, u32 positions, beyond the two-step
     table's range), one rank's shard of reads on this GPU.
-C5  50 M x 250 bp shape, cut to the smallest read set whose index needs 64-bit positions (17.2 M x 250 bp = 4.32e9
-    symbols; the full 1.255e10-symbol set differs in size only): the WIDE kernels and superblock counters on a real
-    index, one shard of reads.
+C5  50 M x 250 bp from a 230 Mb genome (the stand-in for chr1), seed 3: the FULL configuration -- index
+    of 1.255e10 symbols per strand with 64-bit positions (WIDE kernels, superblock counters), built on the GPU, 190 GB of
+    tables on the device (rank granules, two-step lines, bare 34-bit row-table entries + text: the entries with symbols do
+    not fit), rank 0's shard of 8 = 6.25 M reads through sigax_overlap_batch in pieces.
 For C3/C5 the oracle checks a random sample of the shard read by read (it runs from the same index files), and the
 shard is checked whole through size-independent properties: idempotence, invariance under re-sharding (read_base),
 self-containment blocks, dedup rule and order of the edge records, N_occ_min additivity."""
@@ -141,8 +142,7 @@ def test_c3_shape_index_3e9_symbols_one_shard():
     assert info["n_symbols"] == 20000000 * 151 and info["wide"] == 0
 
 
-def test_c5_shape_wide_index_one_shard():
-    # the smallest 250 bp read set whose BWT needs 64-bit positions, at C5's coverage (54x); shard = 1/32 of the reads
-    N = 17200000
-    info = _big_case("c5", N, 80000000, 250, 3, world=32, sample=10000)
+def test_c5_full_size_wide_index_one_shard_of_eight():
+    N = 50000000
+    info = _big_case("c5", N, 230000000, 250, 3, world=8, sample=10000)
     assert info["n_symbols"] == N * 251 >= 2**32 and info["wide"] == 1

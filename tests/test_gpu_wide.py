@@ -55,18 +55,45 @@ def test_arena_regrow_and_rerun():
     _run_parity({"SIGAX_TEST_POOL_CAP": "24", "SIGAX_GENERAL_ONLY": "1", "SIGAX_TEST_FIN_CAP": "100"}, "hits_and_asqg and (toy or rep or corner)")
 
 
+def test_candidate_slots_sized_by_the_batch_and_overlap_in_pieces():
+    """The candidate arena gives a chain the slots the longest chain so far needed, not one per overlap length: a first try
+    of two slots (SIGAX_CAND_CAP=2) makes every run overflow once and repeat itself with what its chains reported;
+    SIGAX_CAND_CAP=worst is the round-2 sizing.  sigax_overlap_batch in pieces of 37 reads (what a read set beyond one
+    device workspace gets) joins the pieces' results in read order.  All give the oracle's bytes."""
+    _run_parity({"SIGAX_CAND_CAP": "2"}, "hits_and_asqg or non_acgt or duplicate or deep or in_flight")
+    _run_parity({"SIGAX_CAND_CAP": "2", "SIGAX_FIND_COOP": "1", "SIGAX_FORCE_WIDE": "1"}, "hits_and_asqg and (toy or dup or rep or ragged)")
+    _run_parity({"SIGAX_CAND_CAP": "worst"}, "hits_and_asqg and (toy or dup)")
+    _run_parity({"SIGAX_TEST_PIECE": "37"}, "hits_and_asqg or non_acgt or duplicate or deep")
+    _run_parity({"SIGAX_TEST_PIECE": "37", "SIGAX_CAND_CAP": "4"}, None, seeds=(1, 3, 8))
+
+
 def test_cooperative_finder_bit_exact():
     """k_find_c2 (two-step lines fetched eight lanes per line through LDS; what indexes of 2^30 symbols and more run) forced
     on the small fixtures: same bytes as the oracle, ragged reads, non-ACGT bases, duplicates and deep coverage included."""
     _run_parity({"SIGAX_FIND_COOP": "1"}, "hits_and_asqg or non_acgt or duplicate or in_flight or deep or mid")
 
 
+def test_locality_order_of_the_batch_bit_exact():
+    """The finder may walk a batch in its locality order (minimizer keys + one radix sort per batch, sigax_order_reads; on by
+    default from 2^30 symbols): forced on for the small fixtures, per-lane and cooperative finder, 32- and 64-bit positions,
+    several sub-batches.  Same bytes as the oracle."""
+    _run_parity({"SIGAX_READ_ORDER": "1"}, "hits_and_asqg or non_acgt or duplicate or deep or in_flight")
+    _run_parity({"SIGAX_READ_ORDER": "1", "SIGAX_FIND_COOP": "1"}, "hits_and_asqg or non_acgt or deep")
+    _run_parity({"SIGAX_READ_ORDER": "1", "SIGAX_FIND_COOP": "1", "SIGAX_FORCE_WIDE": "1", "SIGAX_SUBBATCHES": "3"}, None, seeds=(1, 2, 8, 21))
+
+
 def test_extractor_forms_without_the_row_tables():
-    """The look-ahead and row-end tables (fm_layout.h) are accelerators: with both, filter/extract reads a block's next ten
-    symbols from one lookup and a lone single-row group is a countdown (what every other test runs); with
-    SIGAX_LOOKAHEAD=0 the rounds come from two-step lines (or one-step granules) and only the countdown uses the row-end
-    table; with SIGAX_ROWEND=0 neither exists and the extractor walks as the reference does.  Every form gives the oracle's
-    bytes on read sets with substitutions, duplicates and substrings, 32- and 64-bit positions."""
+    """The row table and the stretch text (fm_layout.h) are accelerators.  With both, filter/extract reads a block's next
+    symbols off its read's text -- the first ones from the row-table entry itself when memory allows (what every other test
+    runs), or with bare entries (SIGAX_ROW_SYMS=0: what BASELINE configs[4] at full size gets) from the text alone -- and a
+    lone single-row group is a countdown; with SIGAX_LOOKAHEAD=0 the rounds come from two-step lines (or one-step
+    granules) and only the countdown uses the row table; with SIGAX_ROWEND=0 neither exists and the extractor walks as the
+    reference does.  Every form gives the oracle's bytes on read sets with substitutions, duplicates and substrings, 32- and
+    64-bit positions."""
+    _run_parity({"SIGAX_ROW_SYMS": "0"}, None, seeds=(1, 2, 3, 5, 8, 13, 21))
+    _run_parity({"SIGAX_ROW_SYMS": "0", "SIGAX_FORCE_WIDE": "1"}, None, seeds=(2, 3, 8, 21))
+    _run_parity({"SIGAX_ROW_SYMS": "0"}, "hits_and_asqg or non_acgt or duplicate or deep")
+    _run_parity({"SIGAX_ROW_SYMS": "3"}, None, seeds=(1, 2, 5, 8))
     _run_parity({"SIGAX_LOOKAHEAD": "0"}, None, seeds=(1, 2, 5, 8, 13, 21))
     _run_parity({"SIGAX_LOOKAHEAD": "0", "SIGAX_TWO_STEP": "0"}, None, seeds=(2, 3, 8))
     _run_parity({"SIGAX_ROWEND": "0"}, None, seeds=(1, 2, 5, 8, 13))
