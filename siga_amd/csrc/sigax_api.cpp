@@ -104,6 +104,8 @@ struct sigax_index {
   u32 tab_syms;      // symbols a row-table entry carries (plan)
   u32 max_read_len;  // longest read of sigax_index_set_reads (0: not told yet), an upper bound of the longest stretch
   void* d_super[2];
+  void* d_ptab;      // intervals of all 12-mers of the forward index: `siga correct`'s k-mer lookups start there (built by the
+  bool ptab_tried;   // first correction call; SIGAX_KMER_PREFIX=0: never)
   uint32_t* d_sai[2];
   u64 n_sai;
   uint32_t* d_read_len;
@@ -301,6 +303,7 @@ extern "C" void sigax_index_close(sigax_index* ix) {
   }
   if (ix->d_read_len) hipFree(ix->d_read_len);
   if (ix->d_name_rank) hipFree(ix->d_name_rank);
+  if (ix->d_ptab) hipFree(ix->d_ptab);
   if (ix->s_find) hipStreamDestroy(ix->s_find);
   if (ix->s_fx) hipStreamDestroy(ix->s_fx);
   if (ix->s_tail) hipStreamDestroy(ix->s_tail);
@@ -354,14 +357,14 @@ static void plan_row_tables(sigax_index* ix) {
   size_t mfree = 0, mtotal = 0;
   (void)hipMemGetInfo(&mfree, &mtotal);
   ix->tab_text = !(envl && envl[0] == '0');
-  // entries with their first symbols when that fits 40 % of the free memory (one lookup then serves an item's first rounds:
-  // at BASELINE configs[1] 14 symbols, 56 bits per row), bare entries when those fit 70 %
+  // entries with as many of their first symbols (14 at most) as fit half of the free memory (one lookup then serves an
+  // item's first rounds: at BASELINE configs[1] 14 symbols, 56 bits per row); bare entries when they fit 70 %
   static const char* envk = getenv("SIGAX_ROW_SYMS");
-  for (u32 syms = ix->tab_text ? (envk ? (u32)atoi(envk) : 14u) : 0u;; syms = 0) {
+  for (u32 syms = ix->tab_text ? (envk ? (u32)atoi(envk) : 14u) : 0u;; --syms) {
     const RowTabGeom g = row_tab_geom(ix, maxlen_bound(ix), syms);
     if (g.sa_bits > 57) return;
     const u64 want = 2 * (g.sa_bytes + (ix->tab_text ? g.text_bytes : 0));
-    if (want < mfree / 10 * (syms ? 4 : 7)) {
+    if (want < mfree / 10 * (syms ? 5 : 7)) {
       ix->tab_plan = want;
       ix->tab_syms = syms;
       return;
@@ -822,6 +825,30 @@ extern "C" int sigax_kmer_count_batch(sigax_index* ix, const char* kmers, uint32
   return SIGAX_OK;
 }
 
+// the 12-mer table of the k-mer lookups, built on first use (an accelerator: without it every lookup walks all its steps)
+static void ensure_prefix_table(sigax_index* ix) {
+  std::lock_guard<std::mutex> lock(*ix->enqueue_mu);
+  if (ix->ptab_tried) return;
+  ix->ptab_tried = true;
+  const char* env = getenv("SIGAX_KMER_PREFIX");
+  if (env && env[0] == '0') return;
+  void* tab = nullptr;
+  if (hipMalloc(&tab, prefix_table_bytes(ix->wide)) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  launch_prefix_build(ix->st[0], ix->wide, tab, nullptr);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    hipFree(tab);
+    return;
+  }
+  ix->d_ptab = tab;
+  ix->device_bytes += prefix_table_bytes(ix->wide);
+}
+
 static CorrectArgs correct_args(sigax_index* ix, const unsigned char* d_seqs, const unsigned char* d_quals, const u64* d_offs, u64 n_reads,
                                 uint32_t kmer_size, int32_t kmer_threshold, uint32_t kmer_rounds, uint32_t count_offset,
                                 unsigned char* d_out, unsigned char* d_valid, u64* d_stat) {
@@ -840,6 +867,8 @@ static CorrectArgs correct_args(sigax_index* ix, const unsigned char* d_seqs, co
   ca.out = d_out;
   ca.valid = d_valid;
   ca.dstat = d_stat;
+  ensure_prefix_table(ix);
+  ca.ptab = ix->d_ptab;
   return ca;
 }
 
@@ -1196,7 +1225,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
         if ((rc = ensure(&b->ord_tmp, tb)) != SIGAX_OK) return rc;
         uint32_t bounds[SIGAX_MAX_SUB + 1];
         for (unsigned i = 0; i <= nsub; ++i) bounds[i] = (uint32_t)((u64)n * i / nsub);
-        rc = sigax_order_reads(b->d_seqs, b->d_offs, n, bounds, nsub, (uint32_t*)b->ord_keys.p, (uint32_t*)b->perm.p, b->ord_tmp.p, tb,
+        rc = sigax_order_reads(b->d_seqs, b->d_offs, n, b->cur_max_len, bounds, nsub, (uint32_t*)b->ord_keys.p, (uint32_t*)b->perm.p, b->ord_tmp.p, tb,
                                &b->perm_cur, st);
         if (rc != SIGAX_OK) return rc;
         HIP_TRY(hipEventRecord(b->ev[EV_ORD1], st));
@@ -1338,8 +1367,13 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
       xa.n_work_ptr = nullptr;
     }
     HIP_TRY(hipEventRecord(b->sev[i][SV_X1], ix->s_fx));
-    launch_filter_extract(xa, ix->wide, b->fx_grid, ix->s_fx);
-    HIP_TRY(hipEventRecord(b->sev[i][SV_G1], ix->s_fx));
+    // The general kernel (what the lane-group launches queued: usually nothing) goes to the high-priority tail stream: on
+    // the low-priority one its 170-register workgroups found no room beside the finder's, whose own new workgroups took
+    // every slot that came free first -- at the BASELINE configs[4] shape an EMPTY launch sat there for 3 to 6 ms per run
+    // and held up the next batch's filter/extract chain behind it.
+    HIP_TRY(hipStreamWaitEvent(ix->s_tail, b->sev[i][SV_X1], 0));
+    launch_filter_extract(xa, ix->wide, b->fx_grid, ix->s_tail);
+    HIP_TRY(hipEventRecord(b->sev[i][SV_G1], ix->s_tail));
   }
   HIP_TRY(hipEventRecord(b->ev[EV_FX_DONE], ix->s_fx));
   // The short tail (scan, ordered scatter, edge records) runs on its own high-priority stream: queued behind the

@@ -836,10 +836,10 @@ int sigax_decode_strand(const uint8_t* runs, u64 n_runs, u64 nsym, bool wide, vo
 // -------------------------------------------------------------------------------------------------------
 namespace {
 struct OrderBounds { u32 n, b[9]; };
-// One thread per read; the workgroup's 256 reads (one byte range of the batch) are first copied to LDS with coalesced word
-// loads -- round 2's kernel had every thread walk its read byte by byte in global memory, 150 scattered loads per read, and
-// took 2.4 ms per 1 M reads against the 0.1 ms of the sort it feeds.  Tiles whose bytes do not fit the LDS buffer are read in
-// place.
+// One thread per read; the workgroup's `per` reads (one byte range of the batch; 256, or fewer when the reads are long, so
+// that the range fits the LDS buffer) are first copied to LDS with coalesced word loads -- round 2's kernel had every
+// thread walk its read byte by byte in global memory, 150 scattered loads per read, and took 2.4 ms per 1 M reads against
+// the 0.1 ms of the sort it feeds (250 bp reads read in place: 13.6 ms).  Tiles whose bytes still do not fit are read in place.
 #define KEYS_LDS_BYTES 49152u
 template <class GetByte>
 __device__ __forceinline__ u32 read_key(u32 L, u32 sub, GetByte get) {
@@ -864,9 +864,9 @@ __device__ __forceinline__ u32 read_key(u32 L, u32 sub, GetByte get) {
   const u32 ord = bs ? o9 : 0x1FFu - o9;  // grows with the read's start position in the genome, per strand
   return (sub << 29) | ((best >> 13) << 10) | (bs << 9) | ord;
 }
-__global__ __launch_bounds__(256) void k_read_keys(const unsigned char* seqs, const u64* offs, u32 n, OrderBounds ob, u32* keys, u32* idx) {
+__global__ __launch_bounds__(256) void k_read_keys(const unsigned char* seqs, const u64* offs, u32 n, u32 per, OrderBounds ob, u32* keys, u32* idx) {
   __shared__ __attribute__((aligned(16))) u32 tile[KEYS_LDS_BYTES / 4];
-  const u32 r0 = blockIdx.x * 256, r1 = r0 + 256 < n ? r0 + 256 : n;
+  const u32 r0 = blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
   const u64 lo = offs[r0], hi = offs[r1];
   const u64 alo = (reinterpret_cast<u64>(seqs) + lo) & ~3ull;  // whole aligned words: the first one may start before the first base
   const u64 nbytes = reinterpret_cast<u64>(seqs) + hi - alo;
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256) void k_read_keys(const unsigned char* seqs, co
   }
   __syncthreads();
   const u32 r = r0 + threadIdx.x;
-  if (r >= n) return;
+  if (threadIdx.x >= per || r >= n) return;
   u32 sub = 0;
   for (u32 i = 1; i < ob.n; ++i) sub += r >= ob.b[i] ? 1u : 0u;
   const u64 b0 = offs[r];
@@ -904,14 +904,16 @@ size_t sigax_order_reads_tmp_bytes(uint32_t n) {
   return tb ? tb : 16;
 }
 
-int sigax_order_reads(const unsigned char* d_seqs, const u64* d_offs, u32 n, const u32* bounds, u32 nsub, u32* keys, u32* vals, void* tmp,
-                      size_t tmp_bytes, const u32** result, hipStream_t st) {
+int sigax_order_reads(const unsigned char* d_seqs, const u64* d_offs, u32 n, u32 max_len, const u32* bounds, u32 nsub, u32* keys, u32* vals,
+                      void* tmp, size_t tmp_bytes, const u32** result, hipStream_t st) {
   *result = vals;
   if (n == 0) return SIGAX_OK;
   OrderBounds ob;
   ob.n = nsub > 8 ? 8 : nsub;
   for (u32 i = 0; i < 9; ++i) ob.b[i] = i <= ob.n ? bounds[i] : n;
-  hipLaunchKernelGGL(k_read_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_seqs, d_offs, n, ob, keys, vals);
+  u32 per = 256;  // reads per workgroup: as many as fit the LDS tile, a power of two
+  while (per > 16 && (u64)per * max_len + 8 > KEYS_LDS_BYTES) per >>= 1;
+  hipLaunchKernelGGL(k_read_keys, dim3((n + per - 1) / per), dim3(256), 0, st, d_seqs, d_offs, n, per, ob, keys, vals);
   rocprim::double_buffer<u32> K(keys, keys + n);
   rocprim::double_buffer<u32> V(vals, vals + n);
   size_t tb = tmp_bytes;

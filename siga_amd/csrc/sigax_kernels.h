@@ -148,8 +148,12 @@ struct CorrectArgs {
   unsigned char* out;    // corrected sequences, same layout as seqs
   unsigned char* valid;  // CorrectResult::validQC; 2 = read longer than the kernel supports
   unsigned long long* dstat;  // [0] reads too long, [1] rank-table sectors asked for, [2] k-mer lookups (4 x u64)
+  const void* ptab;           // intervals of all 12-mers (launch_prefix_build), or NULL
 };
 void launch_correct(const CorrectArgs& a, bool wide, hipStream_t st);
+// table of the intervals of all 12-mers on strand s: prefix_table_bytes(wide) bytes
+unsigned long long prefix_table_bytes(bool wide);
+void launch_prefix_build(const FmStrand& s, bool wide, void* tab, hipStream_t st);
 
 void launch_occ_batch(const FmStrand& s, bool wide, const unsigned long long* pos, unsigned long long n,
                       unsigned long long* out, hipStream_t st);
@@ -185,7 +189,7 @@ void launch_edges_fill(const EdgeArgs& a, hipStream_t st);
 // queued on `st` without a host wait.  keys = 2 n u32, vals = 2 n u32 of scratch; *result = the half of vals that will hold
 // the order once the stream gets there.
 size_t sigax_order_reads_tmp_bytes(uint32_t n);
-int sigax_order_reads(const unsigned char* d_seqs, const unsigned long long* d_offs, uint32_t n, const uint32_t* bounds, uint32_t nsub,
+int sigax_order_reads(const unsigned char* d_seqs, const unsigned long long* d_offs, uint32_t n, uint32_t max_len, const uint32_t* bounds, uint32_t nsub,
                       uint32_t* keys, uint32_t* vals, void* tmp, size_t tmp_bytes, const uint32_t** result, hipStream_t st);
 
 #endif

@@ -28,11 +28,12 @@ namespace sigah {
 // ------------------------------------------------------------------------------------------------------
 class LineSource {
  public:
-  explicit LineSource(const std::string& path) : _pos(0), _len(0), _eof(false) { _f = gzopen(path.c_str(), "rb"); }
+  explicit LineSource(const std::string& path) : _pos(0), _len(0), _eof(false), _err(false) { _f = gzopen(path.c_str(), "rb"); }
   ~LineSource() {
     if (_f) gzclose(_f);
   }
   bool ok() const { return _f != nullptr; }
+  bool failed() const { return _err; }  // a read error (corrupt .gz), as opposed to the end of the file
   int peek() {
     if (_pos >= _len && !fill()) return -1;
     return (unsigned char)_buf[_pos];
@@ -66,6 +67,7 @@ class LineSource {
     if (_eof) return false;
     int n = gzread(_f, _buf, sizeof(_buf));
     if (n <= 0) {
+      if (n < 0) _err = true;  // a corrupt or truncated .gz is not the end of the reads
       _eof = true;
       return false;
     }
@@ -76,7 +78,7 @@ class LineSource {
   gzFile _f;
   char _buf[1 << 16];
   size_t _pos, _len;
-  bool _eof;
+  bool _eof, _err;
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -160,12 +162,16 @@ static bool slurp(const std::string& path, std::vector<char>* out) {
     for (;;) {
       if (out->size() - len < (1u << 20)) out->resize(out->size() * 2);
       int n = gzread(f, out->data() + len, (unsigned)std::min<size_t>(out->size() - len, 1u << 30));
-      if (n <= 0) break;
+      if (n < 0) {  // a corrupt or truncated .gz must not be taken for a shorter read set
+        gzclose(f);
+        return false;
+      }
+      if (n == 0) break;
       len += (size_t)n;
     }
-    gzclose(f);
+    const bool whole = gzclose(f) == Z_OK;  // Z_BUF_ERROR: the stream ended inside a member
     out->resize(len);
-    return true;
+    return whole;
   }
   out->resize((size_t)st.st_size);
   size_t len = 0;
@@ -392,6 +398,8 @@ DNASeqReader* DNASeqReader::create(const std::string& path) {
   return r;
 }
 
+bool DNASeqReader::failed() const { return _src->failed(); }
+
 void DNASeqReader::reset() {
   _name.clear();
   _src->rewind();
@@ -466,7 +474,7 @@ bool ReadDNASequences(const std::string& file, DNASeqList& sequences, uint32_t f
     if (!(flags & kSeqWithComment)) seq.comment.clear();
     sequences.push_back(seq);
   }
-  return true;
+  return !reader->failed();  // a corrupt .gz is an error, not a shorter read set
 }
 
 std::string Utils::stem(const std::string& filename) {  // src/utils.cpp:128-135
@@ -759,7 +767,7 @@ uint64_t FMIndex::length() const {
 // or GPUs produced it.
 class OutFile {
  public:
-  explicit OutFile(const std::string& path, unsigned threads = 0) : _f(nullptr), _gz(false), _crc(0), _total(0), _nt(threads) {
+  explicit OutFile(const std::string& path, unsigned threads = 0) : _f(nullptr), _gz(false), _bad(false), _crc(0), _total(0), _nt(threads) {
     _gz = path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0;
     _f = fopen(path.c_str(), "wb");
     // deflate at level 6 makes ~12 MB/s per thread on read text: the writer takes up to 128 threads whatever -t says
@@ -767,7 +775,7 @@ class OutFile {
     if (const char* env = getenv("SIGA_HOST_THREADS")) _nt = std::max(1, atoi(env));
     if (_f && _gz) {
       static const unsigned char hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
-      fwrite(hdr, 1, 10, _f);
+      put(hdr, 10);
       _crc = crc32(0L, Z_NULL, 0);
     }
   }
@@ -785,10 +793,10 @@ class OutFile {
   void write_parts(const std::vector<std::string>& parts) {
     if (!_f) return;
     if (!_gz) {
-      if (!_buf.empty()) fwrite(_buf.data(), 1, _buf.size(), _f);
+      if (!_buf.empty()) put(_buf.data(), _buf.size());
       _buf.clear();
       for (const std::string& p : parts)
-        if (!p.empty()) fwrite(p.data(), 1, p.size(), _f);
+        if (!p.empty()) put(p.data(), p.size());
       return;
     }
     std::vector<const std::string*> segs;
@@ -823,7 +831,7 @@ class OutFile {
         deflate_block(tmp.data(), kBlock, false, &outs[i], &crcs[i]);
       });
       for (size_t i = 0; i < nfull; ++i) {
-        fwrite(outs[i].data(), 1, outs[i].size(), _f);
+        put(outs[i].data(), outs[i].size());
         _crc = crc32_combine(_crc, crcs[i], (z_off_t)kBlock);
       }
       _total += nfull * kBlock;
@@ -840,16 +848,18 @@ class OutFile {
       std::string out;
       uLong crc = 0;
       deflate_block(_buf.data(), _buf.size(), true, &out, &crc);  // the last (possibly empty) block ends the deflate stream
-      fwrite(out.data(), 1, out.size(), _f);
+      put(out.data(), out.size());
       _crc = crc32_combine(_crc, crc, (z_off_t)_buf.size());
       _total += _buf.size();
       _buf.clear();
       unsigned char tail[8];
       uint32_t c = (uint32_t)_crc, n = (uint32_t)_total;
       for (int i = 0; i < 4; ++i) { tail[i] = (unsigned char)(c >> (8 * i)); tail[4 + i] = (unsigned char)(n >> (8 * i)); }
-      fwrite(tail, 1, 8, _f);
+      put(tail, 8);
     }
-    bool ok = fclose(_f) == 0;
+    // a short write (disk full, I/O error) leaves the stream's error flag set while fclose may still return 0
+    bool ok = !_bad && ferror(_f) == 0;
+    ok = fclose(_f) == 0 && ok;
     _f = nullptr;
     return ok;
   }
@@ -882,8 +892,11 @@ class OutFile {
     deflateEnd(&z);
     *crc = crc32(crc32(0L, Z_NULL, 0), (const Bytef*)in, (uInt)n);
   }
+  void put(const void* p, size_t n) {
+    if (n && fwrite(p, 1, n, _f) != n) _bad = true;
+  }
   FILE* _f;
-  bool _gz;
+  bool _gz, _bad;
   uLong _crc;
   uint64_t _total;
   unsigned _nt;
@@ -1162,11 +1175,18 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
   if (devs.size() > 1) pt.lap("index replicas");
   // device batches: as many reads as the free memory of a GPU takes with two batches in flight, at most 2^20, and no
   // more than an even share of the input; the reference's threads x batch-size is a lower bound
+  // (asked of every replica: two batch objects per replica, and replicas that share a physical device -- SIGA_DEVICE_MAP
+  // rehearsals -- share its memory; the smallest answer sizes the batches of all)
   uint32_t hint = 1u << 20;
-  if (n > 0 && sigax_batch_size_hint(idx[0], std::max(maxLen, 1u), (uint32_t)minOverlap, flags, 2, &hint) != SIGAX_OK) {
-    _error = std::string("overlap failed: ") + sigax_last_error();
-    drop_replicas();
-    return false;
+  for (size_t k = 0; n > 0 && k < devs.size(); ++k) {
+    uint32_t sharing = 0, h = 0;
+    for (int d : devs) sharing += d == devs[k] ? 1u : 0u;
+    if (sigax_batch_size_hint(idx[k], std::max(maxLen, 1u), (uint32_t)minOverlap, flags, 2 * sharing, &h) != SIGAX_OK) {
+      _error = std::string("overlap failed: ") + sigax_last_error();
+      drop_replicas();
+      return false;
+    }
+    hint = k == 0 ? h : std::min(hint, h);
   }
   size_t per = std::min<size_t>(hint, 1u << 20);
   if (const char* env = getenv("SIGA_BATCH_READS")) per = std::min<size_t>(hint, std::max<size_t>(strtoull(env, nullptr, 10), 1));

@@ -30,6 +30,7 @@ class DNASeqReader {
   static DNASeqReader* create(const std::string& path);  // DNASeqReaderFactory::create; nullptr on failure
   ~DNASeqReader();
   bool read(DNASeq& sequence);
+  bool failed() const;  // the input could not be read to its end (corrupt .gz); read() then returned false early
   void reset();
 
  private:

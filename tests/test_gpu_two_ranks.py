@@ -66,3 +66,32 @@ def test_two_ranks_gathered_edges_give_the_one_gpu_asqg(name, m):
         assert p.exitcode == 0
     same_one, same_oracle, counts = q.get(timeout=10)
     assert same_one and same_oracle and len(counts) == 2 and min(counts) > 0
+
+
+def test_bench_self_launch_two_ranks_gloo_counts_the_one_rank_edges(tmp_path):
+    """`python bench.py --gpus 2` as the driver starts it for N > 1 rehearsed on this one-GPU box: bench.py launches its two
+    ranks itself (fresh torchrun children, before anything touches the GPU), `--backend gloo` gathers the edge records through
+    the host, and rank 0 prints ONE JSON line with n_gpus 2 whose edge count is the one-rank run's on the same reads."""
+    import json
+    import subprocess
+    import sys
+    from tests.fixtures import ROOT
+    bench = os.path.join(ROOT, "bench.py")
+    common = ["--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--seed", "2", "--read-len", "100", "--min-overlap", "40",
+              "--workdir", str(tmp_path / "job")]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def run(extra):
+        r = subprocess.run([sys.executable, bench] + extra + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    two = run(["--gpus", "2", "--backend", "gloo", "--reads-per-gpu", "20000", "--genome-per-gpu", "100000"])
+    one = run(["--gpus", "1", "--reads-per-gpu", "40000", "--genome-per-gpu", "200000"])
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == "weak"
+    assert two["config"]["edges"] == one["config"]["edges"] > 20000
+    assert two["config"]["reads_per_gpu"] == 20000 and two["value"] > 0

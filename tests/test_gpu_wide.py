@@ -73,6 +73,13 @@ def test_cooperative_finder_bit_exact():
     _run_parity({"SIGAX_FIND_COOP": "1"}, "hits_and_asqg or non_acgt or duplicate or in_flight or deep or mid")
 
 
+def test_correct_without_the_kmer_prefix_table():
+    """`siga correct`'s k-mer lookups start from the interval of their last twelve bases (a table of all 12-mers, built on
+    first use); SIGAX_KMER_PREFIX=0 walks every step as the reference does.  Same files either way, 32- and 64-bit positions."""
+    _run_parity({"SIGAX_KMER_PREFIX": "0"}, "correct")
+    _run_parity({"SIGAX_FORCE_WIDE": "1"}, "correct")
+
+
 def test_locality_order_of_the_batch_bit_exact():
     """The finder may walk a batch in its locality order (minimizer keys + one radix sort per batch, sigax_order_reads; on by
     default from 2^30 symbols): forced on for the small fixtures, per-lane and cooperative finder, 32- and 64-bit positions,
