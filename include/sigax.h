@@ -130,6 +130,14 @@ int  sigax_build_strand(const char* seqs, const uint64_t* offs, uint64_t n_reads
                         uint8_t** runs, uint64_t* n_runs, uint32_t** sai, uint64_t* n_symbols);
 void sigax_free(void* p);
 
+/* Self-check of an open index: are the BWT rows of strand `which` (0 forward, 1 reverse) in the suffix order `siga index`
+ * produces (SuffixArrayBuilder "sais2": src/suffix_array_builder.cpp:472-674; SURVEY.md App. C: one '$' smaller than
+ * ACGT, comparisons continuing past it, end of text smallest)?  Every pair of adjacent rows is compared on the device.
+ * *n_bad = pairs out of order (0 = the index is in order), *first_bad = the first such row, *n_undecided = pairs still
+ * tied after 4096 reads' worth of symbols.  Needs the .sai tables and sigax_index_set_reads(); SIGAX_E_STATE when the index
+ * holds non-ACGT bases or has no row tables. */
+int  sigax_index_check_order(sigax_index*, int which, uint64_t* n_bad, uint64_t* first_bad, uint64_t* n_undecided);
+
 /* FMIndex::getOcc(i) for many positions (src/fmindex.cpp:320-323): which = 0 forward, 1 reverse index;
  * counts5[5*k..] = Occ($,A,C,G,T) inclusive of positions[k]; position 2^64-1 gives zeros. Host buffers. */
 int  sigax_occ_batch(sigax_index*, int which, const uint64_t* positions, uint64_t n, uint64_t* counts5);

@@ -51,7 +51,7 @@ class RunInfo(C.Structure):
 # every symbol include/sigax.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "sigax_last_error", "sigax_device_count", "sigax_stream_create", "sigax_stream_destroy", "sigax_index_open", "sigax_index_open_mem", "sigax_index_clone", "sigax_index_close",
-    "sigax_index_info_get", "sigax_index_set_reads", "sigax_occ_batch", "sigax_kmer_count_batch",
+    "sigax_index_info_get", "sigax_index_set_reads", "sigax_index_check_order", "sigax_occ_batch", "sigax_kmer_count_batch",
     "sigax_correct_batch", "sigax_correct_device", "sigax_overlap_batch", "sigax_result_free", "sigax_batch_create", "sigax_batch_destroy", "sigax_batch_upload",
     "sigax_batch_set_device_reads", "sigax_batch_set_subbatches", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
     "sigax_batch_download", "sigax_batch_download_edges", "sigax_batch_size_hint", "sigax_batch_kernel_ms", "sigax_batch_run_info", "sigax_build_strand", "sigax_free",
@@ -84,6 +84,7 @@ def lib():
     L.sigax_index_close.restype = None
     L.sigax_index_info_get.argtypes = [vp, C.POINTER(IndexInfo)]
     L.sigax_index_set_reads.argtypes = [vp, vp, vp, u64]
+    L.sigax_index_check_order.argtypes = [vp, ci, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.sigax_occ_batch.argtypes = [vp, ci, vp, u64, vp]
     L.sigax_kmer_count_batch.argtypes = [vp, cp, u32, u64, vp]
     L.sigax_correct_batch.argtypes = [vp, cp, cp, vp, u32, u32, C.c_int32, u32, u32, vp, vp]

@@ -70,6 +70,13 @@
  * no rank arithmetic. */
 #define SIGAX_TEXT_WINDOW 28  /* symbols per text load that every lane can count on (an unaligned 8-byte load holds 57 to 64 bits of them) */
 
+/* Start table of the block finder (optional, built on the device at open): for every 12-mer, what a chain whose first twelve
+ * symbols (in the order the chain consumes them, first one in the highest two bits of the code, rank - 1 each) are that
+ * 12-mer holds after consuming them with THIS strand as its primary index: { capped/raw [0].lower, [1].lower, size, steps }
+ * -- steps = 12, or where the range emptied (the chain then reports the same number of rank evaluations as the walk).
+ * 16 bytes per entry (32 with 64-bit positions), 268 MB per strand: one gather instead of eleven dependent steps. */
+#define SIGAX_START_K 12
+
 struct FmStrand {
   const uint32_t* granules;  /* n_granules x 16 u32 */
   const unsigned char* sa;    /* row table: n entries of sa_bits bits (+ 8 bytes of padding), or NULL */
@@ -78,6 +85,7 @@ struct FmStrand {
   const uint32_t* gran2;     /* (n / 64 + 1) x 32 u32, or NULL */
   const unsigned long long* super2;  /* [n_super][20], wide mode with two-step tables; else NULL */
   const unsigned long long* super;    /* [n_super][4] absolute A,C,G,T counts at each superblock start (wide mode) */
+  const void* start;                  /* start table of the finder, or NULL */
   unsigned long long n;             /* symbols */
   unsigned long long C[5];           /* FMIndex::_pred (src/fmindex.cpp:156-160) */
   unsigned long long total[5];         /* symbol totals = Occ(c, n-1) */

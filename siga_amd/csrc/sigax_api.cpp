@@ -104,6 +104,7 @@ struct sigax_index {
   u32 tab_syms;      // symbols a row-table entry carries (plan)
   u32 max_read_len;  // longest read of sigax_index_set_reads (0: not told yet), an upper bound of the longest stretch
   void* d_super[2];
+  void* d_start[2];  // start tables of the block finder (fm_layout.h) or NULL
   void* d_ptab;      // intervals of all 12-mers of the forward index: `siga correct`'s k-mer lookups start there (built by the
   bool ptab_tried;   // first correction call; SIGAX_KMER_PREFIX=0: never)
   uint32_t* d_sai[2];
@@ -116,6 +117,9 @@ struct sigax_index {
   // launches on s_find and its filter/extract launches on s_fx, so with two batches in flight batch B's first finder
   // launch runs beside batch A's last filter/extract launch and finder launches never run beside each other.
   hipStream_t s_find, s_fx, s_tail;
+  hipStream_t s_ord;  // the locality ordering of a batch (a key kernel + some twenty launches of the radix sort, 1 ms of work
+                      // per 2.5 M reads): high priority -- queued on the caller's stream beside the long kernels of the
+                      // batches in flight it took 17 ms at the BASELINE configs[2] shape, all of it on the batch's own chain
   std::mutex* enqueue_mu;
   int n_cu;  // compute units of the device
   // The longest chain of candidate blocks any run on this index has produced so far.  The candidate arena gives every chain
@@ -123,6 +127,7 @@ struct sigax_index {
   // chain on average, 30-odd at most, 106 in the worst case.  A run whose chains outgrow their slots is repeated with what
   // it reported (sigax_batch_finish).
   std::atomic<uint32_t>* cap_seen;
+  std::atomic<uint32_t>* mean_chain16;  // 16 x the mean candidate blocks per chain of the last finished run (0: none yet)
   bool split_strands;  // two-step tables too large to gather from both at once: one finder launch per strand
 };
 
@@ -298,6 +303,7 @@ extern "C" void sigax_index_close(sigax_index* ix) {
     if (ix->d_super2[s]) hipFree(ix->d_super2[s]);
     if (ix->d_sa[s]) hipFree(ix->d_sa[s]);
     if (ix->d_text[s]) hipFree(ix->d_text[s]);
+    if (ix->d_start[s]) hipFree(ix->d_start[s]);
     if (ix->d_super[s]) hipFree(ix->d_super[s]);
     if (ix->d_sai[s]) hipFree(ix->d_sai[s]);
   }
@@ -307,8 +313,10 @@ extern "C" void sigax_index_close(sigax_index* ix) {
   if (ix->s_find) hipStreamDestroy(ix->s_find);
   if (ix->s_fx) hipStreamDestroy(ix->s_fx);
   if (ix->s_tail) hipStreamDestroy(ix->s_tail);
+  if (ix->s_ord) hipStreamDestroy(ix->s_ord);
   delete ix->enqueue_mu;
   delete ix->cap_seen;
+  delete ix->mean_chain16;
   delete ix;
 }
 
@@ -530,6 +538,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
   ix->device = device;
   ix->enqueue_mu = new std::mutex();
   ix->cap_seen = new std::atomic<uint32_t>(0);
+  ix->mean_chain16 = new std::atomic<uint32_t>(0);
   if (hipDeviceGetAttribute(&ix->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ix->n_cu <= 0) ix->n_cu = 256;
   {
     // the finder is the critical path of a step: its stream gets the higher priority
@@ -538,6 +547,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_find, hipStreamNonBlocking, prio_greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_fx, hipStreamNonBlocking, prio_least);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_tail, hipStreamNonBlocking, prio_greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_ord, hipStreamNonBlocking, prio_greatest);
     if (e != hipSuccess) {
       sigax_index_close(ix);
       return fail(SIGAX_E_DEVICE, "creating the pipeline streams: %s", hipGetErrorString(e));
@@ -632,6 +642,32 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
       }
     }
   }
+  // Start tables of the finder (fm_layout.h): from 2^22 symbols on (the 2 x 268 MB and 20 ms are out of proportion for
+  // less; SIGAX_FIND_START=1 forces them, =0 turns them off), an accelerator like the others.
+  {
+    const char* envs = getenv("SIGAX_FIND_START");
+    const bool want = envs ? envs[0] != '0' : n_symbols >= (1ull << 22);
+    if (want && n_symbols > 0) {
+      hipError_t e = hipSuccess;
+      for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+        e = hipMalloc(&ix->d_start[s], start_table_bytes(ix->wide));
+        if (e != hipSuccess) break;
+        launch_start_build(ix->st[s], ix->st[1 - s], ix->wide, ix->d_start[s], nullptr);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        for (int s = 0; s < 2; ++s) {
+          if (ix->d_start[s]) hipFree(ix->d_start[s]);
+          ix->d_start[s] = nullptr;
+        }
+      } else {
+        for (int s = 0; s < 2; ++s) ix->st[s].start = ix->d_start[s];
+        ix->device_bytes += 2 * start_table_bytes(ix->wide);
+      }
+    }
+  }
   build_rowend(ix);
   if (sai && rsai) {
     const uint32_t* ss[2] = {sai, rsai};
@@ -707,6 +743,7 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
   ix->device = device;
   ix->enqueue_mu = new std::mutex();
   ix->cap_seen = new std::atomic<uint32_t>(src->cap_seen->load());
+  ix->mean_chain16 = new std::atomic<uint32_t>(src->mean_chain16->load());
   ix->n_cu = src->n_cu;
   (void)hipDeviceGetAttribute(&ix->n_cu, hipDeviceAttributeMultiprocessorCount, device);
   {
@@ -715,6 +752,7 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_find, hipStreamNonBlocking, prio_greatest);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_fx, hipStreamNonBlocking, prio_least);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_tail, hipStreamNonBlocking, prio_greatest);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_ord, hipStreamNonBlocking, prio_greatest);
     if (e != hipSuccess) {
       sigax_index_close(ix);
       return fail(SIGAX_E_DEVICE, "creating the pipeline streams: %s", hipGetErrorString(e));
@@ -745,6 +783,7 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
     if (rc == SIGAX_OK) rc = copy(&ix->d_gran2[s], src->d_gran2[s], ng2 * SIGAX_GRAN2_WORDS * 4);
     if (rc == SIGAX_OK) rc = copy(&ix->d_super2[s], src->d_super2[s], (((ng2 - 1) >> (SIGAX_SUPER_SHIFT - 6)) + 1) * 20 * 8);
     if (rc == SIGAX_OK) rc = copy((void**)&ix->d_sai[s], src->d_sai[s], src->n_sai * 4);
+    if (rc == SIGAX_OK) rc = copy(&ix->d_start[s], src->d_start[s], start_table_bytes(src->wide));
     ix->st[s] = src->st[s];
     ix->st[s].sa = nullptr;
     ix->st[s].text = nullptr;
@@ -752,6 +791,7 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
     ix->st[s].super = (const u64*)ix->d_super[s];
     ix->st[s].gran2 = (const uint32_t*)ix->d_gran2[s];
     ix->st[s].super2 = (const u64*)ix->d_super2[s];
+    ix->st[s].start = ix->d_start[s];
   }
   if (rc == SIGAX_OK) rc = copy((void**)&ix->d_read_len, src->d_read_len, src->n_meta * 4);
   if (rc == SIGAX_OK) rc = copy((void**)&ix->d_name_rank, src->d_name_rank, src->n_meta * 4);
@@ -792,6 +832,42 @@ extern "C" int sigax_index_set_reads(sigax_index* ix, const uint32_t* lengths, c
     if (ix->tab_plan) plan_row_tables(ix);  // planned with an estimate of the longest stretch, not started yet: now with the bound
   }
   return rc;
+}
+
+// Are the BWT rows of strand `which` in the suffix order of record?  Checked on the device from the row table and the
+// stretch text (built now if they were only planned): every pair of adjacent rows.  For tests of the index builder at
+// sizes no second suffix sorter reaches in reasonable time.
+extern "C" int sigax_index_check_order(sigax_index* ix, int which, uint64_t* n_bad, uint64_t* first_bad, uint64_t* n_undecided) {
+  if (!ix || which < 0 || which > 1 || !n_bad) return fail(SIGAX_E_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(ix->device));
+  if (!ix->d_sai[which] || !ix->d_read_len) return fail(SIGAX_E_STATE, "the order check needs the .sai tables and sigax_index_set_reads()");
+  if (ix->st[which].C[1] != ix->n_strings) return fail(SIGAX_E_STATE, "reads with non-ACGT bases: stretches are not reads, order not checkable");
+  {
+    std::lock_guard<std::mutex> lock(*ix->enqueue_mu);
+    if (ix->tab_thread) {  // a build in flight: wait for it
+      ix->tab_thread->join();
+      delete ix->tab_thread;
+      ix->tab_thread = nullptr;
+    }
+    publish_tables(ix);
+    if (!ix->st[which].sa && ix->tab_plan) start_row_tables(ix, true);
+  }
+  if (!ix->st[which].sa || !ix->st[which].text) return fail(SIGAX_E_STATE, "no row tables on this index (memory short or turned off)");
+  DevGuard g;
+  uint32_t* isai = nullptr;
+  u64* bad = nullptr;
+  HIP_TRY(g.alloc((void**)&isai, ix->n_strings * 4));
+  HIP_TRY(g.alloc((void**)&bad, 32));
+  const u64 init[4] = {0, ~0ull, 0, 0};
+  HIP_TRY(hipMemcpy(bad, init, 32, hipMemcpyHostToDevice));
+  launch_suffix_order_check(ix->st[which], ix->d_sai[which], isai, ix->d_read_len, ix->n_strings, bad, nullptr);
+  HIP_TRY(hipGetLastError());
+  u64 out[4];
+  HIP_TRY(hipMemcpy(out, bad, 32, hipMemcpyDeviceToHost));
+  *n_bad = out[0];
+  if (first_bad) *first_bad = out[1];
+  if (n_undecided) *n_undecided = out[2];
+  return SIGAX_OK;
 }
 
 extern "C" int sigax_occ_batch(sigax_index* ix, int which, const uint64_t* positions, uint64_t n, uint64_t* counts5) {
@@ -1204,12 +1280,25 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   b->last_ordered = false;
   const uint32_t perm_stride = (b->cur_max_len + 3u) & ~3u;
   {
-    // Off by default below 2^30 symbols: measured at BASELINE configs[1] with the ordering inside the timed step (as every
-    // product batch pays it), 105.0 M reads/s with it against 110.5 M without -- the table is cache-resident there and the
-    // order buys the finder 1 %.  On for the big indexes, where what it saves is page translations.  SIGAX_READ_ORDER=0/1.
+    // When does it pay?  Measured with the ordering inside the timed step, as every product batch pays it: at BASELINE
+    // configs[1] 105.0 M reads/s with it against 110.5 M without (the table is cache-resident there and the order buys the
+    // finder 1 to 5 %); at the configs[4] shape 35.7 against 38.8 M (a batch of 1 M reads out of 50 M covers the genome 1.1
+    // times: hardly any read has a neighbour in its batch); at the configs[2] shape, where a batch covers the genome 3.75
+    // times and what the order saves is page translations, the finder goes from 26.9 to 23.9 ms per 2.5 M reads.  So: on
+    // from 2^30 symbols when the batch covers the genome at least 2.5 times -- coverage of the whole set estimated from
+    // the candidate blocks per chain of the index's last run (a chain of a read of L bases holds the reads starting in
+    // L - m of its positions on one strand), times this batch's share of the reads.  SIGAX_READ_ORDER=0/1 decides instead.
     static const char* env_ord = getenv("SIGAX_READ_ORDER");
     static const char* env_omin = getenv("SIGAX_ORDER_MIN_SYMBOLS");
-    const bool order_on = env_ord ? env_ord[0] != '0' : ix->n_symbols >= (env_omin ? strtoull(env_omin, nullptr, 10) : (1ull << 30));
+    bool order_on = false;
+    if (env_ord) {
+      order_on = env_ord[0] != '0';
+    } else if (ix->n_symbols >= (env_omin ? strtoull(env_omin, nullptr, 10) : (1ull << 30)) && ix->n_strings > 0) {
+      const double mean_chain = ix->mean_chain16->load() / 16.0;
+      const double span = b->cur_max_len > b->minov ? (double)(b->cur_max_len - b->minov) : 1.0;
+      const double coverage = 2.0 * mean_chain * b->cur_max_len / span;
+      order_on = coverage * n / (double)ix->n_strings >= 2.5;
+    }
     static const char* env_coop0 = getenv("SIGAX_FIND_COOP");
     static const char* env_cmin0 = getenv("SIGAX_COOP_MIN_SYMBOLS");
     const u64 coop_min0 = env_cmin0 ? strtoull(env_cmin0, nullptr, 10) : (1ull << 31);
@@ -1217,18 +1306,20 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
                             32ull * perm_stride + 32 <= 32768;
     if (order_on && n >= 2 && (coop_would || 128ull * perm_stride + 8 <= find_stage_capacity())) {
       if (!b->perm_valid || b->perm_nsub != nsub) {
-        HIP_TRY(hipEventRecord(b->ev[EV_ORD0], st));
+        HIP_TRY(hipEventRecord(b->ev[EV_ORD0], st));  // behind the upload of the reads
+        HIP_TRY(hipStreamWaitEvent(ix->s_ord, b->ev[EV_ORD0], 0));
         b->last_ordered = true;
         const size_t tb = sigax_order_reads_tmp_bytes(n);
-        if ((rc = ensure(&b->ord_keys, (size_t)n * 8)) != SIGAX_OK) return rc;
-        if ((rc = ensure(&b->perm, (size_t)n * 8)) != SIGAX_OK) return rc;
+        if ((rc = ensure(&b->ord_keys, (size_t)n * 4)) != SIGAX_OK) return rc;
+        if ((rc = ensure(&b->perm, (size_t)n * 4)) != SIGAX_OK) return rc;
         if ((rc = ensure(&b->ord_tmp, tb)) != SIGAX_OK) return rc;
         uint32_t bounds[SIGAX_MAX_SUB + 1];
         for (unsigned i = 0; i <= nsub; ++i) bounds[i] = (uint32_t)((u64)n * i / nsub);
         rc = sigax_order_reads(b->d_seqs, b->d_offs, n, b->cur_max_len, bounds, nsub, (uint32_t*)b->ord_keys.p, (uint32_t*)b->perm.p, b->ord_tmp.p, tb,
-                               &b->perm_cur, st);
+                               &b->perm_cur, ix->s_ord);
         if (rc != SIGAX_OK) return rc;
-        HIP_TRY(hipEventRecord(b->ev[EV_ORD1], st));
+        HIP_TRY(hipEventRecord(b->ev[EV_ORD1], ix->s_ord));
+        HIP_TRY(hipStreamWaitEvent(st, b->ev[EV_ORD1], 0));
         b->perm_valid = true;
         b->perm_nsub = nsub;
       }
@@ -1252,6 +1343,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.chain_mask = (b->flags & SIGAX_DUPLICATE) ? 0x9u : (b->flags & SIGAX_RC) ? 0xFu : 0x5u;
     fa.cap = b->cap;
     fa.max_seen = ix->cap_seen->load();
+    fa.start_ok = (ix->st[0].start && ix->st[1].start && b->minov >= (uint32_t)SIGAX_START_K) ? 1u : 0u;
     fa.read_begin = rb;
     fa.read_end = re;
     fa.stage_bytes = 0;  // set by launch_find
@@ -1494,6 +1586,8 @@ extern "C" int sigax_batch_finish(sigax_batch* b, void* stream, sigax_stats* sta
     memset(&b->last, 0, sizeof(b->last));
     b->last.n_reads = b->n_reads;
     b->last.n_candidate_blocks = ds[DS_CAND_BLOCKS];
+    if (b->n_reads && !(b->flags & SIGAX_DUPLICATE))
+      b->ix->mean_chain16->store((uint32_t)std::min<u64>(ds[DS_CAND_BLOCKS] * 16 / (4ull * b->n_reads), 0xFFFFFFFFull));
     b->last.n_blocks = ds[DS_TOTAL_BLOCKS];
     b->last.n_edges = (b->flags & SIGAX_EDGES) ? ds[DS_TOTAL_EDGES] : 0;
     b->last.n_occ_find = ds[DS_OCC_FIND];

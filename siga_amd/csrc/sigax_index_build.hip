@@ -829,21 +829,25 @@ int sigax_decode_strand(const uint8_t* runs, u64 n_runs, u64 nsym, bool wide, vo
 // Locality order of a batch of reads for the block finder (sigax_api.cpp: enqueue): reads that overlap walk nested BWT
 // intervals a few steps apart, so when they sit in neighbouring lanes their rank lines -- and, on big indexes, the page
 // translations -- are still cached (reads handed over in genome order: +14 % at BASELINE configs[1], +23 % at the
-// configs[2] shape).  Real input comes in any order, so each read gets the key (hash of its minimizer = the
-// canonical 16-mer with the smallest hash, strand of that occurrence, its offset turned so that it grows with the read's
-// start in the genome): reads of one (hash, strand) class share a genome 16-mer and sort by start position inside the
-// class.  `bounds` = the sub-batches' slot ranges: the order is a permutation inside each.
+// configs[2] shape).  Real input comes in any order, so the reads of a batch are grouped by their minimizer (the canonical
+// 16-mer with the smallest hash): reads of one class share a genome 16-mer.  A counting sort in three launches -- keys +
+// histogram, scan, scatter -- because what the ordering costs a batch is the LATENCY of its launches on a GPU the other
+// batches' kernels keep full (every launch waits a millisecond or two for workgroup slots): the radix sort of round 2,
+// some twenty dependent launches, took 17 to 40 ms of a batch's chain at the configs[2] shape for 1 ms of work.  The order
+// inside a class is whatever the scatter's atomics make it (the results do not depend on the order, only the finder's
+// cache behaviour does).  `bounds` = the sub-batches' slot ranges: the order is a permutation inside each.
 // -------------------------------------------------------------------------------------------------------
 namespace {
 struct OrderBounds { u32 n, b[9]; };
+#define ORDER_CLASS_BITS 16u
 // One thread per read; the workgroup's `per` reads (one byte range of the batch; 256, or fewer when the reads are long, so
 // that the range fits the LDS buffer) are first copied to LDS with coalesced word loads -- round 2's kernel had every
-// thread walk its read byte by byte in global memory, 150 scattered loads per read, and took 2.4 ms per 1 M reads against
-// the 0.1 ms of the sort it feeds (250 bp reads read in place: 13.6 ms).  Tiles whose bytes still do not fit are read in place.
+// thread walk its read byte by byte in global memory, 150 scattered loads per read, and took 2.4 ms per 1 M reads (250 bp
+// reads read in place: 13.6 ms).  Tiles whose bytes still do not fit are read in place.
 #define KEYS_LDS_BYTES 49152u
 template <class GetByte>
-__device__ __forceinline__ u32 read_key(u32 L, u32 sub, GetByte get) {
-  u32 fwd = 0, rev = 0, have = 0, best = 0xFFFFFFFFu, bo = 0, bs = 0;
+__device__ __forceinline__ u32 read_class(u32 L, GetByte get) {
+  u32 fwd = 0, rev = 0, have = 0, best = 0xFFFFFFFFu;
   for (u32 i = 0; i < L; ++i) {
     const u32 ch = get(i);
     const u32 c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
@@ -851,20 +855,15 @@ __device__ __forceinline__ u32 read_key(u32 L, u32 sub, GetByte get) {
     fwd = (fwd << 2) | c;
     rev = (rev >> 2) | ((3u - c) << 30);
     if (++have < 16u) continue;
-    const u32 st = fwd <= rev ? 0u : 1u;
-    u32 h = (st ? rev : fwd) * 0x9E3779B1u;
+    u32 h = (fwd <= rev ? fwd : rev) * 0x9E3779B1u;
     h ^= h >> 15;
     h *= 0x85EBCA77u;
     h ^= h >> 13;
-    if (h < best) { best = h; bo = i - 15u; bs = st; }
+    best = h < best ? h : best;
   }
-  // 32 bits (four radix passes instead of eight): sub-batch, 19 bits of the hash (half a million classes: a batch of a
-  // few million reads at 30x holds fewer), strand, offset in 4-base steps up to 1 kb
-  const u32 o9 = (bo >> 2) > 0x1FFu ? 0x1FFu : (bo >> 2);
-  const u32 ord = bs ? o9 : 0x1FFu - o9;  // grows with the read's start position in the genome, per strand
-  return (sub << 29) | ((best >> 13) << 10) | (bs << 9) | ord;
+  return best >> (32u - ORDER_CLASS_BITS);
 }
-__global__ __launch_bounds__(256) void k_read_keys(const unsigned char* seqs, const u64* offs, u32 n, u32 per, OrderBounds ob, u32* keys, u32* idx) {
+__global__ __launch_bounds__(256) void k_read_keys(const unsigned char* seqs, const u64* offs, u32 n, u32 per, OrderBounds ob, u32* keys, u32* hist) {
   __shared__ __attribute__((aligned(16))) u32 tile[KEYS_LDS_BYTES / 4];
   const u32 r0 = blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
   const u64 lo = offs[r0], hi = offs[r1];
@@ -883,26 +882,47 @@ __global__ __launch_bounds__(256) void k_read_keys(const unsigned char* seqs, co
   for (u32 i = 1; i < ob.n; ++i) sub += r >= ob.b[i] ? 1u : 0u;
   const u64 b0 = offs[r];
   const u32 L = (u32)(offs[r + 1] - b0);
-  u32 key;
+  u32 cls;
   if (staged) {
     const u32 d = (u32)(reinterpret_cast<u64>(seqs) + b0 - alo);  // this read's first base in the tile
     const unsigned char* tb = reinterpret_cast<const unsigned char*>(tile) + d;
-    key = read_key(L, sub, [&](u32 i) { return (u32)tb[i]; });
+    cls = read_class(L, [&](u32 i) { return (u32)tb[i]; });
   } else {
-    key = read_key(L, sub, [&](u32 i) { return (u32)seqs[b0 + i]; });
+    cls = read_class(L, [&](u32 i) { return (u32)seqs[b0 + i]; });
   }
-  keys[r] = key;
-  idx[r] = r;
+  const u32 bucket = (sub << ORDER_CLASS_BITS) | cls;
+  keys[r] = bucket;
+  atomicAdd(&hist[bucket], 1u);
+}
+// exclusive scan of the class counts in place, one workgroup (8 x 65536 counters at most)
+__global__ __launch_bounds__(1024) void k_order_scan(u32* hist, u32 nb) {
+  __shared__ u32 part[1024];
+  const u32 per = (nb + 1023u) / 1024u;
+  const u32 lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+  u32 sum = 0;
+  for (u32 i = lo; i < hi; ++i) sum += hist[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (u32 off = 1; off < 1024u; off <<= 1) {
+    const u32 v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  u32 run = part[threadIdx.x] - sum;
+  for (u32 i = lo; i < hi; ++i) {
+    const u32 c = hist[i];
+    hist[i] = run;
+    run += c;
+  }
+}
+__global__ __launch_bounds__(256) void k_order_scatter_reads(const u32* keys, u32 n, u32* cursor, u32* perm) {
+  const u32 r = blockIdx.x * 256 + threadIdx.x;
+  if (r < n) perm[atomicAdd(&cursor[keys[r]], 1u)] = r;
 }
 }  // namespace
 
-size_t sigax_order_reads_tmp_bytes(uint32_t n) {
-  rocprim::double_buffer<u32> K(nullptr, nullptr);
-  rocprim::double_buffer<u32> V(nullptr, nullptr);
-  size_t tb = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, tb, K, V, (size_t)n, 0, 32, (hipStream_t)0);
-  return tb ? tb : 16;
-}
+size_t sigax_order_reads_tmp_bytes(uint32_t) { return ((size_t)8 << ORDER_CLASS_BITS) * 4; }  // the class counters
 
 int sigax_order_reads(const unsigned char* d_seqs, const u64* d_offs, u32 n, u32 max_len, const u32* bounds, u32 nsub, u32* keys, u32* vals,
                       void* tmp, size_t tmp_bytes, const u32** result, hipStream_t st) {
@@ -911,19 +931,22 @@ int sigax_order_reads(const unsigned char* d_seqs, const u64* d_offs, u32 n, u32
   OrderBounds ob;
   ob.n = nsub > 8 ? 8 : nsub;
   for (u32 i = 0; i < 9; ++i) ob.b[i] = i <= ob.n ? bounds[i] : n;
-  u32 per = 256;  // reads per workgroup: as many as fit the LDS tile, a power of two
-  while (per > 16 && (u64)per * max_len + 8 > KEYS_LDS_BYTES) per >>= 1;
-  hipLaunchKernelGGL(k_read_keys, dim3((n + per - 1) / per), dim3(256), 0, st, d_seqs, d_offs, n, per, ob, keys, vals);
-  rocprim::double_buffer<u32> K(keys, keys + n);
-  rocprim::double_buffer<u32> V(vals, vals + n);
-  size_t tb = tmp_bytes;
-  hipError_t e = rocprim::radix_sort_pairs(tmp, tb, K, V, (size_t)n, 0, 32, st);
-  if (e == hipSuccess) e = hipGetLastError();
+  const u32 nb = ob.n << ORDER_CLASS_BITS;
+  if ((size_t)nb * 4 > tmp_bytes) return sigax_fail(SIGAX_E_ARG, "ordering scratch too small");
+  u32* hist = (u32*)tmp;
+  hipError_t e = hipMemsetAsync(hist, 0, (size_t)nb * 4, st);
+  if (e == hipSuccess) {
+    u32 per = 256;  // reads per workgroup: as many as fit the LDS tile, a power of two
+    while (per > 16 && (u64)per * max_len + 8 > KEYS_LDS_BYTES) per >>= 1;
+    hipLaunchKernelGGL(k_read_keys, dim3((n + per - 1) / per), dim3(256), 0, st, d_seqs, d_offs, n, per, ob, keys, hist);
+    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, st, hist, nb);
+    hipLaunchKernelGGL(k_order_scatter_reads, dim3((n + 255) / 256), dim3(256), 0, st, (const u32*)keys, n, hist, vals);
+    e = hipGetLastError();
+  }
   if (e != hipSuccess) {
     (void)hipGetLastError();
     return sigax_fail(SIGAX_E_DEVICE, "ordering the batch's reads: %s", hipGetErrorString(e));
   }
-  *result = V.current();  // known on the host: it follows from the number of passes
   return SIGAX_OK;
 }
 

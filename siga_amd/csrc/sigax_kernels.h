@@ -44,6 +44,7 @@ struct FindArgs {
   const unsigned long long* offs;
   uint32_t n_reads, minov, chain_mask, cap;  // chain_mask bit o = find o runs; cap = slots per chain, last = containment
   uint32_t max_seen;                 // chains no longer than this need not report their length (DS_MAX_CHAIN)
+  uint32_t start_ok;                 // both strands carry the start table and min-overlap >= 12: chains may start twelve symbols in
   uint32_t read_begin, read_end;     // this launch's sub-batch
   uint32_t stage_bytes;              // dynamic LDS per workgroup that may hold the workgroup's reads (set by launch_find)
   uint32_t two_step;                 // both strands carry the two-step table (u32 positions only)
@@ -160,6 +161,12 @@ void launch_occ_batch(const FmStrand& s, bool wide, const unsigned long long* po
 void launch_kmer_count(const FmStrand& s, bool wide, const unsigned char* kmers, uint32_t k, unsigned long long n,
                        unsigned long long* out, hipStream_t st);
 void launch_find(const FindArgs& a, bool wide, hipStream_t st);
+// rows of strand s in suffix order?  bad3 (device, zeroed except [1] = ~0): pairs out of order, first such row, undecided pairs
+void launch_suffix_order_check(const FmStrand& s, const uint32_t* sai, uint32_t* isai_tmp, const uint32_t* read_len,
+                               unsigned long long n_strings, unsigned long long* bad3, hipStream_t st);
+// start table of the finder for chains whose primary index is `prim` (fm_layout.h): start_table_bytes(wide) bytes
+unsigned long long start_table_bytes(bool wide);
+void launch_start_build(const FmStrand& prim, const FmStrand& other, bool wide, void* tab, hipStream_t st);
 unsigned long long find_stage_capacity();  // bytes of reads a finder workgroup can stage in LDS
 void launch_filter_extract(const FxArgs& a, bool wide, unsigned grid, hipStream_t st);
 // qhint: items the three queues held last time (per sub-batch; ~0 = unknown), or NULL
@@ -186,8 +193,8 @@ void launch_pick_read_offsets(const unsigned long long* offs2, unsigned long lon
                               hipStream_t st);
 void launch_edges_fill(const EdgeArgs& a, hipStream_t st);
 // sigax_index_build.hip: locality order of a batch's reads (a permutation inside each of the nsub slot ranges bounds[0..nsub]),
-// queued on `st` without a host wait.  keys = 2 n u32, vals = 2 n u32 of scratch; *result = the half of vals that will hold
-// the order once the stream gets there.
+// queued on `st` without a host wait.  keys = n u32 of scratch, vals = n u32 = the order once the stream gets there
+// (*result = vals), tmp = sigax_order_reads_tmp_bytes(n) bytes for the class counters.
 size_t sigax_order_reads_tmp_bytes(uint32_t n);
 int sigax_order_reads(const unsigned char* d_seqs, const unsigned long long* d_offs, uint32_t n, uint32_t max_len, const uint32_t* bounds, uint32_t nsub,
                       uint32_t* keys, uint32_t* vals, void* tmp, size_t tmp_bytes, const uint32_t** result, hipStream_t st);

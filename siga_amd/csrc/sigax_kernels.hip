@@ -416,6 +416,59 @@ __device__ __forceinline__ u64 text_window(const FmStrand& st, u32 ld, u32 t) {
   __builtin_memcpy(&w, st.text + (u64)ld * st.text_stride + b, 8);  // rows are padded (fm_layout.h)
   return w << (64u - (end - 8u * b));
 }
+// -------------------------------------------------------------------------------------------------------
+// Self-check of an index against the order of record (sigax_index_check_order): the row table IS the suffix array, the
+// stretch text IS the reads, so whether the BWT rows are in suffix order can be seen on the device without a second
+// suffix sort: one lane per pair of adjacent rows compares the two suffixes of r0 $ r1 $ ... r(n-1) $ -- one '$' smaller
+// than A, C, G, T, comparisons running on past a '$' into the next read, the end of the text smallest (the order `siga
+// index` produces: SURVEY.md App. C model B; src/suffix_array_builder.cpp:472-674).  28 symbols per 8-byte load.
+// -------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 text_bits(const FmStrand& st, u32 ld, u32 off) {  // symbols off, off+1, ... lowest first
+  u64 w;
+  __builtin_memcpy(&w, st.text + (u64)ld * st.text_stride + (off >> 2), 8);
+  return w >> (2u * (off & 3u));
+}
+__global__ __launch_bounds__(256) void k_isai(const u32* sai, u64 n, u32* isai) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) isai[sai[i]] = (u32)i;
+}
+__global__ __launch_bounds__(256) void k_suffix_order_check(FmStrand st, const u32* sai, const u32* isai, const u32* read_len, u64 n_strings,
+                                                            u64* bad) {
+  const u64 p = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (p + 1 >= st.n) return;
+  u32 la, ta, lb, tb;
+  row_lookup(st, p, la, ta);
+  row_lookup(st, p + 1, lb, tb);
+  int verdict = -1;  // 1: suffix(p) < suffix(p + 1); 0: not
+  for (u32 hops = 0; verdict < 0 && hops < 4096u; ++hops) {
+    const u32 ida = sai[la], idb = sai[lb];
+    const u32 ra = read_len[ida] - ta, rb = read_len[idb] - tb;  // symbols left in each read
+    const u32 m = ra < rb ? ra : rb;
+    for (u32 k = 0; k < m && verdict < 0;) {
+      const u32 c = m - k < 28u ? m - k : 28u;
+      const u64 x = (text_bits(st, la, ta + k) ^ text_bits(st, lb, tb + k)) & ((1ull << (2u * c)) - 1ull);
+      if (x) {
+        const u32 d = (u32)__builtin_ctzll(x) >> 1;
+        const u32 sa = (u32)(text_bits(st, la, ta + k + d) & 3ull), sb = (u32)(text_bits(st, lb, tb + k + d) & 3ull);
+        verdict = sa < sb ? 1 : 0;
+      }
+      k += c;
+    }
+    if (verdict >= 0) break;
+    if (ra != rb) { verdict = ra < rb ? 1 : 0; break; }  // a '$' against a base
+    // both reads end here: '$' against '$', on into the reads that follow them in the text (the end of the text is smallest)
+    if ((u64)ida + 1 >= n_strings || (u64)idb + 1 >= n_strings) { verdict = ((u64)ida + 1 >= n_strings && (u64)idb + 1 < n_strings) ? 1 : 0; break; }
+    la = isai[ida + 1]; ta = 0;
+    lb = isai[idb + 1]; tb = 0;
+  }
+  if (verdict == 0) {
+    atomicAdd(&bad[0], 1ull);
+    atomicMin(&bad[1], p);
+  } else if (verdict < 0) {
+    atomicAdd(&bad[2], 1ull);  // undecided after 4096 reads' worth of ties (thousands of identical reads in a row)
+  }
+}
+
 #define ROWS_KMAX 14  // most symbols an entry can carry (fm_layout.h)
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_rows_fill(FmStrand s, u64 n_stretch, const u64* info, unsigned char* sa, u32 sa_bits, u32 ld_bits, u32 t_bits,
@@ -464,6 +517,42 @@ __global__ __launch_bounds__(256) void k_rows_fill(FmStrand s, u64 n_stretch, co
   }
   // the rows whose K symbols run past the read's first base: rank 0 from there on (t counts on below zero for the formula)
   for (u32 i = 1; i < K; ++i) insert(0, 0, false, 0ull - i);
+}
+
+// -------------------------------------------------------------------------------------------------------
+// Start table of the block finder (fm_layout.h): one lane per 12-mer walks IntervalPair::init + eleven updateL steps
+// (src/overlap_builder.cpp:91-122) with `prim` as the primary index.
+// -------------------------------------------------------------------------------------------------------
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_start_build(FmStrand prim, FmStrand other, void* tab) {
+  typedef typename PosOf<WIDE>::type P;
+  const u32 code = blockIdx.x * 256 + threadIdx.x;
+  if (code >= (1u << (2 * SIGAX_START_K))) return;
+  const FmRef f = fm_ref(prim, 0);
+  u32 r = 1u + ((code >> (2 * (SIGAX_START_K - 1))) & 3u);
+  P lo0 = (P)prim.C[r], sz = (P)prim.total[r], lo1 = (P)other.C[r];
+  u32 s = 1;
+  for (int i = 1; i < SIGAX_START_K && sz != 0; ++i, ++s) {
+    r = 1u + ((code >> (2 * (SIGAX_START_K - 1 - i))) & 3u);
+    const u64 n = prim.n;
+    const u64 pl = (u64)lo0 > n ? n : (u64)lo0, pu0 = (u64)(P)(lo0 + sz), pu = pu0 > n ? n : pu0;
+    const Cnt4P<P> l = fm_rank4p<WIDE>(f, (P)pl), u = fm_rank4p<WIDE>(f, (P)pu);
+    const P da = u.a - l.a, dc = u.c - l.c, dg = u.g - l.g, dt = u.t - l.t;
+    const P dd = sz - (da + dc + dg + dt);
+    const P acc = r == 1 ? dd : r == 2 ? dd + da : r == 3 ? dd + da + dc : dd + da + dc + dg;
+    const P lc = r == 1 ? l.a : r == 2 ? l.c : r == 3 ? l.g : l.t;
+    const P dcur = r == 1 ? da : r == 2 ? dc : r == 3 ? dg : dt;
+    lo1 += acc;
+    lo0 = (P)prim.C[r] + lc;
+    sz = dcur;
+  }
+  if (WIDE) {
+    ulonglong2* q = reinterpret_cast<ulonglong2*>(tab) + 2ull * code;
+    q[0] = make_ulonglong2((u64)lo0, (u64)lo1);
+    q[1] = make_ulonglong2((u64)sz, (u64)s);
+  } else {
+    reinterpret_cast<uint4*>(tab)[code] = make_uint4((u32)lo0, (u32)lo1, (u32)sz, s);
+  }
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -777,7 +866,35 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
   };
 
   P lo0 = 0, sz = 0, lo1 = 0;
-  if (live) {
+  u32 s = 1;                  // this chain's current match length
+  bool started = false;
+  if (STAGED && live && A.start_ok && L >= (u32)SIGAX_START_K) {
+    // the chain's first twelve symbols from the start table of its primary index (fm_layout.h), when they are all ACGT
+    const void* ST = pf ? A.fwd.start : A.rev.start;
+    u32 code = 0;
+    bool acgt = true;
+#pragma unroll
+    for (u32 i = 0; i < (u32)SIGAX_START_K; ++i) {
+      const u32 at = rdo + (fromStart ? i : L - 1u - i);
+      u32 r = COOP ? rd_rank(rd, at) : base_rank(rd[at]);
+      if (comp) r = comp_rank(r);
+      acgt = acgt && r != 0u;
+      code = (code << 2) | ((r - 1u) & 3u);
+    }
+    if (acgt) {
+      if (WIDE) {
+        const ulonglong2* q = reinterpret_cast<const ulonglong2*>(ST) + 2ull * code;
+        const ulonglong2 a = q[0], b = q[1];
+        lo0 = (P)a.x; lo1 = (P)a.y; sz = (P)b.x; s = (u32)b.y;
+      } else {
+        const uint4 e = reinterpret_cast<const uint4*>(ST)[code];
+        lo0 = (P)e.x; lo1 = (P)e.y; sz = (P)e.z; s = e.w;
+      }
+      started = true;
+    }
+  }
+  nsec += (u32)__popcll(__ballot(started));
+  if (live && !started) {
     u32 r = (STAGED && COOP) ? rd_rank(rd, rdo + (fromStart ? 0 : L - 1)) : base_rank(STAGED ? rd[rdo + (fromStart ? 0 : L - 1)] : sq[fromStart ? 0 : L - 1]);
     if (comp) r = comp_rank(r);
     // IntervalPair::init (overlap_builder.cpp:91-94, fmindex.h:90-93)
@@ -785,7 +902,6 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
   }
   // All 64 lanes stay in the loop until the wave's last chain is done (a finished chain idles, predicated off):
   // the quad-cooperative record stores need every lane of a quad present.
-  u32 s = 1;                  // this chain's current match length
   bool full = !live;          // the arena slots of this chain ran out ("cannot happen": cap comes from the longest read)
   // probe = ranges; probe.updateL('$') (overlap_builder.cpp:861-865) is valid <=> d > 0: park the candidate block in
   // this lane's row; returns whether the row is now full (to be written by the quad)
@@ -1612,8 +1728,11 @@ struct Fx {
   }
 };
 
+// Held to 128 registers (it spills; it serves a fraction of a per cent of the reads): with its natural 170 no wave of it
+// fits a SIMD beside the finder's resident waves, and a launch -- usually an EMPTY one -- waited milliseconds for a
+// finder workgroup to retire on some CU while the batch's tail waited behind it.
 template <bool WIDE>
-__global__ __launch_bounds__(256) void k_filter_extract(FxArgs A) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_filter_extract(FxArgs A) {
   __shared__ FmTables tb;
   fm_tables_load(tb, A.fwd, A.rev);
   u64 gid = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -3466,6 +3585,19 @@ void launch_prefix_build(const FmStrand& s, bool wide, void* tab, hipStream_t st
   const unsigned g = (1u << (2 * SIGAX_PREFIX_K)) / 256u;
   if (wide) hipLaunchKernelGGL(k_prefix_build<true>, dim3(g), dim3(256), 0, st, s, tab);
   else hipLaunchKernelGGL(k_prefix_build<false>, dim3(g), dim3(256), 0, st, s, tab);
+}
+
+unsigned long long start_table_bytes(bool wide) { return (1ull << (2 * SIGAX_START_K)) * (wide ? 32u : 16u); }
+void launch_start_build(const FmStrand& prim, const FmStrand& other, bool wide, void* tab, hipStream_t st) {
+  const unsigned g = (1u << (2 * SIGAX_START_K)) / 256u;
+  if (wide) hipLaunchKernelGGL(k_start_build<true>, dim3(g), dim3(256), 0, st, prim, other, tab);
+  else hipLaunchKernelGGL(k_start_build<false>, dim3(g), dim3(256), 0, st, prim, other, tab);
+}
+
+void launch_suffix_order_check(const FmStrand& s, const u32* sai, u32* isai_tmp, const u32* read_len, u64 n_strings, u64* bad3, hipStream_t st) {
+  if (n_strings == 0 || s.n < 2) return;
+  hipLaunchKernelGGL(k_isai, dim3(nblk(n_strings, 256)), dim3(256), 0, st, sai, n_strings, isai_tmp);
+  hipLaunchKernelGGL(k_suffix_order_check, dim3(nblk(s.n - 1, 256)), dim3(256), 0, st, s, sai, (const u32*)isai_tmp, read_len, n_strings, bad3);
 }
 
 void launch_correct(const CorrectArgs& a, bool wide, hipStream_t st) {

@@ -155,6 +155,12 @@ class FMIndexPair:
         _check(_lib.lib().sigax_index_set_reads(self._h, lengths.ctypes.data, ranks.ctypes.data, len(lengths)),
                "sigax_index_set_reads")
 
+    def check_order(self, which=0):
+        """sigax_index_check_order: (pairs of adjacent BWT rows out of suffix order, first such row, undecided pairs)"""
+        bad, first, und = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(_lib.lib().sigax_index_check_order(self._h, which, C.byref(bad), C.byref(first), C.byref(und)), "sigax_index_check_order")
+        return int(bad.value), int(first.value), int(und.value)
+
     def occ(self, positions, which=0):
         """FMIndex::getOcc for many positions -> [n,5] ($,A,C,G,T)."""
         pos = np.ascontiguousarray(positions, dtype=np.uint64)

@@ -125,6 +125,11 @@ def _big_case(tag, N, G, L, seed, world, sample, M=45):
     # edge records of the whole shard from the GPU's blocks by the numpy restatement of the converter
     exp = expected_edges(got10, full["block_offs"], fwd.sai(), rev.sai(), np.full(N, L, dtype=np.uint32), rank, read_base=lo)
     assert np.array_equal(edges_matrix(e), exp)
+    # the index files this test and the oracle sample both read were written by the GPU suffix sorter: every pair of
+    # adjacent BWT rows of both strands is in the order of record (checked on the device: sigax_index_check_order)
+    for which in (0, 1):
+        bad, first, und = pair.check_order(which)
+        assert bad == 0 and und == 0, (tag, which, bad, first, und)
     t7 = time.time()
     s = full["stats"]
     print("%s: %d symbols/strand wide=%d device %.1f GB | reads %.0fs, index build %.1fs, load %.1fs, shard of %d reads %.1fs "

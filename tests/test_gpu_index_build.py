@@ -113,3 +113,55 @@ def test_cli_index_on_gpu(tmp_path):
     r = subprocess.run([host.CLI_PATH, "index", "--cpu", "-p", "c", fx.fa], cwd=cwd, capture_output=True)
     assert r.returncode == 0, r.stderr
     _same(os.path.join(cwd, "c"), fx.prefix)
+
+
+def _rl_units(bwt_ranks):
+    """RL units of src/rlstring.h:10-63 with the 31-cap of src/bwt.cpp:17 for a sequence of symbol ranks"""
+    out = []
+    i = 0
+    while i < len(bwt_ranks):
+        j = i
+        while j < len(bwt_ranks) and bwt_ranks[j] == bwt_ranks[i] and j - i < 31:
+            j += 1
+        out.append((bwt_ranks[i] << 5) | (j - i))
+        i = j
+    return np.array(out, dtype=np.uint8)
+
+
+def _index_with_sentinels_ordered_by_read(seqs, reverse=False):
+    """A valid FM-index of the same reads in ANOTHER suffix order: every read's own '$', ordered by read index (what `-a sais`
+    gives) instead of one shared '$' with comparisons running on into the next read."""
+    if reverse:
+        seqs = [s[::-1] for s in seqs]
+    rank = {"A": 1, "C": 2, "G": 3, "T": 4}
+    rows = [(("", i), i, len(s)) for i, s in enumerate(seqs)]  # the '$' suffixes first, by read index
+    rows += sorted(((s[t:], i), i, t) for i, s in enumerate(seqs) for t in range(len(s)))
+    bwt = [rank[seqs[i][t - 1]] if t > 0 else 0 for _, i, t in rows]
+    sai = np.array([i for _, i, t in rows if t == 0], dtype=np.uint32)  # the full-read suffixes in row order (no empty reads here)
+    return _rl_units(bwt), sai, len(bwt)
+
+
+def test_order_check_passes_builders_and_flags_another_suffix_order():
+    """sigax_index_check_order compares every pair of adjacent BWT rows on the device (row table = suffix array, stretch text =
+    reads).  The oracle's and the GPU builder's indexes are in order; an index of the same reads with the sentinels ordered
+    by read index -- a valid FM-index, LF walks and all, but not the order of record -- is flagged."""
+    import siga_amd
+    from siga_amd.overlap import name_ranks
+    for name in ("toy", "dup", "tiny"):
+        fx = fixture(name)
+        pair = siga_amd.FMIndexPair.load(fx.prefix)
+        pair.set_reads(np.array([len(s) for s in fx.seqs], dtype=np.uint32), name_ranks([n for n, _ in fx.reads]))
+        for which in (0, 1):
+            bad, first, und = pair.check_order(which)
+            assert bad == 0, (name, which, bad, first)
+        pair.close()
+    fx = fixture("dup")
+    seqs = fx.seqs
+    runs, sai, nsym = _index_with_sentinels_ordered_by_read(seqs)
+    rruns, rsai, _ = _index_with_sentinels_ordered_by_read(seqs, reverse=True)
+    assert nsym == sum(len(s) + 1 for s in seqs) and len(sai) == len(seqs)
+    pair = siga_amd.FMIndexPair.from_memory(runs, rruns, nsym, len(seqs), sai, rsai)
+    pair.set_reads(np.array([len(s) for s in seqs], dtype=np.uint32), name_ranks([n for n, _ in fx.reads]))
+    bad, first, und = pair.check_order(0)
+    assert bad > 0
+    pair.close()

@@ -73,6 +73,19 @@ def test_cooperative_finder_bit_exact():
     _run_parity({"SIGAX_FIND_COOP": "1"}, "hits_and_asqg or non_acgt or duplicate or in_flight or deep or mid")
 
 
+def test_finder_start_table_bit_exact():
+    """Chains of the block finder may start twelve symbols in, from a table of all 12-mers per strand (built at open for
+    indexes of 2^22 symbols and more; forced here): same blocks, same hits order, same count of rank evaluations as the walk --
+    also where the range empties inside the first twelve symbols, reads hold non-ACGT bases or are shorter than twelve, and
+    with min-overlap below twelve (no table then)."""
+    _run_parity({"SIGAX_FIND_START": "1"}, "hits_and_asqg or non_acgt or duplicate or deep or in_flight")
+    _run_parity({"SIGAX_FIND_START": "1", "SIGAX_FIND_COOP": "1"}, "hits_and_asqg or non_acgt or deep")
+    _run_parity({"SIGAX_FIND_START": "1", "SIGAX_FORCE_WIDE": "1"}, "hits_and_asqg and (toy or rep or ragged or tiny)")
+    _run_parity({"SIGAX_FIND_START": "1", "SIGAX_TWO_STEP": "0"}, "hits_and_asqg and (toy or ragged)")
+    _run_parity({"SIGAX_FIND_START": "1"}, None, seeds=(1, 2, 3, 5, 8, 13, 21))
+    _run_parity({"SIGAX_FIND_START": "1", "SIGAX_FIND_COOP": "1", "SIGAX_FORCE_WIDE": "1", "SIGAX_READ_ORDER": "1"}, None, seeds=(2, 8, 21))
+
+
 def test_correct_without_the_kmer_prefix_table():
     """`siga correct`'s k-mer lookups start from the interval of their last twelve bases (a table of all 12-mers, built on
     first use); SIGAX_KMER_PREFIX=0 walks every step as the reference does.  Same files either way, 32- and 64-bit positions."""
