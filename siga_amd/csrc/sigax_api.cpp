@@ -127,7 +127,6 @@ struct sigax_index {
   // chain on average, 30-odd at most, 106 in the worst case.  A run whose chains outgrow their slots is repeated with what
   // it reported (sigax_batch_finish).
   std::atomic<uint32_t>* cap_seen;
-  std::atomic<uint32_t>* mean_chain16;  // 16 x the mean candidate blocks per chain of the last finished run (0: none yet)
   bool split_strands;  // two-step tables too large to gather from both at once: one finder launch per strand
 };
 
@@ -316,7 +315,6 @@ extern "C" void sigax_index_close(sigax_index* ix) {
   if (ix->s_ord) hipStreamDestroy(ix->s_ord);
   delete ix->enqueue_mu;
   delete ix->cap_seen;
-  delete ix->mean_chain16;
   delete ix;
 }
 
@@ -538,7 +536,6 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
   ix->device = device;
   ix->enqueue_mu = new std::mutex();
   ix->cap_seen = new std::atomic<uint32_t>(0);
-  ix->mean_chain16 = new std::atomic<uint32_t>(0);
   if (hipDeviceGetAttribute(&ix->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ix->n_cu <= 0) ix->n_cu = 256;
   {
     // the finder is the critical path of a step: its stream gets the higher priority
@@ -743,7 +740,6 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
   ix->device = device;
   ix->enqueue_mu = new std::mutex();
   ix->cap_seen = new std::atomic<uint32_t>(src->cap_seen->load());
-  ix->mean_chain16 = new std::atomic<uint32_t>(src->mean_chain16->load());
   ix->n_cu = src->n_cu;
   (void)hipDeviceGetAttribute(&ix->n_cu, hipDeviceAttributeMultiprocessorCount, device);
   {
@@ -1280,25 +1276,16 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   b->last_ordered = false;
   const uint32_t perm_stride = (b->cur_max_len + 3u) & ~3u;
   {
-    // When does it pay?  Measured with the ordering inside the timed step, as every product batch pays it: at BASELINE
-    // configs[1] 105.0 M reads/s with it against 110.5 M without (the table is cache-resident there and the order buys the
-    // finder 1 to 5 %); at the configs[4] shape 35.7 against 38.8 M (a batch of 1 M reads out of 50 M covers the genome 1.1
-    // times: hardly any read has a neighbour in its batch); at the configs[2] shape, where a batch covers the genome 3.75
-    // times and what the order saves is page translations, the finder goes from 26.9 to 23.9 ms per 2.5 M reads.  So: on
-    // from 2^30 symbols when the batch covers the genome at least 2.5 times -- coverage of the whole set estimated from
-    // the candidate blocks per chain of the index's last run (a chain of a read of L bases holds the reads starting in
-    // L - m of its positions on one strand), times this batch's share of the reads.  SIGAX_READ_ORDER=0/1 decides instead.
+    // Off unless SIGAX_READ_ORDER=1.  Measured with the ordering inside the timed step, as every product batch pays it:
+    // BASELINE configs[1] 107-111 M reads/s with it against 119-121 M without (the table is cache-resident there and the
+    // order buys the finder 1 to 5 %); the configs[2] shape 87.2 / 89.3 M against 90.9 / 89.6 M (3.75-fold coverage inside a
+    // batch: the finder gains 0.4 ms of 26.7, the batch's chain gets 7 ms longer); the configs[4] shape 35.7 against 38.8 M
+    // (a batch covers the genome 1.1 times: hardly any read has a neighbour in its batch).  What reads in GENOME order are
+    // worth (+14 % / +23 %) needs them sorted by position inside a class too -- round 2's full radix sort got
+    // the configs[2] finder from 26.9 to 22.4 ms -- and that costs twenty dependent launches on a GPU the other batches
+    // keep full: 17 to 40 ms on the batch's chain.  Kept as an option for callers whose batches are deep.
     static const char* env_ord = getenv("SIGAX_READ_ORDER");
-    static const char* env_omin = getenv("SIGAX_ORDER_MIN_SYMBOLS");
-    bool order_on = false;
-    if (env_ord) {
-      order_on = env_ord[0] != '0';
-    } else if (ix->n_symbols >= (env_omin ? strtoull(env_omin, nullptr, 10) : (1ull << 30)) && ix->n_strings > 0) {
-      const double mean_chain = ix->mean_chain16->load() / 16.0;
-      const double span = b->cur_max_len > b->minov ? (double)(b->cur_max_len - b->minov) : 1.0;
-      const double coverage = 2.0 * mean_chain * b->cur_max_len / span;
-      order_on = coverage * n / (double)ix->n_strings >= 2.5;
-    }
+    const bool order_on = env_ord != nullptr && env_ord[0] != '0';
     static const char* env_coop0 = getenv("SIGAX_FIND_COOP");
     static const char* env_cmin0 = getenv("SIGAX_COOP_MIN_SYMBOLS");
     const u64 coop_min0 = env_cmin0 ? strtoull(env_cmin0, nullptr, 10) : (1ull << 31);
@@ -1309,7 +1296,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
         HIP_TRY(hipEventRecord(b->ev[EV_ORD0], st));  // behind the upload of the reads
         HIP_TRY(hipStreamWaitEvent(ix->s_ord, b->ev[EV_ORD0], 0));
         b->last_ordered = true;
-        const size_t tb = sigax_order_reads_tmp_bytes(n);
+        const size_t tb = sigax_order_reads_tmp_bytes(nsub);
         if ((rc = ensure(&b->ord_keys, (size_t)n * 4)) != SIGAX_OK) return rc;
         if ((rc = ensure(&b->perm, (size_t)n * 4)) != SIGAX_OK) return rc;
         if ((rc = ensure(&b->ord_tmp, tb)) != SIGAX_OK) return rc;
@@ -1586,8 +1573,6 @@ extern "C" int sigax_batch_finish(sigax_batch* b, void* stream, sigax_stats* sta
     memset(&b->last, 0, sizeof(b->last));
     b->last.n_reads = b->n_reads;
     b->last.n_candidate_blocks = ds[DS_CAND_BLOCKS];
-    if (b->n_reads && !(b->flags & SIGAX_DUPLICATE))
-      b->ix->mean_chain16->store((uint32_t)std::min<u64>(ds[DS_CAND_BLOCKS] * 16 / (4ull * b->n_reads), 0xFFFFFFFFull));
     b->last.n_blocks = ds[DS_TOTAL_BLOCKS];
     b->last.n_edges = (b->flags & SIGAX_EDGES) ? ds[DS_TOTAL_EDGES] : 0;
     b->last.n_occ_find = ds[DS_OCC_FIND];

@@ -839,15 +839,27 @@ int sigax_decode_strand(const uint8_t* runs, u64 n_runs, u64 nsym, bool wide, vo
 // -------------------------------------------------------------------------------------------------------
 namespace {
 struct OrderBounds { u32 n, b[9]; };
-#define ORDER_CLASS_BITS 16u
-// One thread per read; the workgroup's `per` reads (one byte range of the batch; 256, or fewer when the reads are long, so
-// that the range fits the LDS buffer) are first copied to LDS with coalesced word loads -- round 2's kernel had every
-// thread walk its read byte by byte in global memory, 150 scattered loads per read, and took 2.4 ms per 1 M reads (250 bp
-// reads read in place: 13.6 ms).  Tiles whose bytes still do not fit are read in place.
-#define KEYS_LDS_BYTES 49152u
+// Class = the top bits of the minimizer's hash: 2^20 classes (a batch of a few million reads at a few-fold coverage holds
+// about a million minimizers; reads put side by side only help each other when they really share one).  SIGAX_ORDER_BITS.
+static u32 order_class_bits() {
+  static const u32 bits = [] {
+    const char* env = getenv("SIGAX_ORDER_BITS");
+    const int b = env ? atoi(env) : 20;
+    return (u32)(b < 8 ? 8 : b > 24 ? 24 : b);
+  }();
+  return bits;
+}
+// One thread per read, one wave per workgroup; its `per` reads (one byte range of the batch; 64, or fewer when the reads
+// are long, so that the range fits the LDS tile) are first copied to LDS with coalesced word loads -- round 2's kernel had
+// every thread walk its read byte by byte in global memory, 150 scattered loads per read, and took 2.4 ms per 1 M reads (250
+// bp reads read in place: 13.6 ms).  Tiles whose bytes still do not fit are read in place.  The tile is 16 KB: this kernel
+// runs beside the finders of the batches in flight, which leave a CU 4 to 40 KB of LDS, and a workgroup that asks for
+// 48 KB waits for finder workgroups to retire (measured: 25 to 40 ms for 1 ms of work at the BASELINE configs[2] shape).
+#define KEYS_LDS_BYTES 16384u
+#define KEYS_NT 64
 template <class GetByte>
-__device__ __forceinline__ u32 read_class(u32 L, GetByte get) {
-  u32 fwd = 0, rev = 0, have = 0, best = 0xFFFFFFFFu;
+__device__ __forceinline__ u32 read_class(u32 L, u32 bits, GetByte get) {
+  u32 fwd = 0, rev = 0, have = 0, best = 0xFFFFFFFFu, bs = 0;
   for (u32 i = 0; i < L; ++i) {
     const u32 ch = get(i);
     const u32 c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
@@ -855,15 +867,19 @@ __device__ __forceinline__ u32 read_class(u32 L, GetByte get) {
     fwd = (fwd << 2) | c;
     rev = (rev >> 2) | ((3u - c) << 30);
     if (++have < 16u) continue;
-    u32 h = (fwd <= rev ? fwd : rev) * 0x9E3779B1u;
+    const u32 st = fwd <= rev ? 0u : 1u;
+    u32 h = (st ? rev : fwd) * 0x9E3779B1u;
     h ^= h >> 15;
     h *= 0x85EBCA77u;
     h ^= h >> 13;
-    best = h < best ? h : best;
+    if (h < best) { best = h; bs = st; }
   }
-  return best >> (32u - ORDER_CLASS_BITS);
+  // the strand the minimizer was seen on is part of the class: reads of one class then lie the same way round on the
+  // genome, so that it is the same chain (= the same wave of the finder) of each that walks the same rows
+  return ((best >> (33u - bits)) << 1) | bs;
 }
-__global__ __launch_bounds__(256) void k_read_keys(const unsigned char* seqs, const u64* offs, u32 n, u32 per, OrderBounds ob, u32* keys, u32* hist) {
+__global__ __launch_bounds__(KEYS_NT) void k_read_keys(const unsigned char* seqs, const u64* offs, u32 n, u32 per, u32 bits, OrderBounds ob, u32* keys,
+                                                       u32* hist) {
   __shared__ __attribute__((aligned(16))) u32 tile[KEYS_LDS_BYTES / 4];
   const u32 r0 = blockIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
   const u64 lo = offs[r0], hi = offs[r1];
@@ -873,7 +889,7 @@ __global__ __launch_bounds__(256) void k_read_keys(const unsigned char* seqs, co
   if (staged) {
     const u32* src = reinterpret_cast<const u32*>(alo);
     const u32 nw = (u32)((nbytes + 3) >> 2);
-    for (u32 w = threadIdx.x; w < nw; w += 256) tile[w] = src[w];
+    for (u32 w = threadIdx.x; w < nw; w += KEYS_NT) tile[w] = src[w];
   }
   __syncthreads();
   const u32 r = r0 + threadIdx.x;
@@ -886,15 +902,15 @@ __global__ __launch_bounds__(256) void k_read_keys(const unsigned char* seqs, co
   if (staged) {
     const u32 d = (u32)(reinterpret_cast<u64>(seqs) + b0 - alo);  // this read's first base in the tile
     const unsigned char* tb = reinterpret_cast<const unsigned char*>(tile) + d;
-    cls = read_class(L, [&](u32 i) { return (u32)tb[i]; });
+    cls = read_class(L, bits, [&](u32 i) { return (u32)tb[i]; });
   } else {
-    cls = read_class(L, [&](u32 i) { return (u32)seqs[b0 + i]; });
+    cls = read_class(L, bits, [&](u32 i) { return (u32)seqs[b0 + i]; });
   }
-  const u32 bucket = (sub << ORDER_CLASS_BITS) | cls;
+  const u32 bucket = (sub << bits) | cls;
   keys[r] = bucket;
   atomicAdd(&hist[bucket], 1u);
 }
-// exclusive scan of the class counts in place, one workgroup (8 x 65536 counters at most)
+// exclusive scan of the class counts in place, one workgroup
 __global__ __launch_bounds__(1024) void k_order_scan(u32* hist, u32 nb) {
   __shared__ u32 part[1024];
   const u32 per = (nb + 1023u) / 1024u;
@@ -922,7 +938,7 @@ __global__ __launch_bounds__(256) void k_order_scatter_reads(const u32* keys, u3
 }
 }  // namespace
 
-size_t sigax_order_reads_tmp_bytes(uint32_t) { return ((size_t)8 << ORDER_CLASS_BITS) * 4; }  // the class counters
+size_t sigax_order_reads_tmp_bytes(uint32_t nsub) { return ((size_t)(nsub ? nsub : 1) << order_class_bits()) * 4; }  // the class counters
 
 int sigax_order_reads(const unsigned char* d_seqs, const u64* d_offs, u32 n, u32 max_len, const u32* bounds, u32 nsub, u32* keys, u32* vals,
                       void* tmp, size_t tmp_bytes, const u32** result, hipStream_t st) {
@@ -931,14 +947,15 @@ int sigax_order_reads(const unsigned char* d_seqs, const u64* d_offs, u32 n, u32
   OrderBounds ob;
   ob.n = nsub > 8 ? 8 : nsub;
   for (u32 i = 0; i < 9; ++i) ob.b[i] = i <= ob.n ? bounds[i] : n;
-  const u32 nb = ob.n << ORDER_CLASS_BITS;
+  const u32 bits = order_class_bits();
+  const u32 nb = ob.n << bits;
   if ((size_t)nb * 4 > tmp_bytes) return sigax_fail(SIGAX_E_ARG, "ordering scratch too small");
   u32* hist = (u32*)tmp;
   hipError_t e = hipMemsetAsync(hist, 0, (size_t)nb * 4, st);
   if (e == hipSuccess) {
-    u32 per = 256;  // reads per workgroup: as many as fit the LDS tile, a power of two
-    while (per > 16 && (u64)per * max_len + 8 > KEYS_LDS_BYTES) per >>= 1;
-    hipLaunchKernelGGL(k_read_keys, dim3((n + per - 1) / per), dim3(256), 0, st, d_seqs, d_offs, n, per, ob, keys, hist);
+    u32 per = KEYS_NT;  // reads per workgroup: as many as fit the LDS tile, a power of two
+    while (per > 8 && (u64)per * max_len + 8 > KEYS_LDS_BYTES) per >>= 1;
+    hipLaunchKernelGGL(k_read_keys, dim3((n + per - 1) / per), dim3(KEYS_NT), 0, st, d_seqs, d_offs, n, per, bits, ob, keys, hist);
     hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(1024), 0, st, hist, nb);
     hipLaunchKernelGGL(k_order_scatter_reads, dim3((n + 255) / 256), dim3(256), 0, st, (const u32*)keys, n, hist, vals);
     e = hipGetLastError();

@@ -194,8 +194,8 @@ void launch_pick_read_offsets(const unsigned long long* offs2, unsigned long lon
 void launch_edges_fill(const EdgeArgs& a, hipStream_t st);
 // sigax_index_build.hip: locality order of a batch's reads (a permutation inside each of the nsub slot ranges bounds[0..nsub]),
 // queued on `st` without a host wait.  keys = n u32 of scratch, vals = n u32 = the order once the stream gets there
-// (*result = vals), tmp = sigax_order_reads_tmp_bytes(n) bytes for the class counters.
-size_t sigax_order_reads_tmp_bytes(uint32_t n);
+// (*result = vals), tmp = sigax_order_reads_tmp_bytes(nsub) bytes for the class counters.
+size_t sigax_order_reads_tmp_bytes(uint32_t nsub);
 int sigax_order_reads(const unsigned char* d_seqs, const unsigned long long* d_offs, uint32_t n, uint32_t max_len, const uint32_t* bounds, uint32_t nsub,
                       uint32_t* keys, uint32_t* vals, void* tmp, size_t tmp_bytes, const uint32_t** result, hipStream_t st);
 

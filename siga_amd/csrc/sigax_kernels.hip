@@ -3633,8 +3633,11 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
     // 64 reads per workgroup; the dynamic LDS holds exactly their bases (no residency padding: LDS is what limits it)
     const unsigned gc = nblk((u64)(a.read_end - a.read_begin), 64u);
     b.stage_bytes = a.coop_stage_bytes;
-    static const char* env_pad = getenv("SIGAX_FIND_COOP_PAD");  // measurement aid: unused LDS = fewer workgroups per CU
-    const unsigned dyn = a.coop_stage_bytes + (env_pad ? (unsigned)atoi(env_pad) : 0u);
+    // 2 KB of unused LDS per workgroup: five of them per CU instead of six, and 20 KB of a CU's LDS left for the kernels
+    // that run beside the finder (with six the filter/extract workgroups of the batches in flight found no LDS on a CU
+    // until finder workgroups retired: BASELINE configs[2] shape 88.3 -> 90.3 M reads/s; SIGAX_FIND_COOP_PAD=0 for six)
+    static const char* env_pad = getenv("SIGAX_FIND_COOP_PAD");
+    const unsigned dyn = a.coop_stage_bytes + (env_pad ? (unsigned)atoi(env_pad) : 2048u);
     const unsigned gp = a.coop_grid ? std::min(gc, a.coop_grid) : gc;
     if (wide) hipLaunchKernelGGL(k_find_c2w, dim3(gp), dim3(128), dyn, st, b);
     else hipLaunchKernelGGL(k_find_c2, dim3(gp), dim3(128), dyn, st, b);

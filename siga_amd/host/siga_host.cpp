@@ -1006,7 +1006,6 @@ static void write_edge(std::string& o, const sigax_edge& e, const ReadStore& rea
   o += " 0\n";
 }
 
-static bool set_read_info(const FMIndex* fmi, const DNASeqList& reads, std::string* error);
 
 struct PhaseTimer {  // SIGA_TIMING=1: phase times on stderr
   bool on;
@@ -1338,36 +1337,19 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
   return true;
 }
 
-// ReadInfo table for the edge converter: lengths + rank of each name under std::string operator<
-static bool set_read_info(const FMIndex* fmi, const DNASeqList& reads, std::string* error) {
-  const size_t n = reads.size();
-  std::vector<uint32_t> lengths(n), ranks(n), order(n);
-  for (size_t i = 0; i < n; ++i) lengths[i] = (uint32_t)reads[i].seq.size();
-  std::iota(order.begin(), order.end(), 0u);
-  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return reads[a].name < reads[b].name; });
-  uint32_t rk = 0;
-  for (size_t k = 0; k < n; ++k) {
-    if (k > 0 && reads[order[k]].name != reads[order[k - 1]].name) ++rk;
-    ranks[order[k]] = rk;
-  }
-  if (n > 0 && sigax_index_set_reads(fmi->handle(), lengths.data(), ranks.data(), n) != SIGAX_OK) {
-    *error = std::string("failed to load suffix array index: ") + sigax_last_error();
-    return false;
-  }
-  return true;
-}
-
 bool OverlapBuilder::rmdup(const std::string& input, const std::string& output, const std::string& duplicates, size_t threads,
                            size_t* processed) const {
-  (void)threads;
   (void)processed;
   _error.clear();
   if (!_fmi || !_fmi->handle()) {
     _error = "FMIndex not loaded";
     return false;
   }
-  DNASeqList reads;
-  if (!ReadDNASequences(input, reads)) {
+  // the chunk-parallel loader of build() (the reference reads record by record: src/overlap_builder.cpp:511-530); reads stay
+  // packed, a piece of them goes to the device at a time
+  const unsigned nt = (unsigned)std::max<size_t>(threads, 1);
+  ReadStore reads;
+  if (!LoadReads(input, &reads, nt)) {
     _error = "Failed to create DNASeqReader " + input;
     return false;
   }
@@ -1376,20 +1358,24 @@ bool OverlapBuilder::rmdup(const std::string& input, const std::string& output, 
     _error = "Failed to create FASTA " + output;
     return false;
   }
-  if (!set_read_info(_fmi, reads, &_error)) return false;
-  const size_t n = reads.size(), per = 262144;
-  std::string seqs, text;
+  const size_t n = reads.size();
+  {
+    std::vector<uint32_t> lengths, ranks;
+    name_ranks(reads, nt, &lengths, &ranks);
+    if (n > 0 && sigax_index_set_reads(_fmi->handle(), lengths.data(), ranks.data(), n) != SIGAX_OK) {
+      _error = std::string("failed to load suffix array index: ") + sigax_last_error();
+      return false;
+    }
+  }
+  const size_t per = 1u << 20;
+  std::string text;
   std::vector<uint64_t> offs;
   for (size_t base = 0; base < n; base += per) {
-    size_t cnt = std::min(per, n - base);
-    seqs.clear();
-    offs.assign(1, 0);
-    for (size_t i = 0; i < cnt; ++i) {
-      seqs += reads[base + i].seq;
-      offs.push_back(seqs.size());
-    }
+    const size_t cnt = std::min(per, n - base);
+    offs.resize(cnt + 1);
+    for (size_t i = 0; i <= cnt; ++i) offs[i] = reads.offs[base + i] - reads.offs[base];
     sigax_result res;
-    if (sigax_overlap_batch(_fmi->handle(), seqs.data(), offs.data(), (uint32_t)cnt, (uint32_t)base, 0,
+    if (sigax_overlap_batch(_fmi->handle(), reads.seqs.data() + reads.offs[base], offs.data(), (uint32_t)cnt, (uint32_t)base, 0,
                             SIGAX_DUPLICATE | SIGAX_EDGES, &res) != SIGAX_OK) {
       _error = std::string("rmdup failed: ") + sigax_last_error();
       return false;
@@ -1399,24 +1385,24 @@ bool OverlapBuilder::rmdup(const std::string& input, const std::string& output, 
     std::vector<uint8_t> hasEdge(cnt, 0);
     for (uint64_t e = 0; e < res.n_edges; ++e) hasEdge[res.edges[e].query - base] = 1;
     for (size_t i = 0; i < cnt; ++i) {
-      const DNASeq& rd = reads[base + i];
+      const std::string_view name = reads.name(base + i), seq = reads.seq(base + i);
       uint64_t numCopies = 0;
       for (uint64_t k = res.block_offs[i]; k < res.block_offs[i + 1]; ++k)
         numCopies += res.blocks[k].capped0_hi - res.blocks[k].capped0_lo + 1;
       bool contained = res.substring[i] != 0 || hasEdge[i] != 0;
       text.clear();
       text += '>';
-      text += rd.name;
+      text.append(name.data(), name.size());
       if (contained) {
         text += ",seqrank=";
-        text += std::to_string(base + i);
+        append_u64(text, base + i);
       }
       text += ' ';
-      text += rd.name;
+      text.append(name.data(), name.size());
       text += " NumDuplicates=";
-      text += std::to_string(numCopies);
+      append_u64(text, numCopies);
       text += '\n';
-      text += rd.seq;
+      text.append(seq.data(), seq.size());
       text += '\n';
       (contained ? dups : fasta).write(text);
     }
