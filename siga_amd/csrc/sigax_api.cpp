@@ -105,6 +105,7 @@ struct sigax_index {
   u32 max_read_len;  // longest read of sigax_index_set_reads (0: not told yet), an upper bound of the longest stretch
   void* d_super[2];
   void* d_start[2];  // start tables of the block finder (fm_layout.h) or NULL
+  uint32_t ptab_k;
   void* d_ptab;      // intervals of all 12-mers of the forward index: `siga correct`'s k-mer lookups start there (built by the
   bool ptab_tried;   // first correction call; SIGAX_KMER_PREFIX=0: never)
   uint32_t* d_sai[2];
@@ -902,14 +903,18 @@ static void ensure_prefix_table(sigax_index* ix) {
   std::lock_guard<std::mutex> lock(*ix->enqueue_mu);
   if (ix->ptab_tried) return;
   ix->ptab_tried = true;
+  // 0 = none, 8 .. 14 = that many symbols.  Default 13 (537 MB): measured at BASELINE configs[3], k = 31, 28.1 / 31.3 / 29.5 M
+  // reads/s with 12 / 13 / 14 symbols (21.1 M without) -- the 2 GB table of all 14-mers no longer sits in the caches
   const char* env = getenv("SIGAX_KMER_PREFIX");
-  if (env && env[0] == '0') return;
+  uint32_t pk = env ? (uint32_t)atoi(env) : 13u;
+  if (pk == 0) return;
+  pk = std::min(std::max(pk, 8u), 14u);
   void* tab = nullptr;
-  if (hipMalloc(&tab, prefix_table_bytes(ix->wide)) != hipSuccess) {
+  if (hipMalloc(&tab, prefix_table_bytes(ix->wide, pk)) != hipSuccess) {
     (void)hipGetLastError();
     return;
   }
-  launch_prefix_build(ix->st[0], ix->wide, tab, nullptr);
+  launch_prefix_build(ix->st[0], ix->wide, tab, pk, nullptr);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
@@ -918,7 +923,8 @@ static void ensure_prefix_table(sigax_index* ix) {
     return;
   }
   ix->d_ptab = tab;
-  ix->device_bytes += prefix_table_bytes(ix->wide);
+  ix->ptab_k = pk;
+  ix->device_bytes += prefix_table_bytes(ix->wide, pk);
 }
 
 static CorrectArgs correct_args(sigax_index* ix, const unsigned char* d_seqs, const unsigned char* d_quals, const u64* d_offs, u64 n_reads,
@@ -941,6 +947,7 @@ static CorrectArgs correct_args(sigax_index* ix, const unsigned char* d_seqs, co
   ca.dstat = d_stat;
   ensure_prefix_table(ix);
   ca.ptab = ix->d_ptab;
+  ca.pk = ix->ptab_k;
   return ca;
 }
 
@@ -1054,7 +1061,7 @@ struct sigax_batch {
   uint32_t read_base, minov, flags;
   bool ran;
   // arenas
-  DevBuf arena, chain_cnt, pool, wpool, work, work64, work64b, work64c, perm, ord_keys, ord_tmp, occ_side, slow_flag, offs2, item_base, fin, fin_cnt, substring, block_offs, outb, edge_cnt,
+  DevBuf arena, chain_cnt, pool, wpool, work, work64, work64b, work64c, work64d, perm, ord_keys, ord_tmp, occ_side, slow_flag, offs2, item_base, fin, fin_cnt, substring, block_offs, outb, edge_cnt,
       edge_offs, edges, partial, dstat;
   uint32_t cap;
   uint32_t cap_floor;  // records the longest chain of this batch's last (overflowed) run needed
@@ -1069,7 +1076,7 @@ struct sigax_batch {
   bool perm_valid;    // `perm_cur` (one half of `perm`) holds the locality order of the reads now set, for perm_nsub sub-batches
   const uint32_t* perm_cur;
   unsigned perm_nsub;
-  u64 qhint[3];       // items per sub-batch in the three filter/extract queues in the previous run (~0: none yet)
+  u64 qhint[4];       // items per sub-batch in the four filter/extract queues in the previous run (~0: none yet)
   bool qhint_lean_off;  // ... measured with lean_off in this state
   bool lean_off;      // see sigax_batch_finish
   unsigned lean_off_runs;
@@ -1084,7 +1091,7 @@ struct sigax_batch {
 extern "C" void sigax_batch_destroy(sigax_batch* b) {
   if (!b) return;
   hipSetDevice(b->ix->device);
-  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->work64c, &b->perm, &b->ord_keys, &b->ord_tmp, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin,
+  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->work64c, &b->work64d, &b->perm, &b->ord_keys, &b->ord_tmp, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin,
                    &b->fin_cnt, &b->substring, &b->block_offs, &b->outb, &b->edge_cnt, &b->edge_offs, &b->edges,
                    &b->partial, &b->dstat};
   for (DevBuf* d : all)
@@ -1129,7 +1136,7 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
   b->nsub = 1;
   b->lean_off = false;
   b->lean_off_runs = 0;
-  b->qhint[0] = b->qhint[1] = b->qhint[2] = ~0ull;
+  b->qhint[0] = b->qhint[1] = b->qhint[2] = b->qhint[3] = ~0ull;
   b->qhint_lean_off = false;
   b->perm_valid = false;
   b->perm_cur = nullptr;
@@ -1230,6 +1237,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   if ((rc = ensure(&b->work64, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->work64b, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->work64c, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
+  if ((rc = ensure(&b->work64d, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
   // general filter/extract kernel (reads the fast kernel queued): persistent lanes with a private pool each
   unsigned want_grid = (unsigned)std::min<u64>(128, ((u64)n + 255) / 256);
   if (want_grid == 0) want_grid = 1;
@@ -1408,6 +1416,8 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     xa.w64b_counter = dstat + DS_W64B_BASE + i;
     xa.work64c = (uint32_t*)b->work64c.p + 2 * (size_t)rb;
     xa.w64c_counter = dstat + DS_W64C_BASE + i;
+    xa.work64d = (uint32_t*)b->work64d.p + 2 * (size_t)rb;
+    xa.w64d_counter = dstat + DS_W64D_BASE + i;
     xa.q_in = nullptr;
     xa.q_in_n = nullptr;
     xa.q_out = nullptr;
@@ -1587,8 +1597,8 @@ extern "C" int sigax_batch_finish(sigax_batch* b, void* stream, sigax_stats* sta
       // at 8 % handed on, 12 % ahead at 23 %, tools/ab_skip_strict.sh), then tries the strict one again.
       u64 q64 = 0;
       for (int i = 0; i < SIGAX_MAX_SUB; ++i) q64 += ds[DS_W64_BASE + i];
-      for (int k = 0; k < 3; ++k) {
-        const int base = k == 0 ? DS_W64_BASE : k == 1 ? DS_W64B_BASE : DS_W64C_BASE;
+      for (int k = 0; k < 4; ++k) {
+        const int base = k == 0 ? DS_W64_BASE : k == 1 ? DS_W64B_BASE : k == 2 ? DS_W64C_BASE : DS_W64D_BASE;
         u64 m = 0;
         for (int i = 0; i < SIGAX_MAX_SUB; ++i) m = std::max<u64>(m, ds[base + i]);
         b->qhint[k] = m;
@@ -1757,7 +1767,7 @@ extern "C" int sigax_batch_run_info(sigax_batch* b, sigax_run_info* out) {
   out->row_syms = f.sa ? (f.sa_bits - f.ld_bits - f.t_bits) / 2u : 0u;
   out->row_text = f.text ? 1u : 0u;
   out->arena_bytes = b->arena.bytes;
-  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->work64c, &b->perm,
+  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->work64c, &b->work64d, &b->perm,
                    &b->ord_keys, &b->ord_tmp, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin, &b->fin_cnt, &b->substring, &b->block_offs,
                    &b->outb, &b->edge_cnt, &b->edge_offs, &b->edges, &b->partial, &b->dstat};
   for (DevBuf* d : all) out->workspace_bytes += d->bytes;

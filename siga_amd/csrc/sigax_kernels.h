@@ -31,7 +31,8 @@ enum {
   DS_PROF_BASE = 32,               // 32 diagnostic counters (builds with -DSIGAX_FX_PROFILE only)
   DS_W64B_BASE = 64,               // [DS_W64B_BASE + i], [DS_W64C_BASE + i]: items in the second and third queue between
   DS_W64C_BASE = 72,               // sub-batch i's filter/extract launches
-  DS_COUNT = 80
+  DS_W64D_BASE = 80,               // ... in the fourth (what the 16-lane launch hands to the 32-lane one)
+  DS_COUNT = 88
 };
 #define SIGAX_MAX_SUB 8
 
@@ -82,6 +83,8 @@ struct FxArgs {
   unsigned long long* w64b_counter;
   uint32_t* work64c;
   unsigned long long* w64c_counter;
+  uint32_t* work64d;
+  unsigned long long* w64d_counter;
   // set per launch by launch_filter_extract_fast: input queue (NULL: the sub-batch's read range) and output queue (NULL:
   // the last launch, which queues reads for the general kernel)
   const uint32_t* q_in;
@@ -149,12 +152,13 @@ struct CorrectArgs {
   unsigned char* out;    // corrected sequences, same layout as seqs
   unsigned char* valid;  // CorrectResult::validQC; 2 = read longer than the kernel supports
   unsigned long long* dstat;  // [0] reads too long, [1] rank-table sectors asked for, [2] k-mer lookups (4 x u64)
-  const void* ptab;           // intervals of all 12-mers (launch_prefix_build), or NULL
+  const void* ptab;           // intervals of all pk-mers (launch_prefix_build), or NULL
+  uint32_t pk;
 };
 void launch_correct(const CorrectArgs& a, bool wide, hipStream_t st);
-// table of the intervals of all 12-mers on strand s: prefix_table_bytes(wide) bytes
-unsigned long long prefix_table_bytes(bool wide);
-void launch_prefix_build(const FmStrand& s, bool wide, void* tab, hipStream_t st);
+// table of the intervals of all pk-mers on strand s: prefix_table_bytes(wide, pk) bytes
+unsigned long long prefix_table_bytes(bool wide, uint32_t pk);
+void launch_prefix_build(const FmStrand& s, bool wide, void* tab, uint32_t pk, hipStream_t st);
 
 void launch_occ_batch(const FmStrand& s, bool wide, const unsigned long long* pos, unsigned long long n,
                       unsigned long long* out, hipStream_t st);
@@ -169,7 +173,7 @@ unsigned long long start_table_bytes(bool wide);
 void launch_start_build(const FmStrand& prim, const FmStrand& other, bool wide, void* tab, hipStream_t st);
 unsigned long long find_stage_capacity();  // bytes of reads a finder workgroup can stage in LDS
 void launch_filter_extract(const FxArgs& a, bool wide, unsigned grid, hipStream_t st);
-// qhint: items the three queues held last time (per sub-batch; ~0 = unknown), or NULL
+// qhint: items the four queues held last time (per sub-batch; ~0 = unknown), or NULL
 void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid32, unsigned grid64, const unsigned long long* qhint, hipStream_t st);
 unsigned long long fast_pool_entries_per_wave();
 void launch_scan(const uint32_t* cnt, unsigned long long n, unsigned long long* partial, unsigned long long* offs,

@@ -1904,7 +1904,9 @@ struct GFx {
   BigSh<WIDE>* big;  // 64-lane launch only: scratch for items of more than 64 blocks
   const Find2TablesT<WIDE>* t2;  // constants of the two-step table, or NULL when the index has none
   u32 lane;    // lane in the wave
-  u32 gb;      // first lane of this lane's group (0, or 32 for the second group when W == 32)
+  u32 gb;      // first lane of this lane's group (0; 0 or 32 when W == 32; 0, 16, 32 or 48 when W == 16)
+  static constexpr u32 kOutCap = FX_OUTCAP * (u32)W / 64u;            // a group's share of the wave's output slots
+  static constexpr u32 kNSlot = (u32)W < FX_NSLOT ? (u32)W : FX_NSLOT;  // group slots: the table lives in the group's lanes
   u32 gl;      // lane inside the group
   u64 glt;     // group lanes below this one, as a mask over group lanes
   const Cand<WIDE>* slots;
@@ -1915,14 +1917,14 @@ struct GFx {
 
   __device__ GFx(const FxArgs& a, const FmTables& t, SideSh<WIDE>& s, Ent* wp, const Find2TablesT<WIDE>* tt)
       : A(a), tb(t), sh(s), F(fm_ref(a.fwd, 0)), R(fm_ref(a.rev, 1)), wpool(wp), big(nullptr), t2(tt), lane(threadIdx.x & 63u),
-        gb(W == 64 ? 0u : (threadIdx.x & 32u)), gl(W == 64 ? (threadIdx.x & 63u) : (threadIdx.x & 31u)),
-        glt((1ull << (W == 64 ? (threadIdx.x & 63u) : (threadIdx.x & 31u))) - 1ull), slots(nullptr), nout(0), nocc(0),
+        gb(threadIdx.x & (63u & ~(u32)(W - 1))), gl(threadIdx.x & (u32)(W - 1)),
+        glt((1ull << (threadIdx.x & (u32)(W - 1))) - 1ull), slots(nullptr), nout(0), nocc(0),
         xerror(false), fin_cur(0), fin_end(0), nslot(1), ni(0), gAlive(0), gD(0), gI(0) {}
 
-  // ---- lane-group primitives: a group is the whole wave (W == 64) or one half of it (W == 32) ----
+  // ---- lane-group primitives: a group is the whole wave (W == 64), a half (W == 32) or a quarter of it (W == 16) ----
   __device__ u64 gballot(bool p) const {
     u64 b = __ballot(p);
-    return W == 64 ? b : (gb ? (b >> 32) : (b & 0xFFFFFFFFull));
+    return W == 64 ? b : ((b >> gb) & ((1ull << (W & 63)) - 1ull));
   }
   __device__ u32 gshfl(u32 v, u32 idx) const { return (u32)__shfl((int)v, (int)(gb + idx), 64); }
   __device__ u64 gshfl(u64 v, u32 idx) const {
@@ -2016,7 +2018,7 @@ struct GFx {
   // single-symbol one with ITS symbol -- `v` = C[c] + Occ(c, row), computed by the caller from the line it already holds.
   // Groups go to the incomings in rank order A, C, G, T (:781-787).  Not for '$' below the top level (the caller checks).
   __device__ int branch_inreg(E& e, u64 alive, bool mine, u32 cq, P v) {
-    const u32 NSLOT = W == 64 ? FX_NSLOT : 32 < FX_NSLOT ? 32 : FX_NSLOT;
+    const u32 NSLOT = kNSlot;
     const u64 m1 = gballot(mine && cq == 1u), m2 = gballot(mine && cq == 2u), m3 = gballot(mine && cq == 3u), m4 = gballot(mine && cq == 4u);
     const u32 nb = (m1 != 0) + (m2 != 0) + (m3 != 0) + (m4 != 0);
     if (nslot + nb > NSLOT || ni + nb > NSLOT) return RD_BAIL;
@@ -2044,8 +2046,8 @@ struct GFx {
   // RD_UPDATED: the blocks were right-extended in place, *newAlive = those still valid.  RD_ENDED / RD_BRANCHED: the
   // group is finished (top-level blocks emitted, or copies pushed to the incomings).
   __device__ int round(E& e, u64 alive, u64* newAlive) {
-    const u32 OUTCAP = W == 64 ? FX_OUTCAP : FX_OUTCAP / 2;
-    const u32 NSLOT = W == 64 ? FX_NSLOT : 32 < FX_NSLOT ? 32 : FX_NSLOT;
+    const u32 OUTCAP = kOutCap;
+    const u32 NSLOT = kNSlot;
     const bool mine = (alive >> gl) & 1ull;
     const u32 first = ffs0(alive);
     const u32 topLen = gshfl(e.len, first);
@@ -2132,7 +2134,7 @@ struct GFx {
   // range size, i.e. capped[0] does not move and capped[1] = C[b] + Occ(b, lower - 1) keeps its size: one symbol's rank
   // at one position.  Anything else (range across granules, a branch, '$' as the single symbol) goes to round().
   __device__ int round_fast(E& e, u64 alive, u64* newAlive, bool allow2) {
-    const u32 OUTCAP = W == 64 ? FX_OUTCAP : FX_OUTCAP / 2;
+    const u32 OUTCAP = kOutCap;
     const bool mine = (alive >> gl) & 1ull;
     const FmRef ix = ext_index(e.src);
     const u64 p0 = (u64)e.c1lo, p1 = (u64)e.c1hi + 1ull;  // [p0, p1) in the extension index
@@ -2433,8 +2435,8 @@ struct GFx {
   // next one on its path, the update is a step along it (nothing to compute: capped[0] keeps still, capped[1] is only
   // needed at the end, where it is the row-end table's Occ('$')).  Same cases and return codes as round_fast().
   __device__ int round_text(E& e, u64 alive, u64* newAlive) {
-    const u32 OUTCAP = W == 64 ? FX_OUTCAP : FX_OUTCAP / 2;
-    const u32 NSLOT = W == 64 ? FX_NSLOT : 32 < FX_NSLOT ? 32 : FX_NSLOT;
+    const u32 OUTCAP = kOutCap;
+    const u32 NSLOT = kNSlot;
     const bool mine = (alive >> gl) & 1ull;
     const u32 first = ffs0(alive);
     FXP(0);
@@ -2511,7 +2513,7 @@ struct GFx {
   // the item has to be redone by a wider kernel.
   __device__ bool extract(E e, u32 n) {
     if (n == 0) return true;
-    const u32 NSLOT = W == 64 ? FX_NSLOT : 32 < FX_NSLOT ? 32 : FX_NSLOT;
+    const u32 NSLOT = kNSlot;
     nslot = 1;
     ni = 0;
     gAlive = 0;
@@ -2591,7 +2593,7 @@ struct GFx {
           const u32 t = gshfl((u32)e.c1hi, owner);
           if (t == 0 || alone) {
             nocc += 2u * (t + 1u);
-            if (nout + 1 > (W == 64 ? FX_OUTCAP : FX_OUTCAP / 2)) return false;
+            if (nout + 1 > kOutCap) return false;
             if (gl == owner) {
               E br = e;
               br.c0hi = br.c0lo;  // updateR('$') of a single row: one '$' row, capped[0] stays
@@ -2637,7 +2639,7 @@ struct GFx {
 
   // one (read, side) item on this lane group; returns false when it must be redone by a wider kernel
   __device__ bool body(u32 r, u32 sd) {
-    const u32 OUTCAP = W == 64 ? FX_OUTCAP : FX_OUTCAP / 2;
+    const u32 OUTCAP = kOutCap;
     nout = 0;
     nocc = 0;
     xerror = false;
@@ -2949,17 +2951,22 @@ struct GFx {
     if (has) done = body(r, sd);
     wave_lds_sync();
     const u32 mine_n = (has && done) ? nout : 0u;
-    const u32 n0 = __builtin_amdgcn_readlane(mine_n, 0);
-    const u32 n1 = W == 64 ? 0u : __builtin_amdgcn_readlane(mine_n, 32);
-    if (n0 + n1 == 0) return done;
-    if (fin_cur + n0 + n1 > fin_end) {
+    u32 tot = 0, before = 0;  // blocks of all the wave's groups; of the groups below this lane's
+#pragma unroll
+    for (u32 g = 0; g < 64u; g += (u32)W) {
+      const u32 ng = __shfl((int)mine_n, (int)g, 64);
+      before += g < gb ? ng : 0u;
+      tot += ng;
+    }
+    if (tot == 0) return done;
+    if (fin_cur + tot > fin_end) {
       u64 b0 = 0;
       if (lane == 0) b0 = atomicAdd(&A.dstat[DS_FIN_TOP], (u64)FX_FIN_CHUNK);
       fin_cur = readlane64(b0, 0);
       fin_end = fin_cur + FX_FIN_CHUNK;
     }
-    const u64 base = fin_cur + (gb ? n0 : 0u);
-    fin_cur += n0 + n1;
+    const u64 base = fin_cur + before;
+    fin_cur += tot;
     if (has && done) {
       if (gl == 0) A.item_base[2ull * r + sd] = base;
       if (gl < nout && base + gl < A.fin_cap) {
@@ -3048,7 +3055,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? (LEA
   // Items come from this sub-batch's read range (the first launch) or from the queue the launch before filled; what a
   // launch cannot finish goes to a later one's queue -- items with more blocks than the group has lanes to q_wide, the
   // rest to q_out -- and from the last launch to the general kernel (by read).  Queue entries are collected per wave in
-  // LDS and appended 30 or more at a time: one atomic on the queue's counter per item serialises at ~6 ns each.
+  // LDS and appended 28 or more at a time: one atomic on the queue's counter per item serialises at ~6 ns each.
   // The strict lean launch is always the first one (range input) and appends with one atomic per item: its register
   // budget is what the error-free step time hangs on (89 VGPRs; 99 and scratch with the batching below: 9 % on the step),
   // and its atomics hide behind its other work.
@@ -3074,7 +3081,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? (LEA
   } else {
     const u32* qin = A.q_in;
     const u64 nitems = qin ? *A.q_in_n : 2ull * A.read_end - first;
-    const u64 per = W == 32 ? 2u : 1u;
+    const u64 per = 64u / (u32)W;  // items per wave
     __shared__ u32 qbuf[4][2][32];  // items a wave hands on, waiting to be appended to the later launches' queues
     u32 qn[2] = {0, 0};
     auto flush = [&](int which) {
@@ -3093,10 +3100,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? (LEA
       if (p) qbuf[wid][which][qn[which] + (u32)__popcll(m & ((1ull << lane) - 1ull))] = it;
       wave_lds_sync();
       qn[which] += (u32)__popcll(m);
-      if (qn[which] >= 30u) flush(which);
+      if (qn[which] >= 28u) flush(which);  // up to four more (16-lane groups) must still fit the 32 entries
     };
     for (u64 i0 = wave * per; i0 < nitems; i0 += nwaves * per) {
-      const u64 idx = i0 + (W == 32 ? (lane >> 5) : 0u);
+      const u64 idx = i0 + lane / (u32)W;
       const bool has = idx < nitems;
       const u64 item = !has ? 0ull : (qin ? (u64)qin[idx] : first + idx);
       const bool done = fx.run(has, (u32)(item >> 1), (u32)(item & 1));
@@ -3156,20 +3163,19 @@ struct CorrectSh {
 // pair containing a non-ACGT base, and the last step of an odd count, take the one-step form.  An interval that the first
 // step of a pair would have emptied comes out empty after the pair (R2 over no rows), so the reference's early exit
 // (fmindex.h:67-86) and this give the same count: 0.
-// Prefix table of the k-mer lookups (CorrectArgs::ptab): entry [code] = (lower, size) of the interval of the 12-mer whose
-// symbols, first one in the highest two bits, are `code` -- what Interval::get holds after its first twelve symbols
-// (the LAST twelve of the k-mer: the search runs backwards).  A lookup whose last twelve bases are all ACGT starts there:
-// one gather from a 134 MB table instead of eleven dependent rank steps (5.5 two-step lines).
-#define SIGAX_PREFIX_K 12
+// Prefix table of the k-mer lookups (CorrectArgs::ptab, pk = 13 by default): entry [code] = (lower, size) of the interval of
+// the pk-mer whose symbols, first one in the highest two bits, are `code` -- what Interval::get holds after its first pk
+// symbols (the LAST pk of the k-mer: the search runs backwards).  A lookup whose last pk bases are all ACGT starts there:
+// at pk = 12 one gather from a 134 MB table instead of eleven dependent rank steps (5.5 two-step lines).
 template <bool WIDE>
-__global__ __launch_bounds__(256) void k_prefix_build(FmStrand s, void* tab) {
+__global__ __launch_bounds__(256) void k_prefix_build(FmStrand s, void* tab, u32 pk) {
   typedef typename PosOf<WIDE>::type P;
   const u32 code = blockIdx.x * 256 + threadIdx.x;
-  if (code >= (1u << (2 * SIGAX_PREFIX_K))) return;
+  if (code >= (1u << (2 * pk))) return;
   const FmRef f = fm_ref(s, 0);
   u32 r = 1u + (code & 3u);  // the last symbol first (src/fmindex.h:67-79)
   P lo = (P)s.C[r], hi = lo + (P)s.total[r] - 1;
-  for (int i = 1; i < SIGAX_PREFIX_K && hi != (P)~(P)0 && hi >= lo; ++i) {
+  for (u32 i = 1; i < pk && hi != (P)~(P)0 && hi >= lo; ++i) {
     r = 1u + ((code >> (2 * i)) & 3u);
     P l[5], u[5];
     fm_rank5p<WIDE>(f, lo, l);
@@ -3185,18 +3191,17 @@ __global__ __launch_bounds__(256) void k_prefix_build(FmStrand s, void* tab) {
 
 template <bool WIDE>
 __device__ __forceinline__ u32 kmer_occ(const FmRef& f, const FmTables& tb, const Find2TablesT<WIDE>* t2, const uint32_t* gran2,
-                                        const u64* super2, const void* ptab, const unsigned char* seq, u32 s, u32 k, u32 ovpos, u32 ovrank,
-                                        u32& nsec) {
+                                        const u64* super2, const void* ptab, u32 pk, const unsigned char* seq, u32 s, u32 k, u32 ovpos,
+                                        u32 ovrank, u32& nsec) {
   typedef typename PosOf<WIDE>::type P;
   u32 j = k;
   P lo, hi;
   bool started = false;
-  if (ptab != nullptr && k >= (u32)SIGAX_PREFIX_K) {
+  if (ptab != nullptr && k >= pk) {
     u32 code = 0;
     bool acgt = true;
-#pragma unroll
-    for (u32 i = 0; i < (u32)SIGAX_PREFIX_K; ++i) {
-      const u32 p = s + k - (u32)SIGAX_PREFIX_K + i;
+    for (u32 i = 0; i < pk; ++i) {
+      const u32 p = s + k - pk + i;
       const u32 r = p == ovpos ? ovrank : base_rank(seq[p]);
       acgt = acgt && r != 0u;
       code = (code << 2) | ((r - 1u) & 3u);
@@ -3215,7 +3220,7 @@ __device__ __forceinline__ u32 kmer_occ(const FmRef& f, const FmTables& tb, cons
       nsec += 1u;
       if (cnt == 0) return 0u;  // the reference stops updating an empty interval and reports no occurrence
       hi = lo + (P)cnt - 1;
-      j = k - (u32)SIGAX_PREFIX_K;
+      j = k - pk;
       started = true;
     }
   }
@@ -3319,7 +3324,7 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs A) {
           bool good = false;
           if (s < nw) {
             if (sh.redo[s]) {
-              sh.cnt[s] = kmer_occ<WIDE>(F, tb, t2, A.fwd.gran2, A.fwd.super2, A.ptab, sh.seq, s, k, 0xFFFFFFFFu, 0u, nsec);
+              sh.cnt[s] = kmer_occ<WIDE>(F, tb, t2, A.fwd.gran2, A.fwd.super2, A.ptab, A.pk, sh.seq, s, k, 0xFFFFFFFFu, 0u, nsec);
               ++nlook;
               sh.redo[s] = 0;
             }
@@ -3371,7 +3376,7 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs A) {
                 const u32 kidx = side ? (pos < n - k ? pos : n - k) : (pos + 1 >= k ? pos + 1 - k : 0u);
                 const u32 thr = sh.score[pos] >= A.cutoff ? A.high : A.low;
                 const u32 minCount = A.offset > thr ? A.offset : thr;  // max(countVector[..] (always 0) + offset, threshold)
-                cand = kmer_occ<WIDE>(F, tb, t2, A.fwd.gran2, A.fwd.super2, A.ptab, sh.seq, kidx, k, pos, brank, nsec) >= minCount;
+                cand = kmer_occ<WIDE>(F, tb, t2, A.fwd.gran2, A.fwd.super2, A.ptab, A.pk, sh.seq, kidx, k, pos, brank, nsec) >= minCount;
                 ++nlook;
               }
             }
@@ -3580,11 +3585,11 @@ void launch_kmer_count(const FmStrand& s, bool wide, const unsigned char* kmers,
   else hipLaunchKernelGGL(k_kmer_count<false>, dim3(nblk(n, 256)), dim3(256), 0, st, s, kmers, k, n, out);
 }
 
-unsigned long long prefix_table_bytes(bool wide) { return (1ull << (2 * SIGAX_PREFIX_K)) * (wide ? 16u : 8u); }
-void launch_prefix_build(const FmStrand& s, bool wide, void* tab, hipStream_t st) {
-  const unsigned g = (1u << (2 * SIGAX_PREFIX_K)) / 256u;
-  if (wide) hipLaunchKernelGGL(k_prefix_build<true>, dim3(g), dim3(256), 0, st, s, tab);
-  else hipLaunchKernelGGL(k_prefix_build<false>, dim3(g), dim3(256), 0, st, s, tab);
+unsigned long long prefix_table_bytes(bool wide, u32 pk) { return (1ull << (2 * pk)) * (wide ? 16u : 8u); }
+void launch_prefix_build(const FmStrand& s, bool wide, void* tab, u32 pk, hipStream_t st) {
+  const unsigned g = (1u << (2 * pk)) / 256u;
+  if (wide) hipLaunchKernelGGL(k_prefix_build<true>, dim3(g), dim3(256), 0, st, s, tab, pk);
+  else hipLaunchKernelGGL(k_prefix_build<false>, dim3(g), dim3(256), 0, st, s, tab, pk);
 }
 
 unsigned long long start_table_bytes(bool wide) { return (1ull << (2 * SIGAX_START_K)) * (wide ? 32u : 16u); }
@@ -3658,16 +3663,16 @@ static void launch_fx_stages(const FxArgs& a, unsigned grid32, unsigned grid64, 
   //   -> branching lean 32 lanes -> branching lean 64 lanes (items of 33..64 blocks) -> full 64 lanes (everything else the
   //   lane-group form can do, items of up to 256 blocks) -> general kernel (launched by the caller).
   // Exhaustive mode: full 32 lanes -> full 64 lanes.
-  u32* q[3] = {a.work64, a.work64b, a.work64c};
-  u64* qn[3] = {a.w64_counter, a.w64b_counter, a.w64c_counter};
+  u32* q[4] = {a.work64, a.work64b, a.work64c, a.work64d};
+  u64* qn[4] = {a.w64_counter, a.w64b_counter, a.w64c_counter, a.w64d_counter};
   // stage(kernel, grid, in, out, wide): queue indices, -1 = the read range as input / the general kernel as output /
   // no separate queue for items wider than the lane group
-  auto stage = [&](auto kernel, unsigned grid, int in, int out, int widei) {
+  auto stage = [&](auto kernel, unsigned grid, int in, int out, int widei, unsigned items_per_wg = 0) {
     FxArgs x = a;
     if (in >= 0 && qhint && qhint[in] != ~0ull) {
       // a queue that held few items in this batch object's previous run gets a small grid (any grid is correct: the
       // waves loop over the queue; an empty 768-workgroup launch costs ~25 us beside the finder)
-      const u64 per_wg = grid == grid32 ? 8 : 4;
+      const u64 per_wg = items_per_wg ? items_per_wg : grid == grid32 ? 8 : 4;
       const u64 want = (qhint[in] + qhint[in] / 2 + per_wg - 1) / per_wg + 4;
       if (want < grid) grid = (unsigned)want;
     }
@@ -3690,11 +3695,24 @@ static void launch_fx_stages(const FxArgs& a, unsigned grid32, unsigned grid64, 
     stage(k_filter_extract_fast<WIDE, 64, 0>, grid64, 2, -1, -1);
     return;
   }
-  // queue 0: items for the branching 32-lane launch; queue 1: for the branching 64-lane launch; queue 2: for the full one
+  // queue 0: items the strict launch handed on; queue 1: for the branching 64-lane launch; queue 2: for the full one;
+  // queue 3 (text launches): what the 16-lane launch leaves to the branching 32-lane one
   static const bool no_text = getenv("SIGAX_FX_NO_TEXT") != nullptr;  // A/B aid
+  static const bool use_16 = getenv("SIGAX_FX_16") != nullptr;  // see below
   if (a.fwd.text && a.rev.text && a.fwd.sa && a.rev.sa && !no_text) {
     if (!a.no_lean) { route(); stage(k_filter_extract_fast<WIDE, 32, 5>, grid32, -1, 0, -1); }
-    stage(k_filter_extract_fast<WIDE, 32, 6>, grid32, a.no_lean ? -1 : 0, 1, -1);
+    // SIGAX_FX_16=1: branching items of at most 16 blocks -- what reads with substitutions mostly make: errors cost them
+    // overlaps -- four to a wave in a launch of their own; wider ones, and whatever outgrows a quarter wave's slots, go on
+    // to the 32-lane launch.  Built on the round-2 expectation that twice the items in flight would halve the time of reads
+    // with errors; measured, it is +7 % at 1 % substitutions (31.6 -> 33.7 M reads/s) and -5 % at 0.3 % (60.4 -> 57.6): four
+    // items that branch differently share a wave's instruction stream, and the branching rounds are bound by instruction
+    // issue, not by latency.  Off by default.
+    if (use_16) {
+      stage(k_filter_extract_fast<WIDE, 16, 6>, grid32, a.no_lean ? -1 : 0, 3, 3, 16);
+      stage(k_filter_extract_fast<WIDE, 32, 6>, grid32, 3, 1, -1);
+    } else {
+      stage(k_filter_extract_fast<WIDE, 32, 6>, grid32, a.no_lean ? -1 : 0, 1, -1);
+    }
     stage(k_filter_extract_fast<WIDE, 64, 6>, grid64, 1, 2, -1);
   } else if (have2) {
     if (!a.no_lean) { route(); stage(k_filter_extract_fast<WIDE, 32, 1>, grid32, -1, 0, -1); }

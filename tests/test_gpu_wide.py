@@ -86,6 +86,14 @@ def test_finder_start_table_bit_exact():
     _run_parity({"SIGAX_FIND_START": "1", "SIGAX_FIND_COOP": "1", "SIGAX_FORCE_WIDE": "1", "SIGAX_READ_ORDER": "1"}, None, seeds=(2, 8, 21))
 
 
+def test_sixteen_lane_groups_bit_exact():
+    """SIGAX_FX_16=1: branching items of at most 16 blocks run four to a wave (a launch of its own between the strict and the
+    branching 32-lane one; an option, off by default: DESIGN.md 4.3).  Read sets with substitutions, duplicates, repeats."""
+    _run_parity({"SIGAX_FX_16": "1"}, None, seeds=(1, 2, 3, 5, 8, 13, 21, 22, 23, 24))
+    _run_parity({"SIGAX_FX_16": "1", "SIGAX_FORCE_WIDE": "1"}, None, seeds=(2, 8, 21))
+    _run_parity({"SIGAX_FX_16": "1"}, "hits_and_asqg or deep or in_flight")
+
+
 def test_correct_without_the_kmer_prefix_table():
     """`siga correct`'s k-mer lookups start from the interval of their last twelve bases (a table of all 12-mers, built on
     first use); SIGAX_KMER_PREFIX=0 walks every step as the reference does.  Same files either way, 32- and 64-bit positions."""

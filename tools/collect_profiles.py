@@ -8,7 +8,7 @@ HBM-side bytes per launch come from the L2's memory-side request counters by siz
 because FETCH_SIZE = 64 B x TCC_EA0_RDREQ whatever the request size (tools/fetch_calib.hip: it reads exactly half of a
 coalesced stream's bytes, and 64 B per line for random 16-byte pieces of 128-byte lines)."""
 import collections, csv, glob, json, os, shutil, sys
-R = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+R = sys.argv[1] if len(sys.argv) > 1 else 'r03'
 O = 'gpurun_out/prof'
 def latest(pat):
     fs = sorted(glob.glob(pat), key=os.path.getmtime)
@@ -42,7 +42,8 @@ for tag, d in (('default', 'q_kt'), ('sub1', 'q_kt1'), ('correct', 'k_kt')):
             print(tag, 'rocprof', k, 'calls', r['Calls'], 'avg ms', float(r['AverageNs']) / 1e6)
     print(tag, 'bench avg_launch_ms', b['roofline']['avg_launch_ms'], 'value', b['value'], 'frac', b['roofline']['frac'])
 
-res, tr = {}, {}
+res = {}
+tr = json.load(open('profiles/traffic.json')) if os.path.exists('profiles/traffic.json') else {}
 for tag, suffix in (('default', ''), ('subbatches_1', '1')):
     merged = collections.defaultdict(dict)
     for name in ('q_rd', 'q_wr', 'q_hm', 'q_fetch'):
@@ -60,7 +61,7 @@ for tag, suffix in (('default', ''), ('subbatches_1', '1')):
             tr['k_find/1000000/5000000/150/%d' % launches] = {
                 'hbm_bytes_per_launch': rd_bytes(c) + wr_bytes(c), 'read': rd_bytes(c), 'write': wr_bytes(c), 'kernel': k,
                 'source': 'profiles/%s_pmc_per_launch.json %s: TCC_EA0_RDREQ/_WRREQ by size class (tools/collect_profiles.py)' % (R, tag)}
-        if k.startswith('k_filter_extract_fast'):
+        if k.startswith('k_filter_extract_fast') or k.startswith('k_fx_route'):
             fx_rd += rd_bytes(c); fx_wr += wr_bytes(c)
     if fx_rd:
         tr['k_filter_extract_fast/1000000/5000000/150/%d' % launches] = {

@@ -46,4 +46,9 @@ if [ "$what" = correct ] || [ "$what" = all ]; then
   run k_rd --kernel-trace --pmc $RD -d $O/k_rd --output-format csv -- $C &&
   run k_hm --kernel-trace --pmc $HM -d $O/k_hm --output-format csv -- $C || exit 1
 fi
+if [ "$what" = full ] || [ "$what" = all ]; then
+  # the plain default run (300 timed steps, CPU baseline leg) as the driver runs it, plus --isolated
+  timeout -k 10 400 python3 bench.py --isolated > $O/bench_full.json 2> $O/bench_full.err; echo "bench_full rc=$?" >> $O/profiles.log
+fi
+find $O -name "*kernel_trace.csv" -size +4M -delete
 cat $O/profiles.log
