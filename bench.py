@@ -396,10 +396,12 @@ def bench_overlap(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": named + "synthetic %dx%d bp reads from %d bp genome, seed %d, min-overlap %d, irreducible, both strands; "
-                                   "FM-index (both strands) resident in HBM, reads sharded over %d GPU(s)%s, locality order of "
-                                   "the batch and edge records to pinned host memory on rank 0 inside the timed region" % (
+                                   "FM-index (both strands) resident in HBM, reads sharded over %d GPU(s)%s; every step hands "
+                                   "the batch its reads anew (what a product batch pays per upload%s is inside the timed region) and "
+                                   "ends with the edge records in pinned host memory on rank 0" % (
                                        n_total, L, G, args.seed, args.min_overlap, job_world,
-                                       " (this process: rank 0's shard only)" if job_world != world else ""),
+                                       " (this process: rank 0's shard only)" if job_world != world else "",
+                                       ", the locality ordering included," if ri["read_order"] else ""),
                        "reads_per_gpu": n_local, "edges": total_edges, "blocks_per_read": st["n_blocks"] / max(n_local, 1),
                        "n_occ_min_per_read": (st["n_occ_find"] + st["n_occ_extract"]) / max(n_local, 1),
                        "sectors_per_read": {"find": sec_f / max(n_local, 1), "extract": sec_x / max(n_local, 1)},
