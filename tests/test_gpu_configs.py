@@ -143,11 +143,11 @@ def _big_case(tag, N, G, L, seed, world, sample, M=45):
 
 
 def test_c3_shape_index_3e9_symbols_one_shard():
-    info = _big_case("c3", 20000000, 100000000, 150, 2, world=8, sample=20000)
+    info = _big_case("c3", 20000000, 100000000, 150, 2, world=8, sample=100000)
     assert info["n_symbols"] == 20000000 * 151 and info["wide"] == 0
 
 
 def test_c5_full_size_wide_index_one_shard_of_eight():
     N = 50000000
-    info = _big_case("c5", N, 230000000, 250, 3, world=8, sample=10000)
+    info = _big_case("c5", N, 230000000, 250, 3, world=8, sample=50000)
     assert info["n_symbols"] == N * 251 >= 2**32 and info["wide"] == 1
