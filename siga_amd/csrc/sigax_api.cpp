@@ -1296,7 +1296,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     const bool order_on = env_ord != nullptr && env_ord[0] != '0';
     static const char* env_coop0 = getenv("SIGAX_FIND_COOP");
     static const char* env_cmin0 = getenv("SIGAX_COOP_MIN_SYMBOLS");
-    const u64 coop_min0 = env_cmin0 ? strtoull(env_cmin0, nullptr, 10) : (1ull << 31);
+    const u64 coop_min0 = env_cmin0 ? strtoull(env_cmin0, nullptr, 10) : (1ull << 30);
     const bool coop_would = (ix->st[0].gran2 && ix->st[1].gran2) && (env_coop0 ? env_coop0[0] != '0' : (ix->wide || ix->n_symbols >= coop_min0)) &&
                             32ull * perm_stride + 32 <= 32768;
     if (order_on && n >= 2 && (coop_would || 128ull * perm_stride + 8 <= find_stage_capacity())) {
@@ -1346,9 +1346,11 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     {
       static const char* env_coop = getenv("SIGAX_FIND_COOP");
       static const char* env_cmin = getenv("SIGAX_COOP_MIN_SYMBOLS");
-      // from 2^31 symbols the per-lane finder's 32-bit byte offsets no longer reach the table; below, it is the faster one
-      // (1.2e9 symbols, one rank's view of an 8-GPU job: 80 M reads/s per lane vs 66 M cooperative, gpurun_out/emu/)
-      const u64 coop_min = env_cmin ? strtoull(env_cmin, nullptr, 10) : (1ull << 31);
+      // From 2^30 symbols the cooperative finder is the faster one (round 3, one rank's view of the 2- / 4- / 8-GPU jobs of
+      // bench.py: 7.6e8 symbols 93.6 M reads/s per lane vs 92.3 M cooperative; 1.5e9 symbols 76.7 vs 90.4 M; round 2, before
+      // the cooperative finder's LDS diet, had 80 vs 66 M at 1.2e9); from 2^31 the per-lane finder's 32-bit byte offsets
+      // no longer reach the table at all.
+      const u64 coop_min = env_cmin ? strtoull(env_cmin, nullptr, 10) : (1ull << 30);
       // the workgroup's 64 reads, staged as 4-bit ranks: one byte range, or by slot under the locality order
       const u64 need = d_perm ? 32ull * perm_stride + 32 : (64ull * b->cur_max_len + 16) / 2 + 16;
       const bool can = fa.two_step && need <= 32768;
