@@ -845,7 +845,7 @@ static u32 order_class_bits() {
   static const u32 bits = [] {
     const char* env = getenv("SIGAX_ORDER_BITS");
     const int b = env ? atoi(env) : 20;
-    return (u32)(b < 8 ? 8 : b > 24 ? 24 : b);
+    return (u32)(b < 8 ? 8 : b > 20 ? 20 : b);  // 3 bits of sub-batch + the class share the low 23 bits of a key
   }();
   return bits;
 }
@@ -858,8 +858,8 @@ static u32 order_class_bits() {
 #define KEYS_LDS_BYTES 16384u
 #define KEYS_NT 64
 template <class GetByte>
-__device__ __forceinline__ u32 read_class(u32 L, u32 bits, GetByte get) {
-  u32 fwd = 0, rev = 0, have = 0, best = 0xFFFFFFFFu, bs = 0;
+__device__ __forceinline__ u32 read_class(u32 L, u32 bits, u32* ord_out, GetByte get) {
+  u32 fwd = 0, rev = 0, have = 0, best = 0xFFFFFFFFu, bs = 0, bo = 0;
   for (u32 i = 0; i < L; ++i) {
     const u32 ch = get(i);
     const u32 c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
@@ -872,8 +872,11 @@ __device__ __forceinline__ u32 read_class(u32 L, u32 bits, GetByte get) {
     h ^= h >> 15;
     h *= 0x85EBCA77u;
     h ^= h >> 13;
-    if (h < best) { best = h; bs = st; }
+    if (h < best) { best = h; bs = st; bo = i - 15u; }
   }
+  // where the minimizer sits in the read, in 4-base steps, turned so that it grows with the read's start in the genome
+  const u32 o9 = (bo >> 2) > 0x1FFu ? 0x1FFu : (bo >> 2);
+  *ord_out = bs ? o9 : 0x1FFu - o9;
   // the strand the minimizer was seen on is part of the class: reads of one class then lie the same way round on the
   // genome, so that it is the same chain (= the same wave of the finder) of each that walks the same rows
   return ((best >> (33u - bits)) << 1) | bs;
@@ -898,16 +901,18 @@ __global__ __launch_bounds__(KEYS_NT) void k_read_keys(const unsigned char* seqs
   for (u32 i = 1; i < ob.n; ++i) sub += r >= ob.b[i] ? 1u : 0u;
   const u64 b0 = offs[r];
   const u32 L = (u32)(offs[r + 1] - b0);
-  u32 cls;
+  u32 cls, ord;
   if (staged) {
     const u32 d = (u32)(reinterpret_cast<u64>(seqs) + b0 - alo);  // this read's first base in the tile
     const unsigned char* tb = reinterpret_cast<const unsigned char*>(tile) + d;
-    cls = read_class(L, bits, [&](u32 i) { return (u32)tb[i]; });
+    cls = read_class(L, bits, &ord, [&](u32 i) { return (u32)tb[i]; });
   } else {
-    cls = read_class(L, bits, [&](u32 i) { return (u32)seqs[b0 + i]; });
+    cls = read_class(L, bits, &ord, [&](u32 i) { return (u32)seqs[b0 + i]; });
   }
   const u32 bucket = (sub << bits) | cls;
   keys[r] = bucket;
+  (void)ord;  // the order by start inside a class (an insertion sort per class, a fourth launch) was tried: it buys the
+              // finder nothing measurable at the configs[2] shape (21.65 ms alone either way, 23.3 ms unordered)
   atomicAdd(&hist[bucket], 1u);
 }
 // exclusive scan of the class counts in place, one workgroup
