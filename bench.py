@@ -412,7 +412,8 @@ def bench_overlap(args):
                        "order_in_timed_region": not args.reuse_order,
                        "candidate_slots_per_chain": ri["cap"], "worst_case_slots_per_chain": ri["worst_cap"],
                        "candidate_arena_bytes": ri["arena_bytes"], "batch_workspace_bytes": ri["workspace_bytes"], "reruns": ri["reruns"],
-                       "row_table": {"bits_per_row": ri["row_bits"], "symbols_per_entry": ri["row_syms"], "text": bool(ri["row_text"])},
+                       "row_table": {"bits_per_row": ri["row_bits"], "symbols_per_entry": ri["row_syms"], "text": bool(ri["row_text"]),
+                                     "direct_maps": bool(ri["row_direct"])},
                        "index_device_bytes": info["device_bytes"]},
             "kernel_ms_per_step": dict({k: float(v) for k, v in zip(KERNELS, kavg)}, order_reads=order_avg),
             "launches_per_step": launches,

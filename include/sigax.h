@@ -216,6 +216,8 @@ typedef struct sigax_run_info {
   uint32_t row_bits;      /* bits per entry of the index's row tables, 0 = none */
   uint32_t row_syms;      /* symbols an entry carries */
   uint32_t row_text;      /* the stretch text exists (extension rounds are read off it) */
+  uint32_t row_direct;    /* ... reached through the direct maps (8 bytes per read) instead of a row table */
+  uint32_t reserved0;
   uint64_t arena_bytes;   /* candidate arena of this batch object */
   uint64_t workspace_bytes; /* all device buffers of this batch object */
   uint64_t reruns;        /* runs of this batch object repeated so far because an arena was too small */

@@ -41,7 +41,7 @@ class IndexInfo(C.Structure):
 
 class RunInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("n_sub", "find_per_sub", "two_step", "coop", "read_order", "cap", "worst_cap", "row_bits",
-                                          "row_syms", "row_text")] + \
+                                          "row_syms", "row_text", "row_direct", "reserved0")] + \
                [("arena_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64), ("reruns", C.c_uint64), ("order_ms", C.c_float)]
 
     def as_dict(self):

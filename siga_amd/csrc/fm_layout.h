@@ -68,6 +68,13 @@
  * the block is emitted with Occ('$') = ld when its read ends (src/overlap_builder.cpp:747-766).  So the rounds of the
  * extractor are one row-table lookup, one text load per 28 rounds (whose address depends on nothing but registers) and
  * no rank arithmetic. */
+/* Direct map (round 3, what indexes with .sai tables and ACGT-only reads get INSTEAD of the row table): a single-row block
+ * names its target read itself -- capped[0] is the read's rank among the '$' rows of the finder's primary index, the
+ * index into that strand's .sai -- and the block's length says how far into the target the overlap reaches.  For strand X
+ * as the EXTENSION index (OverlapBlock::index, src/overlap_builder.cpp:177-179) xmap[r] = (stretch of that read in X's
+ * order) | (its length << 32), r = the rank in the OTHER strand's '$' rows: the block's path starts at offset
+ * length(target) - block.length of that stretch's text.  8 bytes per read instead of 34-57 bits per BWT symbol, and the
+ * lookup hits a table the caches hold instead of a random row of a table of tens of gigabytes. */
 #define SIGAX_TEXT_WINDOW 28  /* symbols per text load that every lane can count on (an unaligned 8-byte load holds 57 to 64 bits of them) */
 
 /* Start table of the block finder (optional, built on the device at open): for every 12-mer, what a chain whose first twelve
@@ -81,6 +88,7 @@ struct FmStrand {
   const uint32_t* granules;  /* n_granules x 16 u32 */
   const unsigned char* sa;    /* row table: n entries of sa_bits bits (+ 8 bytes of padding), or NULL */
   const unsigned char* text;  /* stretch text: C['A'] rows of text_stride bytes, or NULL (then only countdowns use `sa`) */
+  const unsigned long long* xmap;  /* direct map of this strand as extension index (n_strings entries), or NULL */
   unsigned int sa_bits, ld_bits, t_bits, text_stride;  /* symbols per entry = (sa_bits - ld_bits - t_bits) / 2 */
   const uint32_t* gran2;     /* (n / 64 + 1) x 32 u32, or NULL */
   const unsigned long long* super2;  /* [n_super][20], wide mode with two-step tables; else NULL */

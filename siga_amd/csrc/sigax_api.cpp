@@ -90,6 +90,7 @@ struct sigax_index {
   void* d_super2[2]; // ... their superblock bases (64-bit positions) or NULL
   void* d_sa[2];     // row tables (fm_layout.h) or NULL
   void* d_text[2];   // stretch texts (fm_layout.h) or NULL
+  void* d_xmap[2];   // direct maps (fm_layout.h) or NULL
   u64 sa_alloc[2], text_alloc[2];  // bytes allocated for them
   // The row tables of an index of 2^26 symbols and more are built by a side thread while the caller goes on (at BASELINE
   // configs[1] 0.1 s: more than the whole one-batch `siga overlap` spends on the GPU); runs enqueued before they are ready
@@ -101,6 +102,7 @@ struct sigax_index {
   FmStrand tab_st[2];
   u64 tab_bytes, tab_plan, n_runs;
   bool tab_text;
+  bool tab_direct;   // direct maps instead of row tables (.sai tables present, ACGT-only reads)
   u32 tab_syms;      // symbols a row-table entry carries (plan)
   u32 max_read_len;  // longest read of sigax_index_set_reads (0: not told yet), an upper bound of the longest stretch
   void* d_super[2];
@@ -303,6 +305,7 @@ extern "C" void sigax_index_close(sigax_index* ix) {
     if (ix->d_super2[s]) hipFree(ix->d_super2[s]);
     if (ix->d_sa[s]) hipFree(ix->d_sa[s]);
     if (ix->d_text[s]) hipFree(ix->d_text[s]);
+    if (ix->d_xmap[s]) hipFree(ix->d_xmap[s]);
     if (ix->d_start[s]) hipFree(ix->d_start[s]);
     if (ix->d_super[s]) hipFree(ix->d_super[s]);
     if (ix->d_sai[s]) hipFree(ix->d_sai[s]);
@@ -364,27 +367,49 @@ static void plan_row_tables(sigax_index* ix) {
   size_t mfree = 0, mtotal = 0;
   (void)hipMemGetInfo(&mfree, &mtotal);
   ix->tab_text = !(envl && envl[0] == '0');
-  // entries with as many of their first symbols (14 at most) as fit half of the free memory (one lookup then serves an
-  // item's first rounds: at BASELINE configs[1] 14 symbols, 56 bits per row); bare entries when they fit 70 %
+  // Row table with as many of its entries' first symbols (14 at most) as fit half of the free memory (one lookup then
+  // serves an item's first rounds: at BASELINE configs[1] 14 symbols, 56 bits per row); bare entries when they fit 70 %;
+  // else -- when the .sai tables are there and every stretch is a read (no non-ACGT bases) -- the DIRECT MAPS (fm_layout.h):
+  // text + 8 bytes per read and strand, no table per BWT symbol.  Measured (gpurun_out/r3u/): one lookup in the big table
+  // beats two in small ones -- configs[1] 119.9 M reads/s on the row table, 108.8 M on direct maps (whose 112 MB compete
+  // with the finder's table for the Infinity Cache: the finder goes from 8.3 to 9.1 ms), configs[2] shape 86.4 vs 77.4 M,
+  // configs[4] (bare entries: two lookups either way) 38.4 vs 37.3 M with 188 vs 79 GB on the device -- so the direct maps
+  // are what an index too big for a row table gets instead of nothing.  SIGAX_XMAP=1 forces them, =0 forbids them.
+  const char* envx = getenv("SIGAX_XMAP");
+  const bool can_direct = ix->tab_text && !(envx && envx[0] == '0') && ix->d_sai[0] && ix->d_sai[1] && ix->n_sai == ix->n_strings &&
+                          ix->st[0].C[1] == ix->n_strings && ix->st[1].C[1] == ix->n_strings;
+  auto plan_direct = [&]() -> bool {
+    const RowTabGeom g = row_tab_geom(ix, maxlen_bound(ix), 0);
+    const u64 want = 2 * (g.text_bytes + 8 * ix->n_strings);
+    if (!can_direct || want >= mfree / 10 * 7) return false;
+    ix->tab_direct = true;
+    ix->tab_plan = want;
+    ix->tab_syms = 0;
+    return true;
+  };
+  ix->tab_direct = false;
+  if (envx && envx[0] == '1' && plan_direct()) return;
   static const char* envk = getenv("SIGAX_ROW_SYMS");
   for (u32 syms = ix->tab_text ? (envk ? (u32)atoi(envk) : 14u) : 0u;; --syms) {
     const RowTabGeom g = row_tab_geom(ix, maxlen_bound(ix), syms);
-    if (g.sa_bits > 57) return;
+    if (g.sa_bits > 57) break;
     const u64 want = 2 * (g.sa_bytes + (ix->tab_text ? g.text_bytes : 0));
     if (want < mfree / 10 * (syms ? 5 : 7)) {
       ix->tab_plan = want;
       ix->tab_syms = syms;
       return;
     }
-    if (syms == 0) return;
+    if (syms == 0) break;
   }
+  (void)plan_direct();
 }
 
 static void free_row_tables(sigax_index* ix) {
   for (int s = 0; s < 2; ++s) {
     if (ix->d_sa[s]) hipFree(ix->d_sa[s]);
     if (ix->d_text[s]) hipFree(ix->d_text[s]);
-    ix->d_sa[s] = ix->d_text[s] = nullptr;
+    if (ix->d_xmap[s]) hipFree(ix->d_xmap[s]);
+    ix->d_sa[s] = ix->d_text[s] = ix->d_xmap[s] = nullptr;
     ix->sa_alloc[s] = ix->text_alloc[s] = 0;
   }
 }
@@ -395,8 +420,12 @@ static bool alloc_row_tables(sigax_index* ix) {
   ix->tab_plan = 0;
   hipError_t e = hipSuccess;
   for (int s = 0; s < 2 && e == hipSuccess; ++s) {
-    e = hipMalloc(&ix->d_sa[s], g.sa_bytes);
-    if (e == hipSuccess) ix->sa_alloc[s] = g.sa_bytes;
+    if (!ix->tab_direct) {
+      e = hipMalloc(&ix->d_sa[s], g.sa_bytes);
+      if (e == hipSuccess) ix->sa_alloc[s] = g.sa_bytes;
+    } else {
+      e = hipMalloc(&ix->d_xmap[s], std::max<u64>(ix->n_strings, 1) * 8);
+    }
     if (e == hipSuccess && ix->tab_text) {
       e = hipMalloc(&ix->d_text[s], g.text_bytes);
       if (e == hipSuccess) ix->text_alloc[s] = g.text_bytes;
@@ -426,6 +455,13 @@ static void fill_row_tables(sigax_index* ix, FmStrand out[2], u64* out_bytes) {
   if (e == hipSuccess) e = hipMalloc((void**)&d_max, 8);
   u32 maxlen[2] = {0, 0};
   RowTabGeom g[2];
+  const bool direct = ix->tab_direct;
+  u32* slen[2] = {nullptr, nullptr};  // direct maps: the stretches' lengths by '$' rank (scratch)
+  u32* isai = nullptr;
+  if (direct) {
+    for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipMalloc((void**)&slen[s], std::max<u64>(n_stretch, 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&isai, std::max<u64>(n_stretch, 1) * 4);
+  }
   for (int s = 0; s < 2 && e == hipSuccess; ++s) {
     e = hipMemsetAsync(d_max, 0, 8, sb);
     if (e != hipSuccess) break;
@@ -436,7 +472,7 @@ static void fill_row_tables(sigax_index* ix, FmStrand out[2], u64* out_bytes) {
     if (e != hipSuccess) break;
     g[s] = row_tab_geom(ix, maxlen[s], ix->tab_syms);
     if (g[s].sa_bits > 57) { e = hipErrorInvalidValue; break; }
-    if (g[s].sa_bytes > ix->sa_alloc[s]) {
+    if (!direct && g[s].sa_bytes > ix->sa_alloc[s]) {
       hipFree(ix->d_sa[s]);
       ix->d_sa[s] = nullptr;
       ix->sa_alloc[s] = 0;
@@ -452,14 +488,23 @@ static void fill_row_tables(sigax_index* ix, FmStrand out[2], u64* out_bytes) {
       if (e != hipSuccess) break;
       ix->text_alloc[s] = g[s].text_bytes;
     }
-    e = hipMemsetAsync(ix->d_sa[s], 0, ix->sa_alloc[s], sb);
+    if (!direct) e = hipMemsetAsync(ix->d_sa[s], 0, ix->sa_alloc[s], sb);
     if (e == hipSuccess && ix->tab_text) e = hipMemsetAsync(ix->d_text[s], 0, ix->text_alloc[s], sb);
     if (e != hipSuccess) break;
-    launch_rows_fill(ix->st[s], ix->wide, n_stretch, (const u64*)info, (unsigned char*)ix->d_sa[s], g[s].sa_bits, g[s].ld_bits, g[s].t_bits,
-                     ix->tab_text ? (unsigned char*)ix->d_text[s] : nullptr, g[s].text_stride, sb);
+    launch_rows_fill(ix->st[s], ix->wide, n_stretch, (const u64*)info, direct ? nullptr : (unsigned char*)ix->d_sa[s], g[s].sa_bits, g[s].ld_bits,
+                     g[s].t_bits, ix->tab_text ? (unsigned char*)ix->d_text[s] : nullptr, g[s].text_stride, slen[s], sb);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(sb);
   }
+  // direct maps: strand s as extension index serves the blocks whose capped[0] counts the OTHER strand's '$' rows
+  for (int s = 0; direct && s < 2 && e == hipSuccess; ++s) {
+    launch_xmap(ix->d_sai[1 - s], ix->d_sai[s], isai, slen[s], ix->n_strings, (u64*)ix->d_xmap[s], sb);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(sb);
+  }
+  for (int s = 0; s < 2; ++s)
+    if (slen[s]) hipFree(slen[s]);
+  if (isai) hipFree(isai);
   if (sb) (void)hipStreamDestroy(sb);
   if (info) hipFree(info);
   if (d_max) hipFree(d_max);
@@ -469,7 +514,9 @@ static void fill_row_tables(sigax_index* ix, FmStrand out[2], u64* out_bytes) {
     return;  // the buffers are freed with the index
   }
   for (int s = 0; s < 2; ++s) {
-    out[s].sa = (const unsigned char*)ix->d_sa[s];
+    out[s].sa = direct ? nullptr : (const unsigned char*)ix->d_sa[s];
+    out[s].xmap = direct ? (const u64*)ix->d_xmap[s] : nullptr;
+    if (direct) *out_bytes += 8 * ix->n_strings;
     out[s].text = ix->tab_text ? (const unsigned char*)ix->d_text[s] : nullptr;
     out[s].sa_bits = g[s].sa_bits;
     out[s].ld_bits = g[s].ld_bits;
@@ -477,7 +524,9 @@ static void fill_row_tables(sigax_index* ix, FmStrand out[2], u64* out_bytes) {
     out[s].text_stride = g[s].text_stride;
     *out_bytes += ix->sa_alloc[s] + ix->text_alloc[s];
   }
-  if (getenv("SIGAX_VERBOSE"))
+  if (getenv("SIGAX_VERBOSE") && direct)
+    fprintf(stderr, "[sigax] direct maps (8 bytes per read and strand) + text rows of %u bytes, %.2f GB\n", g[0].text_stride, *out_bytes / 1e9);
+  else if (getenv("SIGAX_VERBOSE"))
     fprintf(stderr, "[sigax] row tables: %u bits per row (stretch %u + offset %u + %u symbols), text rows of %u bytes, %.2f GB\n", g[0].sa_bits,
             g[0].ld_bits, g[0].t_bits, (g[0].sa_bits - g[0].ld_bits - g[0].t_bits) / 2, ix->tab_text ? g[0].text_stride : 0u, *out_bytes / 1e9);
 }
@@ -487,6 +536,7 @@ static void publish_tables(sigax_index* ix) {
   if (!ix->tab_state || ix->tab_state->load(std::memory_order_acquire) != 2) return;
   for (int s = 0; s < 2; ++s) {
     ix->st[s].sa = ix->tab_st[s].sa;
+    ix->st[s].xmap = ix->tab_st[s].xmap;
     ix->st[s].text = ix->tab_st[s].text;
     ix->st[s].sa_bits = ix->tab_st[s].sa_bits;
     ix->st[s].ld_bits = ix->tab_st[s].ld_bits;
@@ -666,7 +716,6 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
       }
     }
   }
-  build_rowend(ix);
   if (sai && rsai) {
     const uint32_t* ss[2] = {sai, rsai};
     for (int s = 0; s < 2; ++s)  // k_edges indexes the read tables with these ids
@@ -685,6 +734,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
     }
     ix->n_sai = n_strings;
   }
+  build_rowend(ix);  // after the .sai tables: with them the extractor's tables are direct maps (fm_layout.h)
   *out = ix;
   return SIGAX_OK;
 }
@@ -783,6 +833,7 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
     if (rc == SIGAX_OK) rc = copy(&ix->d_start[s], src->d_start[s], start_table_bytes(src->wide));
     ix->st[s] = src->st[s];
     ix->st[s].sa = nullptr;
+    ix->st[s].xmap = nullptr;
     ix->st[s].text = nullptr;
     ix->st[s].granules = (const uint32_t*)ix->d_gran[s];
     ix->st[s].super = (const u64*)ix->d_super[s];
@@ -847,9 +898,38 @@ extern "C" int sigax_index_check_order(sigax_index* ix, int which, uint64_t* n_b
       ix->tab_thread = nullptr;
     }
     publish_tables(ix);
-    if (!ix->st[which].sa && ix->tab_plan) start_row_tables(ix, true);
+    if (!ix->st[which].text && ix->tab_plan) start_row_tables(ix, true);
   }
-  if (!ix->st[which].sa || !ix->st[which].text) return fail(SIGAX_E_STATE, "no row tables on this index (memory short or turned off)");
+  if (!ix->st[which].text) return fail(SIGAX_E_STATE, "no extractor tables on this index (memory short or turned off)");
+  // The check reads the suffix array.  An index that runs on direct maps has none: a bare row table of this strand is
+  // built for the duration of the call (two LF walks over the strand).
+  FmStrand cs = ix->st[which];
+  DevGuard tg;
+  if (!cs.sa) {
+    const u64 n_stretch = cs.C[1];
+    void* info = nullptr;
+    u32* d_max = nullptr;
+    HIP_TRY(tg.alloc(&info, std::max<u64>(n_stretch, 1) * 8));
+    HIP_TRY(tg.alloc((void**)&d_max, 8));
+    HIP_TRY(hipMemset(d_max, 0, 8));
+    launch_stretch_scan(cs, ix->wide, n_stretch, (u64*)info, d_max, nullptr);
+    HIP_TRY(hipGetLastError());
+    u32 maxlen = 0;
+    HIP_TRY(hipMemcpy(&maxlen, d_max, 4, hipMemcpyDeviceToHost));
+    const RowTabGeom g = row_tab_geom(ix, maxlen, 0);
+    if (g.sa_bits > 57) return fail(SIGAX_E_STATE, "stretches too long for a row table");
+    void* sa = nullptr;
+    HIP_TRY(tg.alloc(&sa, g.sa_bytes));
+    HIP_TRY(hipMemset(sa, 0, g.sa_bytes));
+    launch_rows_fill(cs, ix->wide, n_stretch, (const u64*)info, (unsigned char*)sa, g.sa_bits, g.ld_bits, g.t_bits, nullptr, g.text_stride, nullptr,
+                     nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    cs.sa = (const unsigned char*)sa;
+    cs.sa_bits = g.sa_bits;
+    cs.ld_bits = g.ld_bits;
+    cs.t_bits = g.t_bits;
+  }
   DevGuard g;
   uint32_t* isai = nullptr;
   u64* bad = nullptr;
@@ -857,7 +937,7 @@ extern "C" int sigax_index_check_order(sigax_index* ix, int which, uint64_t* n_b
   HIP_TRY(g.alloc((void**)&bad, 32));
   const u64 init[4] = {0, ~0ull, 0, 0};
   HIP_TRY(hipMemcpy(bad, init, 32, hipMemcpyHostToDevice));
-  launch_suffix_order_check(ix->st[which], ix->d_sai[which], isai, ix->d_read_len, ix->n_strings, bad, nullptr);
+  launch_suffix_order_check(cs, ix->d_sai[which], isai, ix->d_read_len, ix->n_strings, bad, nullptr);
   HIP_TRY(hipGetLastError());
   u64 out[4];
   HIP_TRY(hipMemcpy(out, bad, 32, hipMemcpyDeviceToHost));
@@ -1407,6 +1487,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     xa.no_lean = (b->lean_off || skip_strict) ? 1u : 0u;
     xa.arena = b->arena.p;
     xa.chain_cnt = (const uint32_t*)b->chain_cnt.p;
+    xa.n_map = ix->n_strings;
     xa.pool = (Ent*)b->pool.p;
     xa.pool_cap = b->pool_cap;
     xa.wpool = (Ent*)b->wpool.p;
@@ -1768,6 +1849,7 @@ extern "C" int sigax_batch_run_info(sigax_batch* b, sigax_run_info* out) {
   out->row_bits = f.sa ? f.sa_bits : 0u;
   out->row_syms = f.sa ? (f.sa_bits - f.ld_bits - f.t_bits) / 2u : 0u;
   out->row_text = f.text ? 1u : 0u;
+  out->row_direct = f.xmap ? 1u : 0u;
   out->arena_bytes = b->arena.bytes;
   DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->work64c, &b->work64d, &b->perm,
                    &b->ord_keys, &b->ord_tmp, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin, &b->fin_cnt, &b->substring, &b->block_offs,

@@ -67,6 +67,7 @@ struct FxArgs {
   uint32_t no_lean;   // skip the lean (single-group only) launches: the previous run of this batch object sent most items on
   const void* arena;
   const uint32_t* chain_cnt;
+  unsigned long long n_map;  // entries of the strands' direct maps (= reads of the index)
   Ent* pool;          // [lanes][pool_cap]
   uint32_t pool_cap;
   const uint32_t* work;  // optional list of read ids; NULL = all reads
@@ -185,11 +186,16 @@ void launch_build2(const FmStrand& s, bool wide, uint32_t* gran2, unsigned long 
                    unsigned long long* total, hipStream_t st);
 // Row table + stretch text of one strand (fm_layout.h), two walks over every stretch (n_stretch = C['A'] of them):
 // launch_stretch_scan fills info[n_stretch] and *maxlen (zeroed by the caller) = the longest stretch, from which the caller
-// sizes the entries; launch_rows_fill writes the table (zeroed by the caller, n * sa_bits bits + 16 bytes) and, unless NULL,
-// the text rows.
+// sizes the entries; launch_rows_fill writes the table (zeroed by the caller, n * sa_bits bits + 16 bytes; or sa = NULL), unless
+// NULL the text rows, and unless NULL the stretches' lengths by their rank among the '$' rows.
 void launch_stretch_scan(const FmStrand& s, bool wide, unsigned long long n_stretch, unsigned long long* info, uint32_t* maxlen, hipStream_t st);
 void launch_rows_fill(const FmStrand& s, bool wide, unsigned long long n_stretch, const unsigned long long* info, unsigned char* sa,
-                      uint32_t sa_bits, uint32_t ld_bits, uint32_t t_bits, unsigned char* text, uint32_t text_stride, hipStream_t st);
+                      uint32_t sa_bits, uint32_t ld_bits, uint32_t t_bits, unsigned char* text, uint32_t text_stride, uint32_t* slen,
+                      hipStream_t st);
+// direct map of strand X as extension index (fm_layout.h) from the other strand's .sai ids (sai_y), X's own (sai_x; isai_tmp =
+// n u32 of scratch for its inverse) and X's stretch lengths by '$' rank (slen_x, written by launch_rows_fill)
+void launch_xmap(const uint32_t* sai_y, const uint32_t* sai_x, uint32_t* isai_tmp, const uint32_t* slen_x, unsigned long long n,
+                 unsigned long long* xmap, hipStream_t st);
 void launch_order_scatter(const OrderArgs& a, hipStream_t st);
 unsigned long long fast_fin_chunk();
 unsigned long long cand_bytes(bool wide);

@@ -428,6 +428,13 @@ __device__ __forceinline__ u64 text_bits(const FmStrand& st, u32 ld, u32 off) { 
   __builtin_memcpy(&w, st.text + (u64)ld * st.text_stride + (off >> 2), 8);
   return w >> (2u * (off & 3u));
 }
+// direct map of strand X as extension index (fm_layout.h): sai_y = the other strand's .sai ids, isai_x = inverse of X's
+__global__ __launch_bounds__(256) void k_xmap(const u32* sai_y, const u32* isai_x, const u32* slen_x, u64 n, u64* xmap) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u32 ldx = isai_x[sai_y[i]];
+  xmap[i] = (u64)ldx | ((u64)slen_x[ldx] << 32);
+}
 __global__ __launch_bounds__(256) void k_isai(const u32* sai, u64 n, u32* isai) {
   const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
   if (i < n) isai[sai[i]] = (u32)i;
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(256) void k_suffix_order_check(FmStrand st, const u
 #define ROWS_KMAX 14  // most symbols an entry can carry (fm_layout.h)
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_rows_fill(FmStrand s, u64 n_stretch, const u64* info, unsigned char* sa, u32 sa_bits, u32 ld_bits, u32 t_bits,
-                                                   unsigned char* text, u32 text_stride) {
+                                                   unsigned char* text, u32 text_stride, u32* slen) {
   const u64 j = (u64)blockIdx.x * 256 + threadIdx.x;
   if (j >= n_stretch) return;
   const u64 v = info[j];
@@ -480,7 +487,8 @@ __global__ __launch_bounds__(256) void k_rows_fill(FmStrand s, u64 n_stretch, co
   const FmRef f = fm_ref(s, 0);
   const u64 C[5] = {s.C[0], s.C[1], s.C[2], s.C[3], s.C[4]};
   const u64 ld = v & 0xFFFFFFFFull;
-  const u32 K = (sa_bits - ld_bits - t_bits) >> 1;  // symbols carried by an entry
+  if (slen != nullptr) slen[ld] = (u32)(v >> 32);  // the stretch's length, by its rank among the '$' rows
+  const u32 K = sa != nullptr ? (sa_bits - ld_bits - t_bits) >> 1 : 0u;  // symbols carried by an entry
   u64 p = j;
   unsigned char* trow = text ? text + ld * text_stride : nullptr;
   // A window of the last ROWS_KMAX rows slides along: when the K-th symbol after a row has been seen its entry is complete
@@ -496,7 +504,7 @@ __global__ __launch_bounds__(256) void k_rows_fill(FmStrand s, u64 n_stretch, co
     R[ROWS_KMAX - 1] = row;
     wsym = (wsym << 2) | ((c - 1u) & 3u);
     vm = (vm << 1) | (real ? 1u : 0u);
-    if (K == 0) return;
+    if (K == 0 || sa == nullptr) return;
     u64 r0 = R[0];
 #pragma unroll
     for (int i = 1; i < ROWS_KMAX; ++i)
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(256) void k_rows_fill(FmStrand s, u64 n_stretch, co
     }
   };
   for (u64 t = v >> 32;; --t) {
-    if (K == 0) packed_or(sa, p, sa_bits, (t << ld_bits) | ld);
+    if (K == 0 && sa != nullptr) packed_or(sa, p, sa_bits, (t << ld_bits) | ld);
     u64 q;
     const u32 c = lf_row<WIDE>(f, C, p, &q);  // the symbol at offset t - 1; rank 0 exactly when t == 0
     insert(p, c, true, t);
@@ -2528,13 +2536,27 @@ struct GFx {
         // the entry's own symbols serve the first rounds (a window that is used up after that many); without them the
         // first text window is loaded at once
         const FmStrand& xs = find_of(e.src) < 2 ? A.rev : A.fwd;
-        const u32 K = (xs.sa_bits - xs.ld_bits - xs.t_bits) >> 1;
-        if (gl < n) {
-          const u64 syms = row_lookup(xs, (u64)e.c1lo, tld, ttt);
-          tw = K ? syms << (64u - 2u * K) : text_window(xs, tld, ttt);
+        if (xs.xmap != nullptr) {
+          // direct: the block names its target (capped[0] = its rank in the other strand's '$' rows) and its length says
+          // where in the target the path starts (fm_layout.h); capped[0].lower is below n_strings by construction
+          if (gl < n) {
+            const u64 m = xs.xmap[(u64)e.c0lo < A.n_map ? (u64)e.c0lo : 0ull];
+            tld = (u32)m;
+            const u32 tl = (u32)(m >> 32), bl = e.len;
+            ttt = tl > bl ? tl - bl : 0u;
+            tw = text_window(xs, tld, ttt);
+          }
+          tk = 0;
+          sec_add(2u * n);
+        } else {
+          const u32 K = (xs.sa_bits - xs.ld_bits - xs.t_bits) >> 1;
+          if (gl < n) {
+            const u64 syms = row_lookup(xs, (u64)e.c1lo, tld, ttt);
+            tw = K ? syms << (64u - 2u * K) : text_window(xs, tld, ttt);
+          }
+          tk = K ? (u32)SIGAX_TEXT_WINDOW - K : 0u;
+          sec_add(K ? n : 2u * n);
         }
-        tk = K ? (u32)SIGAX_TEXT_WINDOW - K : 0u;
-        sec_add(K ? n : 2u * n);
       }
     }
 #ifdef SIGAX_FX_PROFILE
@@ -3699,7 +3721,7 @@ static void launch_fx_stages(const FxArgs& a, unsigned grid32, unsigned grid64, 
   // queue 3 (text launches): what the 16-lane launch leaves to the branching 32-lane one
   static const bool no_text = getenv("SIGAX_FX_NO_TEXT") != nullptr;  // A/B aid
   static const bool use_16 = getenv("SIGAX_FX_16") != nullptr;  // see below
-  if (a.fwd.text && a.rev.text && a.fwd.sa && a.rev.sa && !no_text) {
+  if (a.fwd.text && a.rev.text && ((a.fwd.sa && a.rev.sa) || (a.fwd.xmap && a.rev.xmap)) && !no_text) {
     if (!a.no_lean) { route(); stage(k_filter_extract_fast<WIDE, 32, 5>, grid32, -1, 0, -1); }
     // SIGAX_FX_16=1: branching items of at most 16 blocks -- what reads with substitutions mostly make: errors cost them
     // overlaps -- four to a wave in a launch of their own; wider ones, and whatever outgrows a quarter wave's slots, go on
@@ -3767,10 +3789,15 @@ void launch_stretch_scan(const FmStrand& s, bool wide, u64 n_stretch, u64* info,
   else hipLaunchKernelGGL(k_stretch_scan<false>, dim3(nblk(n_stretch, 256)), dim3(256), 0, st, s, n_stretch, info, maxlen);
 }
 void launch_rows_fill(const FmStrand& s, bool wide, u64 n_stretch, const u64* info, unsigned char* sa, u32 sa_bits, u32 ld_bits, u32 t_bits,
-                      unsigned char* text, u32 text_stride, hipStream_t st) {
+                      unsigned char* text, u32 text_stride, u32* slen, hipStream_t st) {
   if (n_stretch == 0) return;
-  if (wide) hipLaunchKernelGGL(k_rows_fill<true>, dim3(nblk(n_stretch, 256)), dim3(256), 0, st, s, n_stretch, info, sa, sa_bits, ld_bits, t_bits, text, text_stride);
-  else hipLaunchKernelGGL(k_rows_fill<false>, dim3(nblk(n_stretch, 256)), dim3(256), 0, st, s, n_stretch, info, sa, sa_bits, ld_bits, t_bits, text, text_stride);
+  if (wide) hipLaunchKernelGGL(k_rows_fill<true>, dim3(nblk(n_stretch, 256)), dim3(256), 0, st, s, n_stretch, info, sa, sa_bits, ld_bits, t_bits, text, text_stride, slen);
+  else hipLaunchKernelGGL(k_rows_fill<false>, dim3(nblk(n_stretch, 256)), dim3(256), 0, st, s, n_stretch, info, sa, sa_bits, ld_bits, t_bits, text, text_stride, slen);
+}
+void launch_xmap(const u32* sai_y, const u32* sai_x, u32* isai_tmp, const u32* slen_x, u64 n, u64* xmap, hipStream_t st) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_isai, dim3(nblk(n, 256)), dim3(256), 0, st, sai_x, n, isai_tmp);
+  hipLaunchKernelGGL(k_xmap, dim3(nblk(n, 256)), dim3(256), 0, st, sai_y, (const u32*)isai_tmp, slen_x, n, xmap);
 }
 
 u64 scan_partials_needed(u64 n) { return (n + 1 + SCAN_ITEMS - 1) / SCAN_ITEMS + 1; }

@@ -111,13 +111,19 @@ def test_locality_order_of_the_batch_bit_exact():
 
 
 def test_extractor_forms_without_the_row_tables():
-    """The row table and the stretch text (fm_layout.h) are accelerators.  With both, filter/extract reads a block's next
-    symbols off its read's text -- the first ones from the row-table entry itself when memory allows (what every other test
-    runs), or with bare entries (SIGAX_ROW_SYMS=0: what BASELINE configs[4] at full size gets) from the text alone -- and a
-    lone single-row group is a countdown; with SIGAX_LOOKAHEAD=0 the rounds come from two-step lines (or one-step
-    granules) and only the countdown uses the row table; with SIGAX_ROWEND=0 neither exists and the extractor walks as the
-    reference does.  Every form gives the oracle's bytes on read sets with substitutions, duplicates and substrings, 32- and
-    64-bit positions."""
+    """The extractor's tables (fm_layout.h) are accelerators.  With the bit-packed row table + the stretch text,
+    filter/extract reads a block's next symbols off its read's text -- the first ones from the row-table entry itself when
+    memory allows (what every other test runs), with bare entries (SIGAX_ROW_SYMS=0: what BASELINE configs[4] at full size
+    gets) from the text alone.  An index too big for a row table gets DIRECT MAPS instead (SIGAX_XMAP=1 forces them: a
+    single-row block names its target read itself through the .sai tables; reads with non-ACGT bases fall back to the row
+    table).  With SIGAX_LOOKAHEAD=0 there is no text: the rounds come from two-step lines (or one-step granules) and only
+    the countdown uses the row table; with SIGAX_ROWEND=0 nothing exists and the extractor walks as the reference does.
+    Every form gives the oracle's bytes on read sets with substitutions, duplicates and substrings, 32- and 64-bit
+    positions."""
+    _run_parity({"SIGAX_XMAP": "1"}, None, seeds=(1, 2, 3, 5, 8, 13, 21, 22, 23, 24))
+    _run_parity({"SIGAX_XMAP": "1"}, "hits_and_asqg or non_acgt or duplicate or deep or in_flight")
+    _run_parity({"SIGAX_XMAP": "1", "SIGAX_FORCE_WIDE": "1"}, None, seeds=(2, 3, 8, 21))
+    _run_parity({"SIGAX_XMAP": "1", "SIGAX_FIND_COOP": "1", "SIGAX_FX_16": "1"}, None, seeds=(1, 8, 13))
     _run_parity({"SIGAX_ROW_SYMS": "0"}, None, seeds=(1, 2, 3, 5, 8, 13, 21))
     _run_parity({"SIGAX_ROW_SYMS": "0", "SIGAX_FORCE_WIDE": "1"}, None, seeds=(2, 3, 8, 21))
     _run_parity({"SIGAX_ROW_SYMS": "0"}, "hits_and_asqg or non_acgt or duplicate or deep")
