@@ -47,7 +47,7 @@ def build_host(force=False, verbose=False):
     deps = [os.path.join(HOST, f) for f in ("siga_host.cpp", "siga_host.hpp", "sais.hpp", "siga_main.cpp")] + [LIB]
     libdir = os.path.dirname(LIB)
     common = [CXX, "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-sign-compare", "-pthread"]
-    link = ["-L" + libdir, "-lsigax", "-lz", "-Wl,-rpath,$ORIGIN"]
+    link = ["-L" + libdir, "-lsigax", "-lz", "-ldl", "-Wl,-rpath,$ORIGIN"]
     if force or _stale(HOSTLIB, deps):
         cmd = common + ["-shared", "-o", HOSTLIB, os.path.join(HOST, "siga_host.cpp")] + link
         if verbose:

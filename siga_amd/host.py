@@ -21,6 +21,7 @@ def lib():
                                             C.c_char_p, C.c_uint64]
         L.sigah_index_file_dev.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_uint64]
         L.sigah_index_file.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_uint64]
+        L.sigah_index_file_sais.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_uint64]
         L.sigah_overlap_file.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_int, C.c_int, C.c_uint64,
                                          C.c_uint64, C.c_int, C.c_char_p, C.c_uint64]
         L.sigah_overlap_file_gpus.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_int, C.c_int, C.c_uint64,
@@ -68,6 +69,13 @@ def index_file(reads_path, prefix, threads=2):
     err = C.create_string_buffer(512)
     if lib().sigah_index_file(reads_path.encode(), prefix.encode(), threads, err, 512) != 0:
         raise RuntimeError("siga index failed: " + err.value.decode())
+
+
+def index_file_sais(reads_path, prefix, threads=2):
+    """`siga index -a sais`: SAISBuilder's suffix order (every read's own sentinel, ordered by read index), host sorter"""
+    err = C.create_string_buffer(512)
+    if lib().sigah_index_file_sais(reads_path.encode(), prefix.encode(), threads, 1, 1, err, 512) != 0:
+        raise RuntimeError("siga index -a sais failed: " + err.value.decode())
 
 
 def overlap_file(reads_path, prefix, min_overlap, output, irreducible=True, rc=True, threads=1, batch=10000, device=0, gpus=1):

@@ -4,6 +4,7 @@
 
 #include <zlib.h>
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -24,15 +25,102 @@
 namespace sigah {
 
 // ------------------------------------------------------------------------------------------------------
+// bzip2 input (Utils::ifstream, src/utils.cpp:50-126: ".bz2" goes through a bzip2 filter).  The image has libbz2's shared
+// library but not its header: the three entry points of its streaming interface are bound at run time (the bz_stream layout
+// is libbz2's documented public one); without the library a .bz2 input fails to open.
+// ------------------------------------------------------------------------------------------------------
+namespace {
+struct BzStream {
+  char* next_in;
+  unsigned int avail_in, total_in_lo32, total_in_hi32;
+  char* next_out;
+  unsigned int avail_out, total_out_lo32, total_out_hi32;
+  void* state;
+  void* (*bzalloc)(void*, int, int);
+  void (*bzfree)(void*, void*);
+  void* opaque;
+};
+struct Bz2Lib {
+  int (*init)(BzStream*, int, int) = nullptr;
+  int (*run)(BzStream*) = nullptr;
+  int (*end)(BzStream*) = nullptr;
+  Bz2Lib() {
+    void* h = dlopen("libbz2.so.1.0", RTLD_NOW);
+    if (!h) h = dlopen("libbz2.so.1", RTLD_NOW);
+    if (!h) return;
+    init = (int (*)(BzStream*, int, int))dlsym(h, "BZ2_bzDecompressInit");
+    run = (int (*)(BzStream*))dlsym(h, "BZ2_bzDecompress");
+    end = (int (*)(BzStream*))dlsym(h, "BZ2_bzDecompressEnd");
+    if (!init || !run || !end) init = nullptr;
+  }
+};
+}  // namespace
+static bool is_bz2(const unsigned char* magic, ssize_t got) { return got >= 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h'; }
+// the whole of a (possibly multi-stream) bzip2 file, decompressed; false on a corrupt or truncated stream
+static bool bz2_expand(const std::vector<char>& in, std::vector<char>* out) {
+  static const Bz2Lib lib;
+  if (!lib.init) return false;
+  out->resize(std::max<size_t>(in.size() * 5, 1 << 20));
+  size_t len = 0, pos = 0;
+  while (pos < in.size()) {
+    BzStream z;
+    memset(&z, 0, sizeof(z));
+    if (lib.init(&z, 0, 0) != 0) return false;
+    int rc = 0;
+    while (rc == 0) {
+      if (out->size() - len < (1u << 20)) out->resize(out->size() * 2);
+      z.next_in = const_cast<char*>(in.data()) + pos;
+      z.avail_in = (unsigned)std::min<size_t>(in.size() - pos, 1u << 30);
+      z.next_out = out->data() + len;
+      z.avail_out = (unsigned)std::min<size_t>(out->size() - len, 1u << 30);
+      const unsigned in0 = z.avail_in, out0 = z.avail_out;
+      rc = lib.run(&z);
+      pos += in0 - z.avail_in;
+      len += out0 - z.avail_out;
+      if (rc == 0 && in0 == z.avail_in && out0 == z.avail_out) rc = -1;  // no progress: truncated
+    }
+    lib.end(&z);
+    if (rc != 4) return false;  // BZ_STREAM_END
+  }
+  out->resize(len);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // line source / sequence readers
 // ------------------------------------------------------------------------------------------------------
 class LineSource {
  public:
-  explicit LineSource(const std::string& path) : _pos(0), _len(0), _eof(false), _err(false) { _f = gzopen(path.c_str(), "rb"); }
+  explicit LineSource(const std::string& path) : _f(nullptr), _pos(0), _len(0), _eof(false), _err(false), _mpos(0), _ismem(false) {
+    unsigned char magic[3] = {0, 0, 0};
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return;
+    const ssize_t got = pread(fd, magic, 3, 0);
+    if (is_bz2(magic, got)) {  // expanded in memory, then served like a file
+      std::vector<char> raw;
+      struct stat st;
+      bool ok = fstat(fd, &st) == 0;
+      if (ok) {
+        raw.resize((size_t)st.st_size);
+        size_t n = 0;
+        while (n < raw.size()) {
+          ssize_t k = read(fd, raw.data() + n, raw.size() - n);
+          if (k <= 0) break;
+          n += (size_t)k;
+        }
+        ok = n == raw.size() && bz2_expand(raw, &_mem);
+      }
+      close(fd);
+      _ismem = ok;
+      return;
+    }
+    close(fd);
+    _f = gzopen(path.c_str(), "rb");
+  }
   ~LineSource() {
     if (_f) gzclose(_f);
   }
-  bool ok() const { return _f != nullptr; }
+  bool ok() const { return _f != nullptr || _ismem; }
   bool failed() const { return _err; }  // a read error (corrupt .gz), as opposed to the end of the file
   int peek() {
     if (_pos >= _len && !fill()) return -1;
@@ -57,7 +145,8 @@ class LineSource {
     }
   }
   void rewind() {
-    gzrewind(_f);
+    if (_f) gzrewind(_f);
+    _mpos = 0;
     _pos = _len = 0;
     _eof = false;
   }
@@ -65,6 +154,18 @@ class LineSource {
  private:
   bool fill() {
     if (_eof) return false;
+    if (_ismem) {
+      const size_t n = std::min(sizeof(_buf), _mem.size() - _mpos);
+      if (n == 0) {
+        _eof = true;
+        return false;
+      }
+      memcpy(_buf, _mem.data() + _mpos, n);
+      _mpos += n;
+      _pos = 0;
+      _len = n;
+      return true;
+    }
     int n = gzread(_f, _buf, sizeof(_buf));
     if (n <= 0) {
       if (n < 0) _err = true;  // a corrupt or truncated .gz is not the end of the reads
@@ -79,6 +180,9 @@ class LineSource {
   char _buf[1 << 16];
   size_t _pos, _len;
   bool _eof, _err;
+  std::vector<char> _mem;  // a .bz2 input, expanded
+  size_t _mpos;
+  bool _ismem;
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -145,14 +249,25 @@ struct ReadStore {
 static bool slurp(const std::string& path, std::vector<char>* out) {
   int fd = open(path.c_str(), O_RDONLY);
   if (fd < 0) return false;
-  unsigned char magic[2] = {0, 0};
-  ssize_t got = pread(fd, magic, 2, 0);
+  unsigned char magic[3] = {0, 0, 0};
+  ssize_t got = pread(fd, magic, 3, 0);
   struct stat st;
   if (fstat(fd, &st) != 0) {
     close(fd);
     return false;
   }
-  if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {  // gzip (Utils::ifstream, src/utils.cpp:50-90)
+  if (is_bz2(magic, got)) {  // bzip2 (Utils::ifstream, src/utils.cpp:91-126)
+    std::vector<char> raw((size_t)st.st_size);
+    size_t n = 0;
+    while (n < raw.size()) {
+      ssize_t k = read(fd, raw.data() + n, raw.size() - n);
+      if (k <= 0) break;
+      n += (size_t)k;
+    }
+    close(fd);
+    return n == raw.size() && bz2_expand(raw, out);
+  }
+  if (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) {  // gzip (Utils::ifstream, src/utils.cpp:50-90)
     close(fd);
     gzFile f = gzopen(path.c_str(), "rb");
     if (!f) return false;
@@ -508,14 +623,26 @@ static inline int torank(char c) {  // src/alphabet.h:19-39
 // base-6 keys), then comparison-sort the buckets in parallel.  The terminator is unique, so memcmp from offset KP
 // decides every pair.  Same total order as SA-IS by construction (plain suffix array, end of text smallest).  Returns
 // false (caller falls back to SA-IS) when a bucket is so large that long repeats would make it crawl.
-template <typename I>
+//
+// OWN_SENTINELS: the order of `siga index -a sais` (SAISBuilder, src/suffix_array_builder.cpp:31-172: suffixes compared as
+// strings up to the end of their read, ties by read index) -- every read's own '$', ordered by read index, instead of one
+// shared '$' with comparisons running on into the next read.  In the concatenated text that is: compare up to and including
+// the first '$', then by position.  Keys stop at the first '$' (what follows it counts as nothing) and are computed per
+// position instead of rolled.  Reads must be ACGT-only (the caller checks: the reference compares raw characters in one
+// phase and ranks in the other, which agree only on A, C, G, T).
+template <typename I, bool OWN_SENTINELS = false>
 static bool parallel_suffix_sort(const uint8_t* T, uint64_t n /* incl. terminator */, I* SA, unsigned threads) {
   const int KP = 9;
   uint64_t nb = 1;
   for (int i = 0; i < KP; ++i) nb *= 6;
   auto key_at = [&](uint64_t p) {
     uint64_t k = 0;
-    for (int i = 0; i < KP; ++i) k = k * 6 + (p + i < n ? T[p + i] : 0);
+    bool ended = false;
+    for (int i = 0; i < KP; ++i) {
+      const uint64_t c = (p + i < n && !ended) ? T[p + i] : 0;
+      k = k * 6 + c;
+      if (OWN_SENTINELS && c <= 1) ended = true;
+    }
     return k;
   };
   // counting passes: a modest number of threads (each holds a histogram of nb counters), rolling base-6 keys
@@ -532,7 +659,8 @@ static bool parallel_suffix_sort(const uint8_t* T, uint64_t n /* incl. terminato
     for (uint64_t p = b; p < e; ++p) {
       if (scatter) SA[start[k] + hist[t][k]++] = (I)p;
       else ++hist[t][k];
-      k = (k % top) * 6 + (p + KP < n ? T[p + KP] : 0);
+      if (OWN_SENTINELS) k = p + 1 < n ? key_at(p + 1) : 0;
+      else k = (k % top) * 6 + (p + KP < n ? T[p + KP] : 0);
     }
   };
   {
@@ -573,6 +701,19 @@ static bool parallel_suffix_sort(const uint8_t* T, uint64_t n /* incl. terminato
   std::atomic<uint64_t> next(0);
   auto less = [&](I a, I b) {
     uint64_t pa = (uint64_t)a + KP, pb = (uint64_t)b + KP;
+    if (OWN_SENTINELS) {
+      // same key: either both reads ended inside the first KP symbols (equal strings: the earlier read first), or neither
+      // did and the strings go on: compare up to and including the next '$' of the one that ends first
+      bool ended = false;
+      for (int i = 0; i < KP && !ended; ++i) ended = (uint64_t)a + i >= n || T[(uint64_t)a + i] <= 1;
+      if (ended) return a < b;
+      const uint8_t* ea = (const uint8_t*)memchr(T + pa, 1, n - pa);
+      const uint8_t* eb = (const uint8_t*)memchr(T + pb, 1, n - pb);
+      const uint64_t la = (ea ? (uint64_t)(ea - (T + pa)) : n - pa - 1) + 1, lb = (eb ? (uint64_t)(eb - (T + pb)) : n - pb - 1) + 1;
+      const int c = memcmp(T + pa, T + pb, std::min(la, lb));
+      if (c != 0) return c < 0;
+      return a < b;  // both end here ('$' against a base differs above): the earlier read first
+    }
     if (pa >= n || pb >= n) return a > b;  // the shorter suffix (later start) is smaller
     uint64_t la = n - pa, lb = n - pb;
     int c = memcmp(T + pa, T + pb, std::min(la, lb));
@@ -597,7 +738,7 @@ static bool parallel_suffix_sort(const uint8_t* T, uint64_t n /* incl. terminato
 
 template <typename I>
 static bool build_strand(const char* seqs, const uint64_t* offs, uint64_t nReads, bool reverse, StrandIndex* out,
-                         unsigned threads) {
+                         unsigned threads, bool own_sentinels = false) {
   uint64_t total = 0;
   for (uint64_t i = 0; i < nReads; ++i) total += (offs[i + 1] - offs[i]) + 1;
   // text over {terminator 0, $ 1, A 2, C 3, G 4, T 5}; one '$' after every read, unique terminator at the end
@@ -616,7 +757,10 @@ static bool build_strand(const char* seqs, const uint64_t* offs, uint64_t nReads
   }
   T[p] = 0;
   std::vector<I> SA(total + 1);
-  if (threads < 2 || total < (1u << 20) || !parallel_suffix_sort<I>(T.data(), total + 1, SA.data(), threads))
+  if (own_sentinels) {
+    // `-a sais`: the bucket sort with the reads' own sentinels; the terminator's row comes out first (key 0) like the others'
+    if (!parallel_suffix_sort<I, true>(T.data(), total + 1, SA.data(), std::max(threads, 1u))) return false;
+  } else if (threads < 2 || total < (1u << 20) || !parallel_suffix_sort<I>(T.data(), total + 1, SA.data(), threads))
     sais<uint8_t, I>(T.data(), SA.data(), (I)(total + 1), (I)6);
   out->runs.clear();
   out->sai.clear();
@@ -650,7 +794,7 @@ static bool build_strand(const char* seqs, const uint64_t* offs, uint64_t nReads
 }
 
 bool BuildStrandIndex(const char* seqs, const uint64_t* offs, uint64_t nReads, bool reverse, StrandIndex* out,
-                      std::string* error, unsigned threads) {
+                      std::string* error, unsigned threads, bool own_sentinels) {
   uint64_t total = 0;
   for (uint64_t i = 0; i < nReads; ++i) {
     if (offs[i + 1] < offs[i]) {
@@ -663,9 +807,19 @@ bool BuildStrandIndex(const char* seqs, const uint64_t* offs, uint64_t nReads, b
     if (error) *error = "too many reads for the .sai format";
     return false;
   }
+  if (own_sentinels) {
+    for (uint64_t k = offs[0]; k < offs[nReads]; ++k)
+      if (torank(seqs[k]) == 0) {
+        if (error) *error = "algorithm sais: reads with bases other than A, C, G, T are not supported";
+        return false;
+      }
+  }
   try {
-    if (total + 1 < 0x7FFFFFF0ull) return build_strand<int32_t>(seqs, offs, nReads, reverse, out, threads);
-    return build_strand<int64_t>(seqs, offs, nReads, reverse, out, threads);
+    bool ok;
+    if (total + 1 < 0x7FFFFFF0ull) ok = build_strand<int32_t>(seqs, offs, nReads, reverse, out, threads, own_sentinels);
+    else ok = build_strand<int64_t>(seqs, offs, nReads, reverse, out, threads, own_sentinels);
+    if (!ok && error) *error = "algorithm sais: input too repetitive for the bucket sort";
+    return ok;
   } catch (const std::bad_alloc&) {
     if (error) *error = "out of memory building the suffix array";
     return false;
@@ -1579,6 +1733,30 @@ int sigah_index_file_dev(const char* reads_path, const char* prefix, int device,
   int rc = sigah_index_build_dev(rs.seqs.data(), rs.offs.data(), rs.size(), prefix, device, threads, do_fwd, do_rev, err, errcap);
   pt.lap("suffix sort + index files");
   return rc;
+}
+
+// `siga index -a sais READS`: the SAISBuilder order (src/suffix_array_builder.cpp:31-172), host suffix sorter only
+int sigah_index_file_sais(const char* reads_path, const char* prefix, int threads, int do_fwd, int do_rev, char* err, uint64_t errcap) {
+  sigah::ReadStore rs;
+  if (!sigah::LoadReads(reads_path, &rs, sigah::host_threads((size_t)std::max(threads, 1)))) {
+    if (err && errcap) snprintf(err, errcap, "Failed to open input file %s", reads_path);
+    return -1;
+  }
+  const std::string p(prefix);
+  for (int rev = 0; rev < 2; ++rev) {
+    if ((rev == 0 && !do_fwd) || (rev == 1 && !do_rev)) continue;
+    sigah::StrandIndex ix;
+    std::string e;
+    if (!sigah::BuildStrandIndex(rs.seqs.data(), rs.offs.data(), rs.size(), rev != 0, &ix, &e, (unsigned)std::max(threads, 1), true)) {
+      if (err && errcap) snprintf(err, errcap, "%s", e.c_str());
+      return -1;
+    }
+    if (!(ix.writeSAI(p + (rev ? ".rsai" : ".sai")) && ix.writeBWT(p + (rev ? ".rbwt" : ".bwt")))) {
+      if (err && errcap) snprintf(err, errcap, "cannot write index files with prefix %s", p.c_str());
+      return -1;
+    }
+  }
+  return 0;
 }
 
 // `siga index READS`

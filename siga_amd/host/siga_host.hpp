@@ -58,8 +58,10 @@ struct StrandIndex {
 
 // SuffixArrayBuilder "sais2" + BWT(sa, reads) (src/suffix_array_builder.cpp:472-674, src/bwt.cpp:7-32)
 // threads >= 2 selects a multi-threaded bucket sort (same suffix order), 1 the SA-IS
+// own_sentinels: the suffix order of `siga index -a sais` (every read's own '$', ordered by read index) instead of the
+// default "sais2" order (one shared '$', comparisons running on into the next read); host only, ACGT-only reads
 bool BuildStrandIndex(const char* seqs, const uint64_t* offs, uint64_t nReads, bool reverse, StrandIndex* out,
-                      std::string* error, unsigned threads = 1);
+                      std::string* error, unsigned threads = 1, bool own_sentinels = false);
 
 // the same on the GPU (sigax_build_strand); *rc = the library's code (SIGAX_E_CAPACITY: use BuildStrandIndex)
 bool BuildStrandIndexGPU(const char* seqs, const uint64_t* offs, uint64_t nReads, bool reverse, int device, StrandIndex* out,

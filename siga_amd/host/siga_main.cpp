@@ -6,6 +6,7 @@
 
 #include <chrono>
 #include <thread>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,6 +15,7 @@
 #include "siga_host.hpp"
 
 extern "C" int sigah_index_file_dev(const char*, const char*, int, int, int, int, char*, uint64_t);
+extern "C" int sigah_index_file_sais(const char*, const char*, int, int, int, char*, uint64_t);
 
 static int usage() {
   printf("siga [index|correct|overlap|rmdup] [OPTION] ... READSFILE\n"
@@ -28,7 +30,9 @@ static int index_help() {
          "\n"
          "      -h, --help                       display this help and exit\n"
          "\n"
-         "      -a, --algorithm=STR              BWT construction algorithm. Only sais2 (the reference default) is built\n"
+         "      -a, --algorithm=STR              BWT construction algorithm. STR can be:\n"
+         "                                       sais - induced sort algorithm's suffix order (host sorter, ACGT-only reads)\n"
+         "                                       sais2 - very fast and works for very long sequences (default; GPU sorter)\n"
          "      -t, --threads=NUM                use NUM threads to construct the index (default: 1)\n"
          "      -p, --prefix=PREFIX              write index to file using PREFIX instead of prefix of READSFILE\n"
          "          --no-reverse                 suppress construction of the reverse BWT\n"
@@ -85,6 +89,16 @@ static int run_index(int argc, char** argv) {
   if (help || argc - optind != 1) return index_help();
   std::string input = argv[optind];
   if (prefix.empty()) prefix = sigah::Utils::stem(input);
+  // src/suffix_array_builder.cpp:684-692: "sais" and "sais2" (case-insensitive); anything else fails to create a builder
+  for (char& ch : algorithm) ch = (char)tolower((unsigned char)ch);
+  if (algorithm == "sais") {  // SAISBuilder's order (every read's own sentinel, by read index): the host sorter only
+    char err[512] = "";
+    if (sigah_index_file_sais(input.c_str(), prefix.c_str(), threads, nofwd ? 0 : 1, norev ? 0 : 1, err, sizeof(err)) != 0) {
+      fprintf(stderr, "%s\n", err);
+      return -1;
+    }
+    return 0;
+  }
   if (algorithm != "sais2") {
     fprintf(stderr, "Failed to create suffix array builder algorithm %s\n", algorithm.c_str());
     return -1;

@@ -196,3 +196,66 @@ def test_gzip_writer_bytes_do_not_depend_on_the_call_pattern(tmp_path):
         outs.append(open(p, "rb").read())
         assert gzip.decompress(outs[-1]) == data
     assert outs[0] == outs[1] == outs[2]
+
+
+def test_index_algorithm_sais_gives_the_own_sentinel_order(tmp_path):
+    """`siga index -a sais` = SAISBuilder (src/suffix_array_builder.cpp:31-172): suffixes compared as strings up to the end of
+    their read (mkqs over the characters), ties by read index (SuffixIndexCmp, :194-199) -- every read's own sentinel, ordered
+    by read index -- NOT the default "sais2" order.  The host sorter's files equal a Python restatement of that order (RL units
+    with the 31-cap, .sai ids) on read sets with duplicates, substrings and mixed lengths; the CLI takes the option."""
+    import subprocess
+    import numpy as np
+    from siga_amd import host
+    from tests.fixtures import fixture
+    from tests.test_gpu_index_build import _index_with_sentinels_ordered_by_read
+    for name in ("dup", "tiny", "toy", "corner"):
+        fx = fixture(name)
+        prefix = str(tmp_path / name)
+        host.index_file_sais(fx.fa, prefix, threads=3)
+        for ext, rev in ((".bwt", False), (".rbwt", True)):
+            runs, sai, nsym = _index_with_sentinels_ordered_by_read(fx.seqs, reverse=rev)
+            raw = open(prefix + ext, "rb").read()
+            assert raw[:2] == b"\xca\xca" and int.from_bytes(raw[10:18], "little") == nsym
+            assert np.array_equal(np.frombuffer(raw[30:], dtype=np.uint8), runs), (name, ext)
+            ids = [int(l.split()[0]) for l in open(prefix + (".rsai" if rev else ".sai")).read().split("\n")[3:] if l]
+            assert ids == sai.tolist(), (name, ext)
+        if name == "dup":  # differs from the order of record where reads repeat
+            assert open(prefix + ".bwt", "rb").read() != open(fx.prefix + ".bwt", "rb").read()
+    fx = fixture("tiny")
+    cwd = str(tmp_path)
+    assert subprocess.run([host.CLI_PATH, "index", "-a", "SAIS", "-t", "2", "-p", "cli", fx.fa], cwd=cwd).returncode == 0
+    assert open(os.path.join(cwd, "cli.bwt"), "rb").read() == open(str(tmp_path / "tiny") + ".bwt", "rb").read()
+    assert subprocess.run([host.CLI_PATH, "index", "-a", "ropebwt", fx.fa], cwd=cwd, capture_output=True).returncode == 255
+    # reads with other bases are refused for this algorithm
+    bad = os.path.join(cwd, "n.fa")
+    open(bad, "w").write(">a\nACGTNACGT\n>b\nACGTT\n")
+    assert subprocess.run([host.CLI_PATH, "index", "-a", "sais", bad], cwd=cwd, capture_output=True).returncode == 255
+
+
+def test_bzip2_input_reads_like_plain_text(tmp_path):
+    """Utils::ifstream opens ".bz2" through a bzip2 filter (src/utils.cpp:91-126): the parallel loader and the record-at-a-time
+    reader give the same records from reads.fa.bz2 (one stream, and two concatenated streams) as from reads.fa; a truncated
+    file fails to load instead of reading as a shorter set; `siga index` takes the file and names its outputs by the stem
+    (src/utils.cpp:128-135)."""
+    import bz2
+    fx = fixture("tiny")
+    text = open(fx.fa, "rb").read()
+    cut = text.index(b">", len(text) // 2)
+    variants = {"one.fa.bz2": bz2.compress(text), "two.fa.bz2": bz2.compress(text[:cut]) + bz2.compress(text[cut:])}
+    plain = str(tmp_path / "plain.txt")
+    n = host.parse_file(fx.fa, plain)
+    assert n == len(fx.reads)
+    for name, data in variants.items():
+        p = str(tmp_path / name)
+        open(p, "wb").write(data)
+        for parallel in (True, False):
+            out = str(tmp_path / (name + (".par" if parallel else ".ser")))
+            assert host.parse_file(p, out, parallel=parallel) == n
+            assert open(out, "rb").read() == open(plain, "rb").read()
+    bad = str(tmp_path / "bad.fa.bz2")
+    open(bad, "wb").write(variants["one.fa.bz2"][:-20])
+    assert host.parse_file(bad, str(tmp_path / "bad.out")) < 0
+    cwd = str(tmp_path)
+    assert subprocess.run([host.CLI_PATH, "index", "--cpu", "-t", "2", "one.fa.bz2"], cwd=cwd).returncode == 0
+    for ext in (".bwt", ".rbwt", ".sai", ".rsai"):
+        assert open(os.path.join(cwd, "one" + ext), "rb").read() == open(fx.prefix + ext, "rb").read(), ext
