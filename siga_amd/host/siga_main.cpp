@@ -11,11 +11,69 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "siga_host.hpp"
 
 extern "C" int sigah_index_file_dev(const char*, const char*, int, int, int, int, char*, uint64_t);
 extern "C" int sigah_index_file_sais(const char*, const char*, int, int, int, char*, uint64_t);
+
+// -s, --ini=FILE (src/main.cpp:62-77): boost::property_tree::read_ini fills the option tree, then the command line's options
+// are put over it.  Here: the file's top-level `key=value` lines (`;` comments; keys under a [section] have dotted names no
+// option carries) become "--key=value" / "--key" arguments in front of the command line's own, for the keys this
+// sub-command's option table knows, so that what the command line says wins.  Returns 1 (the reference's exit status) when
+// the file cannot be read or a line has no '='.
+static int apply_ini(int argc, char** argv, const option* longopts, std::vector<std::string>* store, std::vector<char*>* out) {
+  std::string path;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    if (a == "--") break;
+    if ((a == "-s" || a == "--ini") && i + 1 < argc) path = argv[i + 1];
+    else if (a.compare(0, 6, "--ini=") == 0) path = a.substr(6);
+    else if (a.size() > 2 && a[0] == '-' && a[1] == 's') path = a.substr(2);
+  }
+  out->assign(argv, argv + argc);
+  if (path.empty()) return 0;
+  FILE* f = fopen(path.c_str(), "r");
+  if (!f) {
+    fprintf(stderr, "load %s failed(cannot open file).\n", path.c_str());
+    return 1;
+  }
+  auto trim = [](std::string x) {
+    const char* ws = " \t\r\n";
+    const size_t b = x.find_first_not_of(ws);
+    if (b == std::string::npos) return std::string();
+    return x.substr(b, x.find_last_not_of(ws) - b + 1);
+  };
+  char line[4096];
+  bool in_section = false;
+  int rc = 0;
+  while (fgets(line, sizeof(line), f)) {
+    const std::string l = trim(line);
+    if (l.empty() || l[0] == ';') continue;
+    if (l[0] == '[') {
+      in_section = true;
+      continue;
+    }
+    const size_t eq = l.find('=');
+    if (eq == std::string::npos) {
+      fprintf(stderr, "load %s failed('=' character not found in line).\n", path.c_str());
+      rc = 1;
+      break;
+    }
+    if (in_section) continue;
+    const std::string key = trim(l.substr(0, eq)), val = trim(l.substr(eq + 1));
+    for (const option* o = longopts; o->name; ++o)
+      if (key == o->name && key != "ini") store->push_back(o->has_arg == no_argument ? "--" + key : "--" + key + "=" + val);
+  }
+  fclose(f);
+  if (rc) return rc;
+  out->clear();
+  out->push_back(argv[0]);
+  for (std::string& x : *store) out->push_back(&x[0]);
+  for (int i = 1; i < argc; ++i) out->push_back(argv[i]);
+  return 0;
+}
 
 static int usage() {
   printf("siga [index|correct|overlap|rmdup] [OPTION] ... READSFILE\n"
@@ -73,6 +131,11 @@ static int run_index(int argc, char** argv) {
   std::string prefix, algorithm = "sais2";
   int threads = 1, c, device = 0;
   bool help = false, nofwd = false, norev = false, cpu = false;
+  std::vector<std::string> ini_store;
+  std::vector<char*> ini_argv;
+  if (apply_ini(argc, argv, longopts, &ini_store, &ini_argv) != 0) return 1;
+  argc = (int)ini_argv.size();
+  argv = ini_argv.data();
   while ((c = getopt_long(argc, argv, "c:s:a:t:p:h", longopts, nullptr)) != -1) {
     switch (c) {
       case 'p': prefix = optarg; break;
@@ -128,6 +191,11 @@ static int run_overlap(int argc, char** argv) {
   size_t threads = 1, batch = 10000, minOverlap = 10;  // code defaults of src/overlap.cpp:44
   bool exhaustive = false, norc = false, help = false;
   int device = 0, gpus = 1, c;
+  std::vector<std::string> ini_store;
+  std::vector<char*> ini_argv;
+  if (apply_ini(argc, argv, longopts, &ini_store, &ini_argv) != 0) return 1;
+  argc = (int)ini_argv.size();
+  argv = ini_argv.data();
   while ((c = getopt_long(argc, argv, "c:s:t:p:m:xh", longopts, nullptr)) != -1) {
     switch (c) {
       case 'p': prefix = optarg; break;
@@ -194,6 +262,11 @@ static int run_rmdup(int argc, char** argv) {
   size_t threads = 1;
   bool help = false;
   int device = 0, c;
+  std::vector<std::string> ini_store;
+  std::vector<char*> ini_argv;
+  if (apply_ini(argc, argv, longopts, &ini_store, &ini_argv) != 0) return 1;
+  argc = (int)ini_argv.size();
+  argv = ini_argv.data();
   while ((c = getopt_long(argc, argv, "c:s:t:p:d:h", longopts, nullptr)) != -1) {
     switch (c) {
       case 'p': prefix = optarg; break;
@@ -254,6 +327,11 @@ static int run_correct(int argc, char** argv) {
   size_t threads = 1;
   bool help = false;
   int device = 0, c;
+  std::vector<std::string> ini_store;
+  std::vector<char*> ini_argv;
+  if (apply_ini(argc, argv, longopts, &ini_store, &ini_argv) != 0) return 1;
+  argc = (int)ini_argv.size();
+  argv = ini_argv.data();
   while ((c = getopt_long(argc, argv, "c:s:p:o:t:a:k:x:i:O:h", longopts, nullptr)) != -1) {
     switch (c) {
       case 'p': prefix = optarg; break;

@@ -259,3 +259,22 @@ def test_bzip2_input_reads_like_plain_text(tmp_path):
     assert subprocess.run([host.CLI_PATH, "index", "--cpu", "-t", "2", "one.fa.bz2"], cwd=cwd).returncode == 0
     for ext in (".bwt", ".rbwt", ".sai", ".rsai"):
         assert open(os.path.join(cwd, "one" + ext), "rb").read() == open(fx.prefix + ext, "rb").read(), ext
+
+
+def test_ini_file_sets_options_the_command_line_overrides(tmp_path):
+    """-s/--ini=FILE (src/main.cpp:62-77): the file's key=value lines fill the option tree, the command line's options go over
+    it.  `siga index --ini` with prefix / algorithm / threads in the file names its outputs by the file's prefix unless -p says
+    otherwise; a file that cannot be read, or a line without '=', ends the run with status 1 before anything is written."""
+    fx = fixture("tiny")
+    cwd = str(tmp_path)
+    ini = os.path.join(cwd, "siga.ini")
+    open(ini, "w").write("; defaults of this project\nprefix = fromini\nalgorithm=sais\nthreads=2\nno-reverse=\n[other]\nprefix=ignored\n")
+    assert subprocess.run([host.CLI_PATH, "index", "--cpu", "--ini", ini, fx.fa], cwd=cwd).returncode == 0
+    assert os.path.exists(os.path.join(cwd, "fromini.bwt")) and not os.path.exists(os.path.join(cwd, "fromini.rbwt"))
+    assert subprocess.run([host.CLI_PATH, "index", "--cpu", "-s", ini, "-a", "sais2", "-p", "cli", fx.fa], cwd=cwd).returncode == 0
+    assert open(os.path.join(cwd, "cli.bwt"), "rb").read() == open(fx.prefix + ".bwt", "rb").read()  # -a sais2 won over the file
+    assert subprocess.run([host.CLI_PATH, "index", "--cpu", "--ini=" + os.path.join(cwd, "missing.ini"), fx.fa], cwd=cwd,
+                          capture_output=True).returncode == 1
+    bad = os.path.join(cwd, "bad.ini")
+    open(bad, "w").write("prefix x\n")
+    assert subprocess.run([host.CLI_PATH, "index", "--cpu", "-s", bad, fx.fa], cwd=cwd, capture_output=True).returncode == 1
