@@ -20,6 +20,14 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
+// Non-temporal hints on data that passes through once -- the finder's candidate records on their way out (bit 2), the
+// records on their way into filter/extract (4), the row-table line a block looks up (1): they leave more of the caches to
+// the finder's tables.  Measured at BASELINE configs[1] (gpurun_out/r3w/): 118.6 M reads/s without, 119.4-120.5 M with one
+// of them, 121.0 M with all three; nothing at the configs[2] shape.  -DSIGAX_NT=0 turns them off.
+#ifndef SIGAX_NT
+#define SIGAX_NT 7
+#endif
+
 // -------------------------------------------------------------------------------------------------------
 // rank: number of A,C,G,T in BWT[0, p)   == FMIndex::getOcc(p - 1) without the '$' column
 // -------------------------------------------------------------------------------------------------------
@@ -66,7 +74,13 @@ __device__ __forceinline__ Cand<WIDE> cand_load(const Cand<WIDE>* src);
 template <>
 __device__ __forceinline__ Cand<false> cand_load<false>(const Cand<false>* src) {
   const uint4* q = reinterpret_cast<const uint4*>(src);
+#if (SIGAX_NT & 4)
+  typedef u32 nt4 __attribute__((ext_vector_type(4)));
+  const nt4 na = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(q)), nb = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(q) + 1);
+  uint4 a = make_uint4(na.x, na.y, na.z, na.w), b = make_uint4(nb.x, nb.y, nb.z, nb.w);
+#else
   uint4 a = q[0], b = q[1];
+#endif
   Cand<false> c;
   c.c0lo = a.x; c.d = a.y; c.c1lo = a.z; c.r0lo = a.w; c.r1lo = b.x; c.sz = b.y; c.len = b.z; c.af = b.w;
   return c;
@@ -396,7 +410,14 @@ __device__ __forceinline__ void packed_or(unsigned char* tab, u64 p, u32 bits, u
 __device__ __forceinline__ u64 packed_get(const unsigned char* tab, u64 p, u32 bits) {
   const u64 B = p * bits;
   u64 v;
+#if (SIGAX_NT & 1)
+  {  // the row-table line is used once
+    typedef u64 __attribute__((aligned(1))) u64u;
+    v = __builtin_nontemporal_load(reinterpret_cast<const u64u*>(tab + (B >> 3)));
+  }
+#else
   __builtin_memcpy(&v, tab + (B >> 3), 8);  // one unaligned 8-byte load (the table is padded by 8 bytes)
+#endif
   return (v >> ((u32)B & 7u)) & ((1ull << bits) - 1ull);
 }
 // (stretch, offset) of the suffix at `row` of a strand that has the row table; returns the entry's symbols (fm_layout.h)
@@ -810,7 +831,16 @@ __device__ __forceinline__ void find_flush(SG& sg, bool want, u32 tid) {
       const u64 tag = sg.tag(src);
       if (piece <= (u32)(tag & 3u)) {
         const uint4 v = sg.row(src)[piece];
+#if (SIGAX_NT & 2)
+        {
+          typedef u32 nt4 __attribute__((ext_vector_type(4)));
+          nt4 w;
+          w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+          __builtin_nontemporal_store(w, reinterpret_cast<nt4*>((tag & ~(u64)3) + piece * 16u));
+        }
+#else
         *reinterpret_cast<uint4*>((tag & ~(u64)3) + piece * 16u) = v;
+#endif
       }
       qm &= qm - 1u;
     }
