@@ -1915,8 +1915,9 @@ __device__ __forceinline__ void fm_rank5p(const FmRef& s, typename PosOf<WIDE>::
 // across lines, the exhaustive output order) is queued for the 64-lane launch, which has everything.  Without the rarely
 // taken code the kernel needs no scratch (124 VGPRs, was 128 + 17 spilled) and runs 1.2-1.4x faster.
 // LEANP = 2: the same for indexes without two-step tables: only the one-granule rounds.
-// LEANP = 5 / 6: strict / branching, with the rounds read off the look-ahead table (fm_layout.h) instead of computed from
-// rank lines: one 8-byte lookup per block and ten rounds; items with a block of more than one row go on to the full launch.
+// LEANP = 5 / 6: strict / branching, with the rounds read off the block's read text (row table or direct map + stretch text,
+// fm_layout.h) instead of computed from rank lines: one lookup per block, then a text window per 28 rounds; items with a
+// block of more than one row go on to the full launch.
 // LEANP = 3 / 4: LEANP 1 / 2 plus branches of single-row blocks (branch_inreg) and the group ring of extract(): what reads
 // with substitutions need.  The strict forms run first because the extra state costs them 17 VGPRs (89 -> 106) and, beside
 // the finder, 9 % of the error-free step; they hand a branching item to the next launch, which has these forms.
@@ -1926,7 +1927,7 @@ struct GFx {
   static constexpr bool LEAN = LEANP != 0;
   static constexpr bool BR = LEANP == 0 || LEANP == 3 || LEANP == 4 || LEANP == 6;  // follows in-register branches
   static constexpr bool TWO_ONLY = LEANP == 1 || LEANP == 3, ONE_ONLY = LEANP == 2 || LEANP == 4;
-  static constexpr bool TEXT = LEANP == 5 || LEANP == 6;  // rounds from the look-ahead table only (single-row blocks)
+  static constexpr bool TEXT = LEANP == 5 || LEANP == 6;  // rounds from the reads' text only (single-row blocks)
   struct E {  // a block's capped pair in registers
     P c0lo, c0hi, c1lo, c1hi;
     u32 src;  // bits 30-31: which find produced it (0..3); bits 0-29: slot in the read's candidate region
@@ -2160,7 +2161,7 @@ struct GFx {
       ++ni;
     }
     // A group of ONE single-row block (the usual branch: an overlapping read with a substitution right of the overlap) has
-    // nothing left to decide: it follows its read to the end and is emitted there.  The row-end table says after how many
+    // nothing left to decide: it follows its read to the end and is emitted there.  The row table says after how many
     // rounds and with which final range; from here on the group is a countdown (extract()), not a walk of ~100 lookups.
     if (inreg && lonely) to_countdown(e);
     return RD_BRANCHED;
@@ -2469,9 +2470,9 @@ struct GFx {
     return RD_UPDATED;
   }
 
-  // One extension round of a group of single-row blocks from the look-ahead table: the symbol that follows a block is the
+  // One extension round of a group of single-row blocks from the reads' text: the symbol that follows a block is the
   // next one on its path, the update is a step along it (nothing to compute: capped[0] keeps still, capped[1] is only
-  // needed at the end, where it is the row-end table's Occ('$')).  Same cases and return codes as round_fast().
+  // needed at the end, where it is the stretch's rank among the '$' rows).  Same cases and return codes as round_fast().
   __device__ int round_text(E& e, u64 alive, u64* newAlive) {
     const u32 OUTCAP = kOutCap;
     const u32 NSLOT = kNSlot;
