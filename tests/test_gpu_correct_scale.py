@@ -1,6 +1,6 @@
-"""BASELINE configs[3] (`siga correct`, k-mer path) beyond fixture size: 100 k reads of 150 bp at 30x with 1 % substitutions
+"""BASELINE configs[3] (`siga correct`, k-mer path) beyond fixture size: 60 k reads of 150 bp at 30x with 1 % substitutions
 through the host CorrectProcessor (GPU kernel k_correct) against the oracle's restatement (one thread, 2.5 k reads/s: the
-sizes are what keeps this test under a minute), k = 31 (code default) and k = 41 (example script, 40 k reads): output
+sizes are what keeps this test at half a minute), k = 31 (code default) and k = 41 (example script, 20 k reads): output
 files byte for byte."""
 import numpy as np
 import pytest
@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("k,N", [(31, 100000), (41, 40000)])
+@pytest.mark.parametrize("k,N", [(31, 60000), (41, 20000)])
 def test_correct_at_scale_matches_oracle(k, N, tmp_path):
     from oracle import pyoracle as po
     from siga_amd import host
