@@ -182,27 +182,93 @@ static int parse_bwt(const std::vector<uint8_t>& buf, const char* path, u64* nst
   return SIGAX_OK;
 }
 
-// src/suffix_array.cpp:57-95: "51914\n<strings>\n<elems>\n" then elems lines "<readIdx> <j>"
+// src/suffix_array.cpp:57-95: "51914\n<strings>\n<elems>\n" then elems lines "<readIdx> <j>".  Tables of a million rows and
+// more are parsed in chunks on the host's threads (BASELINE configs[2]: 2 x 20 M lines were 3 of the 3.9 s of `siga overlap`'s
+// index load): chunks cut at line ends, lines counted, then every chunk parsed to its place.
 static int parse_sai(const std::vector<uint8_t>& buf, const char* path, std::vector<uint32_t>* out) {
   const char* p = (const char*)buf.data();
   const char* e = p + buf.size();
-  auto next = [&](u64* v) -> bool {
-    while (p < e && (*p < '0' || *p > '9')) ++p;
-    if (p >= e) return false;
+  auto next = [&](const char*& q, const char* end, u64* v) -> bool {
+    while (q < end && (*q < '0' || *q > '9')) ++q;
+    if (q >= end) return false;
     u64 x = 0;
-    while (p < e && *p >= '0' && *p <= '9') x = x * 10 + (u64)(*p++ - '0');
+    while (q < end && *q >= '0' && *q <= '9') x = x * 10 + (u64)(*q++ - '0');
     *v = x;
     return true;
   };
   u64 magic = 0, strings = 0, elems = 0;
-  if (!next(&magic) || magic != 0xCACA) return fail(SIGAX_E_IO, "%s: bad .sai magic", path);
-  if (!next(&strings) || !next(&elems)) return fail(SIGAX_E_IO, "%s: truncated .sai header", path);
+  if (!next(p, e, &magic) || magic != 0xCACA) return fail(SIGAX_E_IO, "%s: bad .sai magic", path);
+  if (!next(p, e, &strings) || !next(p, e, &elems)) return fail(SIGAX_E_IO, "%s: truncated .sai header", path);
+  if (elems > (u64)(e - p)) return fail(SIGAX_E_IO, "%s: truncated .sai body", path);  // every line takes bytes
   out->resize(elems);
-  for (u64 i = 0; i < elems; ++i) {
-    u64 a, b;
-    if (!next(&a) || !next(&b)) return fail(SIGAX_E_IO, "%s: truncated .sai body", path);
-    if (a >= strings) return fail(SIGAX_E_IO, "%s: read id %llu at row %llu, the table declares %llu strings", path, a, i, strings);
-    (*out)[i] = (uint32_t)a;
+  // one chunk, or as many as there are threads: [cut[k], cut[k+1]) starts right after a line end
+  unsigned nt = elems >= (1u << 18) ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
+  if (p < e && *p == '\n') ++p;  // the header's own line end
+  std::vector<const char*> cut(nt + 1, e);
+  cut[0] = p;
+  for (unsigned k = 1; k < nt; ++k) {
+    const char* q = p + (u64)(e - p) * k / nt;
+    q = (const char*)memchr(q, '\n', (size_t)(e - q));
+    cut[k] = q ? q + 1 : e;
+    if (cut[k] < cut[k - 1]) cut[k] = cut[k - 1];
+  }
+  std::vector<u64> lines(nt + 1, 0);
+  auto count = [&](unsigned k) {
+    u64 c = 0;
+    for (const char* q = cut[k]; q < cut[k + 1];) {  // a line = something up to '\n' (or the end) holding a digit
+      const char* nl = (const char*)memchr(q, '\n', (size_t)(cut[k + 1] - q));
+      const char* le = nl ? nl : cut[k + 1];
+      bool digit = false;
+      for (const char* t = q; t < le && !digit; ++t) digit = *t >= '0' && *t <= '9';
+      c += digit ? 1 : 0;
+      q = le + 1;
+    }
+    lines[k + 1] = c;
+  };
+  std::vector<int> bad(nt, 0);
+  std::vector<u64> badrow(nt, 0), badid(nt, 0);
+  auto parse = [&](unsigned k) {
+    const char* q = cut[k];
+    for (u64 i = lines[k]; i < lines[k + 1] && i < elems; ++i) {
+      u64 a = 0, b2 = 0;
+      if (!next(q, cut[k + 1], &a) || !next(q, cut[k + 1], &b2)) { bad[k] = 1; badrow[k] = i; return; }
+      if (a >= strings) { bad[k] = 2; badrow[k] = i; badid[k] = a; return; }
+      (*out)[i] = (uint32_t)a;
+    }
+    // one pair per line is what `siga index` writes; a chunk with numbers left over is some other layout: parse serially
+    u64 extra = 0;
+    if (nt > 1 && !bad[k] && next(q, cut[k + 1], &extra)) bad[k] = 3;
+  };
+  auto run = [&](auto fn) {
+    std::vector<std::thread> th;
+    for (unsigned k = 1; k < nt; ++k) th.emplace_back(fn, k);
+    fn(0u);
+    for (auto& t : th) t.join();
+  };
+  for (;;) {
+    if (nt > 1) {
+      run(count);
+      for (unsigned k = 0; k < nt; ++k) lines[k + 1] += lines[k];
+    } else {
+      lines[1] = elems;  // one chunk: the token stream as it comes, whatever the line layout
+    }
+    bool irregular = nt > 1 && lines[nt] != elems;
+    if (!irregular) {
+      run(parse);
+      for (unsigned k = 0; k < nt; ++k) irregular = irregular || bad[k] == 3;
+    }
+    if (!irregular) break;
+    nt = 1;  // once more, serially
+    cut.assign(2, e);
+    cut[0] = p;
+    lines.assign(2, 0);
+    bad.assign(1, 0);
+    badrow.assign(1, 0);
+    badid.assign(1, 0);
+  }
+  for (unsigned k = 0; k < nt; ++k) {
+    if (bad[k] == 1) return fail(SIGAX_E_IO, "%s: truncated .sai body", path);
+    if (bad[k] == 2) return fail(SIGAX_E_IO, "%s: read id %llu at row %llu, the table declares %llu strings", path, badid[k], badrow[k], strings);
   }
   return SIGAX_OK;
 }

@@ -278,3 +278,44 @@ def test_ini_file_sets_options_the_command_line_overrides(tmp_path):
     bad = os.path.join(cwd, "bad.ini")
     open(bad, "w").write("prefix x\n")
     assert subprocess.run([host.CLI_PATH, "index", "--cpu", "-s", bad, fx.fa], cwd=cwd, capture_output=True).returncode == 1
+
+
+def test_sai_tables_parse_in_chunks_like_they_do_serially(tmp_path):
+    """SuffixArray's text format (src/suffix_array.cpp:57-95: magic, strings, elems, then "<read> <j>" lines) is read before any
+    device is touched.  Tables of 2^18 rows and more are parsed in chunks on the host's threads: a good table gets as far as the
+    size check against the .bwt (which names both tables' row counts), a bad read id is reported with ITS row whichever chunk
+    holds it, a cut-off body is refused, and a layout other than one pair per line is still read (serially)."""
+    fx = fixture("tiny")
+    n = 300_000
+    rng = np.random.default_rng(5)
+    ids = rng.permutation(n)
+
+    def table(rows, elems=None, per_line=1):
+        pairs = ["%d 0" % r for r in rows]
+        body = "\n".join(" ".join(pairs[i:i + per_line]) for i in range(0, len(pairs), per_line))
+        return "51914\n%d\n%d\n%s\n" % (n, len(rows) if elems is None else elems, body)
+
+    def open_with(text, rtext=None):
+        sai, rsai = str(tmp_path / "t.sai"), str(tmp_path / "t.rsai")
+        open(sai, "w").write(text)
+        open(rsai, "w").write(text if rtext is None else rtext)
+        h = C.c_void_p()
+        rc = _lib.lib().sigax_index_open((fx.prefix + ".bwt").encode(), (fx.prefix + ".rbwt").encode(), sai.encode(), rsai.encode(),
+                                         0, C.byref(h))
+        assert rc != 0 and not h.value
+        return rc, _lib.last_error()
+
+    good = table(ids)
+    rc, msg = open_with(good)
+    assert rc == -2 and "(%d, %d entries) do not match" % (n, n) in msg, msg  # SIGAX_E_IO from the size check: both parsed
+    rc, msg = open_with(table(ids, per_line=2))
+    assert rc == -2 and "(%d, %d entries) do not match" % (n, n) in msg, msg
+    for row in (7, n // 2 + 3, n - 2):  # first chunk, a middle one, the last
+        bad = ids.copy()
+        bad[row] = n + 11
+        rc, msg = open_with(table(bad))
+        assert rc == -2 and "read id %d at row %d" % (n + 11, row) in msg, msg
+        rc, msg = open_with(good, rtext=table(bad))  # the reverse table's error comes through from its thread
+        assert rc == -2 and "read id %d at row %d" % (n + 11, row) in msg, msg
+    rc, msg = open_with(table(ids[:n - 5], elems=n))
+    assert rc == -2 and "truncated .sai body" in msg, msg
