@@ -44,7 +44,7 @@ CXX = os.environ.get("CXX", "g++")
 def build_host(force=False, verbose=False):
     """libsiga_host.so (host C++ mirror of the reference classes over the C-ABI) and the `siga` CLI."""
     build_libsigax(force=force, verbose=verbose)
-    deps = [os.path.join(HOST, f) for f in ("siga_host.cpp", "siga_host.hpp", "sais.hpp", "siga_main.cpp")] + [LIB]
+    deps = [os.path.join(HOST, f) for f in ("siga_host.cpp", "siga_host.hpp", "sais.hpp", "line_deflate.hpp", "siga_main.cpp")] + [LIB]
     libdir = os.path.dirname(LIB)
     common = [CXX, "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-sign-compare", "-pthread"]
     link = ["-L" + libdir, "-lsigax", "-lz", "-ldl", "-Wl,-rpath,$ORIGIN"]

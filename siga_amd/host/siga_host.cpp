@@ -20,6 +20,7 @@
 #include <string_view>
 #include <thread>
 
+#include "line_deflate.hpp"
 #include "sais.hpp"
 
 namespace sigah {
@@ -980,8 +981,13 @@ class OutFile {
       std::vector<std::string> outs(nfull);
       std::vector<uLong> crcs(nfull, 0);
       parallel_for(nfull, _nt, [&](size_t i) {
+        const size_t off = i * kBlock, k = (size_t)(std::upper_bound(start.begin(), start.end(), off) - start.begin()) - 1;
+        if (off - start[k] + kBlock <= segs[k]->size()) {  // the block lies in one segment: no copy
+          deflate_block(segs[k]->data() + (off - start[k]), kBlock, false, &outs[i], &crcs[i]);
+          return;
+        }
         std::string tmp(kBlock, '\0');
-        gather(i * kBlock, kBlock, &tmp[0]);
+        gather(off, kBlock, &tmp[0]);
         deflate_block(tmp.data(), kBlock, false, &outs[i], &crcs[i]);
       });
       for (size_t i = 0; i < nfull; ++i) {
@@ -1020,22 +1026,42 @@ class OutFile {
 
  private:
   static const size_t kBlock = 1 << 20, kFlush = 64u << 20;
-  // Level 4 by default: on read text (four-letter sequences with little to match inside a 32 KiB window) zlib's level 6,
-  // what the reference's gzip filter uses, makes 10 MB/s per thread for a file 5 % smaller than level 4 at 62 MB/s; with
-  // the kernels done in milliseconds the deflate of the VT lines was the longest phase of `siga overlap`.
-  // SIGA_GZIP_LEVEL=6 restores the reference's setting.
-  static int gzip_level() {
-    static const int level = [] {
+  // On read text (four-letter sequences with little to match inside a 32 KiB window) zlib's level 6, what the
+  // reference's gzip filter uses, makes 10 MB/s per thread, level 4 62 MB/s for a file 5 % larger; with the kernels done
+  // in milliseconds the deflate of the VT lines was the longest phase of `siga overlap`.  Blocks that are mostly bases
+  // (VT lines, FASTA) go through the line coder of line_deflate.hpp: 670 MB/s per thread and 9 % SMALLER than level 6
+  // on VT lines; everything else (ED lines: numbers, where a real match finder pays) through zlib at level 4.  The
+  // choice depends on the block's bytes alone, so the file still does not depend on threads, batches or GPUs.
+  // SIGA_GZIP_LEVEL=<1..9> sends every block through zlib at that level (6 = the reference's setting).
+  static int gzip_level(bool* forced = nullptr) {
+    static const int env_level = [] {
       const char* env = getenv("SIGA_GZIP_LEVEL");
-      int l = env ? atoi(env) : 4;
-      return l < 1 || l > 9 ? 4 : l;
+      const int l = env ? atoi(env) : 0;
+      return l < 1 || l > 9 ? 0 : l;
     }();
-    return level;
+    if (forced) *forced = env_level != 0;
+    return env_level ? env_level : 4;
+  }
+  static bool mostly_bases(const char* in, size_t n) {  // every 13th byte looked at
+    size_t seen = 0, bases = 0;
+    for (size_t i = 0; i < n; i += 13, ++seen) {
+      const char c = in[i];
+      bases += c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N';
+    }
+    return seen >= 64 && 2 * bases >= seen;
   }
   static void deflate_block(const char* in, size_t n, bool last, std::string* out, uLong* crc) {
+    *crc = ldef::crc32_fast(0, (const unsigned char*)in, n,
+                            [](uint32_t c, const unsigned char* p, size_t k) { return (uint32_t)crc32(c, (const Bytef*)p, (uInt)k); });
+    bool forced = false;
+    const int level = gzip_level(&forced);
+    if (!forced && mostly_bases(in, n)) {
+      ldef::deflate_lines((const unsigned char*)in, n, last, out);
+      return;
+    }
     z_stream z;
     memset(&z, 0, sizeof(z));
-    deflateInit2(&z, gzip_level(), Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    deflateInit2(&z, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
     out->resize(deflateBound(&z, (uLong)n) + 16);
     z.next_in = (Bytef*)in;
     z.avail_in = (uInt)n;
@@ -1044,7 +1070,6 @@ class OutFile {
     deflate(&z, last ? Z_FINISH : Z_SYNC_FLUSH);
     out->resize(out->size() - z.avail_out);
     deflateEnd(&z);
-    *crc = crc32(crc32(0L, Z_NULL, 0), (const Bytef*)in, (uInt)n);
   }
   void put(const void* p, size_t n) {
     if (n && fwrite(p, 1, n, _f) != n) _bad = true;

@@ -319,3 +319,58 @@ def test_sai_tables_parse_in_chunks_like_they_do_serially(tmp_path):
         assert rc == -2 and "read id %d at row %d" % (n + 11, row) in msg, msg
     rc, msg = open_with(table(ids[:n - 5], elems=n))
     assert rc == -2 and "truncated .sai body" in msg, msg
+
+
+def test_line_coder_blocks_inflate_to_the_text(tmp_path):
+    """Blocks that are mostly bases go through the writer's own deflate coder (line_deflate.hpp: matches against the previous
+    line's same column, one dynamic Huffman code per block, CRC-32 by carry-less multiplication) instead of zlib.  Whatever
+    the text looks like -- VT lines with names that grow a digit, FASTA, lines longer than deflate's 32 KiB window, one
+    endless line, a single base repeated (one literal symbol), runs longer than the longest match, no line end at the end,
+    block edges inside a line -- gzip must give the text back, as ONE member, and the bytes must not depend on how the text
+    was handed over.  SIGA_GZIP_LEVEL=6 sends everything through zlib (the reference's setting) and reads back the same."""
+    import gzip
+    import zlib
+    rng = np.random.default_rng(11)
+
+    def bases(n):
+        return rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n).tobytes()
+
+    genome = bases(200_000)
+
+    def read(i, length=150):
+        p = (i * 7919) % (len(genome) - length)
+        return genome[p:p + length]
+
+    texts = {
+        "vt": b"".join(b"VT\tr%d\t%s\tSS:i:%d\n" % (i, read(i), i % 7 == 0) for i in range(9_990, 30_000)),
+        "vt_ragged": b"".join(b"VT\tread/%d\t%s\tSS:i:0\n" % (i, read(i, 30 + (i * 37) % 220)) for i in range(20_000)),
+        "fasta": b"".join(b">r%d some comment\n%s\n" % (i, read(i)) for i in range(20_000)),
+        "long_lines": b"".join(b">c%d\n%s\n" % (i, bases(40_000 + 1000 * i)) for i in range(12)),
+        "one_line": bases(1_500_000),
+        "same_base": b"A" * 2_200_000,
+        "same_line": (b"ACGTTGCAACGT" * 30 + b"\n") * 9_000 + b"ACGT",
+        "short": b"ACGTACGTAC\n" * 9,
+        "identical_reads": (b"VT\tx\t" + read(5) + b"\tSS:i:0\n") * 20_000,
+    }
+    for name, data in texts.items():
+        outs = []
+        for pieces in (1, 13):
+            path = str(tmp_path / ("%s_%d.gz" % (name, pieces)))
+            host.write_file(path, data, pieces)
+            raw = open(path, "rb").read()
+            d = zlib.decompressobj(16 + zlib.MAX_WBITS)
+            assert d.decompress(raw) == data and d.eof and d.unused_data == b"", name
+            outs.append(raw)
+        assert outs[0] == outs[1], name
+    # the coder is on: VT lines come out smaller than zlib's best makes them
+    vt = texts["vt"]
+    assert len(open(str(tmp_path / "vt_1.gz"), "rb").read()) < len(zlib.compress(vt, 9))
+    code = ("import sys; sys.path.insert(0, %r); from siga_amd import host; host.write_file(sys.argv[1], open(sys.argv[2], 'rb').read(), 3)"
+            % ROOT)
+    src = str(tmp_path / "vt.txt")
+    open(src, "wb").write(vt)
+    ref = str(tmp_path / "vt_level6.gz")
+    import sys
+    assert subprocess.run([sys.executable, "-c", code, ref, src], env=dict(os.environ, SIGA_GZIP_LEVEL="6")).returncode == 0
+    assert gzip.open(ref, "rb").read() == vt
+    assert len(open(ref, "rb").read()) > len(open(str(tmp_path / "vt_1.gz"), "rb").read())
