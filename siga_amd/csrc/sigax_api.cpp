@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -662,6 +663,18 @@ static void build_rowend(sigax_index* ix) {
   if (ix->n_symbols < (1ull << 26) || getenv("SIGAX_TABLES_SYNC") != nullptr) start_row_tables(ix, true);
 }
 
+// SIGAX_VERBOSE: where the time of opening an index goes
+struct OpenClock {
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  OpenClock() : on(getenv("SIGAX_VERBOSE") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void lap(const char* what) {
+    const auto n = std::chrono::steady_clock::now();
+    if (on) fprintf(stderr, "[sigax] open: %-34s %7.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+
 extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const uint8_t* rruns, uint64_t n_rruns,
                                     uint64_t n_symbols, uint64_t n_strings, const uint32_t* sai, const uint32_t* rsai,
                                     int device, sigax_index** out) {
@@ -672,6 +685,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
     return fail(SIGAX_E_DEVICE, "no HIP device visible: the overlap path has no CPU fallback");
   if (device < 0 || device >= ndev) return fail(SIGAX_E_ARG, "device %d out of range (%d visible)", device, ndev);
   HIP_TRY(hipSetDevice(device));
+  OpenClock clk;
   sigax_index* ix = new sigax_index();
   memset(ix, 0, sizeof(*ix));
   ix->device = device;
@@ -713,6 +727,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
       ix->st[s].total[k] = total[k];
     }
   }
+  clk.lap("streams, upload + decode");
   for (int k = 0; k < 5; ++k) {
     if (ix->st[0].total[k] != ix->st[1].total[k]) {
       sigax_index_close(ix);
@@ -780,6 +795,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
       }
     }
   }
+  clk.lap("two-step tables");
   // Start tables of the finder (fm_layout.h): from 2^22 symbols on (the 2 x 268 MB and 20 ms are out of proportion for
   // less; SIGAX_FIND_START=1 forces them, =0 turns them off), an accelerator like the others.
   {
@@ -806,6 +822,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
       }
     }
   }
+  clk.lap("start tables");
   if (sai && rsai) {
     const uint32_t* ss[2] = {sai, rsai};
     for (int s = 0; s < 2; ++s)  // k_edges indexes the read tables with these ids
@@ -824,7 +841,9 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
     }
     ix->n_sai = n_strings;
   }
+  clk.lap(".sai check + upload");
   build_rowend(ix);  // after the .sai tables: with them the extractor's tables are direct maps (fm_layout.h)
+  clk.lap("row tables (plan, start of build)");
   *out = ix;
   return SIGAX_OK;
 }
@@ -851,9 +870,12 @@ extern "C" int sigax_index_open(const char* bwt_path, const char* rbwt_path, con
     sides.push_back(side(2, [&] { return load_sai(sai_path, &sai); }));
     sides.push_back(side(3, [&] { return load_sai(rsai_path, &rsai); }));
   }
+  OpenClock clk;
   rcs[0] = read_file(bwt_path, &fb);
   if (rcs[0] != SIGAX_OK) errs[0] = g_err;
+  clk.lap(".bwt read");
   for (auto& t : sides) t.join();
+  clk.lap(".rbwt read, .sai tables parsed");
   for (int k = 0; k < 2; ++k)
     if (rcs[k] != SIGAX_OK) return fail(rcs[k], "%s", errs[k].c_str());
   int rc;

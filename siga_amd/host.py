@@ -107,6 +107,12 @@ def parse_file(path, out_path, parallel=True, threads=4):
     return lib().sigah_parse_file(path.encode(), 0 if parallel else 1, out_path.encode(), threads)
 
 
+def read_table(path, out_path, threads=4):
+    """the edge converter's read table as the host builds it: one "rank<TAB>length" line per read (name ranks under
+    std::string's order, equal names equal rank)"""
+    return lib().sigah_parse_file(path.encode(), 2, out_path.encode(), threads)
+
+
 def write_file(path, data, pieces=1):
     """The host library's output stream (multi-threaded single-member gzip when the name ends with .gz)."""
     if lib().sigah_write_file(path.encode(), data, len(data), pieces) != 0:

@@ -124,88 +124,119 @@ struct BitSink {
   }
 };
 
+// length 3..258 -> symbol 257..285 with its extra bits; distance 1..32768 -> symbol 0..29 (RFC 1951 3.2.5)
+struct LenCode { uint16_t sym; uint8_t extra_bits, extra; };
+inline const LenCode* length_table() {
+  static const LenCode* tab = [] {
+    static LenCode t[259];
+    static const uint16_t base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t eb[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    for (int len = 3; len <= 258; ++len) {
+      int s = 28;
+      while (base[s] > len) --s;
+      t[len] = {(uint16_t)(257 + s), eb[s], (uint8_t)(len - base[s])};
+    }
+    return t;
+  }();
+  return tab;
+}
 inline int length_symbol(int len, int* extra_bits, int* extra) {
-  static const uint16_t base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-  static const uint8_t eb[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-  int s = 28;
-  while (base[s] > len) --s;
-  *extra_bits = eb[s];
-  *extra = len - base[s];
-  return 257 + s;
+  const LenCode& c = length_table()[len];
+  *extra_bits = c.extra_bits;
+  *extra = c.extra;
+  return c.sym;
 }
 inline int dist_symbol(int dist, int* extra_bits, int* extra) {
-  static const uint16_t base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-  static const uint8_t eb[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-  int s = 29;
-  while (base[s] > dist) --s;
-  *extra_bits = eb[s];
-  *extra = dist - base[s];
-  return s;
+  const unsigned v = (unsigned)dist - 1;
+  if (v < 4) {
+    *extra_bits = 0;
+    *extra = 0;
+    return (int)v;
+  }
+  const int nb = 31 - __builtin_clz(v);  // v in [2^nb, 2^(nb+1)): two symbols per power of two
+  *extra_bits = nb - 1;
+  *extra = (int)(v & ((1u << (nb - 1)) - 1));
+  return 2 * nb + (int)((v >> (nb - 1)) & 1u);
 }
 
-// Matches against the previous line's same column: distance = length of the previous line, which changes at every line
-// end -- also at those a match runs over.  64 bytes of the line are compared with the 64 above them in four SSE2
-// compares; bit k of the result says "byte k equals", and runs of kMinMatch set bits are where matches start.
-inline uint64_t equal_mask64(const unsigned char* a, const unsigned char* b) {
-  uint64_t m = 0;
-  for (int k = 0; k < 4; ++k) {
-    const __m128i x = _mm_loadu_si128((const __m128i*)(a + 16 * k)), y = _mm_loadu_si128((const __m128i*)(b + 16 * k));
-    m |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, y)) << (16 * k);
+// Matches against the previous line, field by field.  A line is cut at its tabs and blanks; field j of a line is compared
+// with field j of the line above, from the separator on, and what is equal -- on into the following fields, over the line
+// end and into the next line, as far as it goes -- is one match.  Aligned columns (VT lines: tag and running name prefix,
+// the trailing tags) and columns that shift because a number before them grew a digit (ED lines: "... 149 150 0 ") are
+// found alike; the bases of a read are never searched, only compared once with the read above.  Separators and line
+// ends are located 16 bytes at a time (SSE2).
+static const int kMaxFields = 24;
+struct Fields {
+  uint32_t at[kMaxFields];  // at[0] = start of the line, at[k] = position of its k-th separator
+  int n;
+};
+// fields of the line that starts at `from`; returns the position of its line end (or n)
+inline size_t split_line(const unsigned char* in, size_t n, size_t from, Fields* f) {
+  f->at[0] = (uint32_t)from;
+  f->n = 1;
+  const __m128i nl = _mm_set1_epi8('\n'), tab = _mm_set1_epi8('\t'), blank = _mm_set1_epi8(' ');
+  size_t p = from;
+  for (; p + 16 <= n; p += 16) {
+    const __m128i x = _mm_loadu_si128((const __m128i*)(in + p));
+    const unsigned e = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(x, nl));
+    unsigned sep = (unsigned)_mm_movemask_epi8(_mm_or_si128(_mm_cmpeq_epi8(x, tab), _mm_cmpeq_epi8(x, blank)));
+    if (e) sep &= (e & (0u - e)) - 1;  // separators before the line end only
+    for (; sep && f->n < kMaxFields; sep &= sep - 1) f->at[f->n++] = (uint32_t)(p + (size_t)__builtin_ctz(sep));
+    if (e) return p + (size_t)__builtin_ctz(e);
   }
-  return m;
+  for (; p < n; ++p) {
+    if (in[p] == '\n') return p;
+    if ((in[p] == '\t' || in[p] == ' ') && f->n < kMaxFields) f->at[f->n++] = (uint32_t)p;
+  }
+  return n;
+}
+inline size_t common_run(const unsigned char* in, size_t n, size_t s, size_t src) {
+  size_t run = 0;
+  while (run < (size_t)kMaxMatch && s + run + 8 <= n) {
+    uint64_t x, y;
+    memcpy(&x, in + s + run, 8);
+    memcpy(&y, in + src + run, 8);
+    if (x != y) {
+      run += (size_t)(__builtin_ctzll(x ^ y) >> 3);
+      return std::min(run, (size_t)kMaxMatch);
+    }
+    run += 8;
+  }
+  while (run < (size_t)kMaxMatch && s + run < n && in[s + run] == in[src + run]) ++run;
+  return std::min(run, (size_t)kMaxMatch);
+}
+// is a match of `run` bytes at s cheaper than its bytes as literals?  (a match: ~13 bits; a base 2.25, anything else ~4)
+inline bool match_pays(const unsigned char* in, size_t s, size_t run) {
+  if (run >= 7) return true;
+  if (run < 4) return false;
+  unsigned quarter_bits = 0;
+  for (size_t k = 0; k < run; ++k) {
+    const unsigned char c = in[s + k];
+    quarter_bits += (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? 9u : 16u;
+  }
+  return quarter_bits > 52u;
 }
 inline void find_matches(const unsigned char* in, size_t n, std::vector<Match>* ms) {
   ms->clear();
-  const size_t none = (size_t)-1;
-  const int stride = 64 - (kMinMatch - 1);  // a run that starts in a chunk's last bytes is seen by the next chunk
-  size_t line = 0, prev = none, i = 0;
-  while (i < n) {
-    const unsigned char* q = (const unsigned char*)memchr(in + i, '\n', n - i);
-    const size_t nlpos = q ? (size_t)(q - in) : n;   // this line's end
-    const size_t lim = std::min(nlpos + 1, n);       // matches of this line's distance start below lim
-    const size_t d = prev == none ? 0 : line - prev;
-    bool crossed = false;
-    if (d != 0 && d <= 32768) {
-      while (i < lim) {
-        uint64_t m;
-        if (i + 64 <= n) {
-          m = equal_mask64(in + i, in + i - d);
-        } else {
-          m = 0;
-          for (size_t k = 0; i + k < n; ++k) m |= (uint64_t)(in[i + k] == in[i + k - d]) << k;
-        }
-        uint64_t r = m & (m >> 1) & (m >> 2);
-        r = r & (r >> 3);  // bit k: bytes k .. k+5 equal
-        static_assert(kMinMatch == 6, "the run detector above is written for six");
-        const size_t starts = std::min<size_t>((size_t)stride, lim - i);
-        if (starts < 64) r &= (((uint64_t)1 << starts) - 1);
-        if (r == 0) {
-          i += starts;
-          continue;
-        }
-        const size_t s = i + (size_t)__builtin_ctzll(r);
-        size_t run = kMinMatch;
-        while (run < (size_t)kMaxMatch && s + run < n && in[s + run] == in[s + run - d]) ++run;
-        ms->push_back({(uint32_t)s, (uint32_t)run, (uint32_t)d});
-        i = s + run;
-        if (i > nlpos) {  // over the line end(s): every one of them moves the lines
-          for (size_t p = nlpos; p < i; ++p)
-            if (in[p] == '\n') {
-              prev = line;
-              line = p + 1;
-            }
-          crossed = true;
-          break;
-        }
-      }
+  Fields fa, fb;
+  Fields *cur = &fa, *prev = &fb;
+  prev->n = 0;
+  size_t covered = 0;  // text below this position is inside a match already
+  for (size_t ls = 0; ls < n;) {
+    const size_t le = split_line(in, n, ls, cur);
+    const int nf = std::min(cur->n, prev->n);
+    for (int j = 0; j < nf; ++j) {
+      const size_t s = cur->at[j];
+      if (s < covered) continue;
+      const size_t src = prev->at[j], d = s - src;
+      if (d > 32768) break;
+      const size_t run = common_run(in, n, s, src);
+      if (!match_pays(in, s, run)) continue;
+      ms->push_back({(uint32_t)s, (uint32_t)run, (uint32_t)d});
+      covered = s + run;
     }
-    if (!crossed) {
-      if (nlpos < n) {
-        prev = line;
-        line = nlpos + 1;
-      }
-      i = lim;
-    }
+    std::swap(cur, prev);
+    ls = le + 1;
   }
 }
 
@@ -213,7 +244,7 @@ inline void find_matches(const unsigned char* in, size_t n, std::vector<Match>* 
 // brings the stream to a byte boundary (what zlib's Z_SYNC_FLUSH emits), so that blocks made apart concatenate.
 inline void deflate_lines(const unsigned char* in, size_t n, bool last, std::string* out) {
   BitSink bs(out);
-  bs.room(n / 2 + 1024);
+  bs.room(1024);
   if (n == 0) {
     if (last) {
       bs.put(1, 1);  // BFINAL, fixed codes, end of block
@@ -336,35 +367,43 @@ inline void deflate_lines(const unsigned char* in, size_t n, bool last, std::str
       const int a = present[x], b = present[y];  // a is the first byte in memory = the low byte of the pair
       pair[(size_t)a | ((size_t)b << 8)] = {(uint32_t)lc[a] | ((uint32_t)lc[b] << ll[a]), (uint32_t)ll[a] + ll[b]};
     }
+  {  // what the block's symbols will take is known to the bit: room for it once, no checks from here on
+    uint64_t bits = 0;
+    for (int c = 0; c < 286; ++c) bits += (uint64_t)lf[c] * ll[c];
+    for (int c = 0; c < 30; ++c) bits += (uint64_t)df[c] * dl[c];
+    bits += 18ull * ms.size();  // extra bits of a length (<= 5) and a distance (<= 13)
+    bs.room((size_t)(bits / 8) + 1024);
+  }
   auto literals = [&](size_t from, size_t to) {
-    bs.room((to - from) * 2 + 64);
-    // the sink's state in locals for the loop: byte stores may alias anything, members would be reloaded per symbol
-    uint64_t acc = bs.acc;
-    int nb = bs.n;
-    char* dst = &(*bs.out)[0] + bs.at;
-    const Pair* __restrict tab = pair.data();
     size_t p = from;
-    for (; p + 4 <= to; p += 4) {  // two pairs (<= 60 bits) per flush of whole bytes
-      uint16_t v0, v1;
-      memcpy(&v0, in + p, 2);
-      memcpy(&v1, in + p + 2, 2);
-      const Pair e0 = tab[v0], e1 = tab[v1];
-      acc |= (uint64_t)e0.code << nb;
-      nb += (int)e0.bits;
-      memcpy(dst, &acc, 8);
-      dst += nb >> 3;
-      acc >>= (nb & ~7);
-      nb &= 7;
-      acc |= (uint64_t)e1.code << nb;
-      nb += (int)e1.bits;
-      memcpy(dst, &acc, 8);
-      dst += nb >> 3;
-      acc >>= (nb & ~7);
-      nb &= 7;
+    if (to - from >= 16) {
+      // the sink's state in locals for the loop: byte stores may alias anything, members would be reloaded per symbol
+      uint64_t acc = bs.acc;
+      int nb = bs.n;
+      char* dst = &(*bs.out)[0] + bs.at;
+      const Pair* __restrict tab = pair.data();
+      for (; p + 4 <= to; p += 4) {  // two pairs (<= 60 bits), whole bytes flushed after each
+        uint16_t v0, v1;
+        memcpy(&v0, in + p, 2);
+        memcpy(&v1, in + p + 2, 2);
+        const Pair e0 = tab[v0], e1 = tab[v1];
+        acc |= (uint64_t)e0.code << nb;
+        nb += (int)e0.bits;
+        memcpy(dst, &acc, 8);
+        dst += nb >> 3;
+        acc >>= (nb & ~7);
+        nb &= 7;
+        acc |= (uint64_t)e1.code << nb;
+        nb += (int)e1.bits;
+        memcpy(dst, &acc, 8);
+        dst += nb >> 3;
+        acc >>= (nb & ~7);
+        nb &= 7;
+      }
+      bs.acc = acc;
+      bs.n = nb;
+      bs.at = (size_t)(dst - &(*bs.out)[0]);
     }
-    bs.acc = acc;
-    bs.n = nb;
-    bs.at = (size_t)(dst - &(*bs.out)[0]);
     for (; p < to; ++p) bs.put(lc[in[p]], ll[in[p]]);
   };
   size_t at = 0;
@@ -380,12 +419,10 @@ inline void deflate_lines(const unsigned char* in, size_t n, bool last, std::str
     at = (size_t)m.pos + m.len;
   }
   literals(at, n);
-  bs.room(64);
   bs.put(lc[256], ll[256]);
   if (!last) {
     bs.put(0, 3);  // empty stored block: to the byte boundary, LEN 0, NLEN ~0
     bs.align();
-    bs.room(8);
     bs.put(0x0000, 16);
     bs.put(0xFFFF, 16);
   }

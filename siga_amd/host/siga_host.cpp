@@ -6,6 +6,7 @@
 
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -227,8 +228,25 @@ static inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' 
 // parallel for FASTA; names and comments are spans of the file image, sequences are packed the way the device batches
 // take them
 // ------------------------------------------------------------------------------------------------------
+// The bytes of a reads file: a plain file is mapped (its pages come in under the parsing threads: reading 3.4 GB --
+// BASELINE configs[2]'s reads as FASTA -- into a vector took one thread 1.3 s before the first chunk could be parsed),
+// a compressed one is expanded into memory.
+struct FileImage {
+  std::vector<char> owned;
+  const char* map = nullptr;
+  size_t map_size = 0;
+  FileImage() = default;
+  FileImage(const FileImage&) = delete;
+  FileImage& operator=(const FileImage&) = delete;
+  ~FileImage() {
+    if (map) munmap((void*)map, map_size);
+  }
+  const char* data() const { return map ? map : owned.data(); }
+  size_t size() const { return map ? map_size : owned.size(); }
+};
+
 struct ReadStore {
-  std::vector<char> file;
+  FileImage file;
   std::vector<char> seqs;
   std::vector<uint64_t> offs;                 // n + 1
   std::vector<uint64_t> head_off;             // raw header (after '>' / '@'), a span of `file`
@@ -247,7 +265,8 @@ struct ReadStore {
   }
 };
 
-static bool slurp(const std::string& path, std::vector<char>* out) {
+static bool slurp(const std::string& path, FileImage* img) {
+  std::vector<char>* out = &img->owned;
   int fd = open(path.c_str(), O_RDONLY);
   if (fd < 0) return false;
   unsigned char magic[3] = {0, 0, 0};
@@ -288,6 +307,16 @@ static bool slurp(const std::string& path, std::vector<char>* out) {
     const bool whole = gzclose(f) == Z_OK;  // Z_BUF_ERROR: the stream ended inside a member
     out->resize(len);
     return whole;
+  }
+  if (S_ISREG(st.st_mode) && st.st_size >= (1 << 20)) {
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m != MAP_FAILED) {
+      (void)madvise(m, (size_t)st.st_size, MADV_WILLNEED);
+      img->map = (const char*)m;
+      img->map_size = (size_t)st.st_size;
+      close(fd);
+      return true;
+    }
   }
   out->resize((size_t)st.st_size);
   size_t len = 0;
@@ -1028,11 +1057,10 @@ class OutFile {
   static const size_t kBlock = 1 << 20, kFlush = 64u << 20;
   // On read text (four-letter sequences with little to match inside a 32 KiB window) zlib's level 6, what the
   // reference's gzip filter uses, makes 10 MB/s per thread, level 4 62 MB/s for a file 5 % larger; with the kernels done
-  // in milliseconds the deflate of the VT lines was the longest phase of `siga overlap`.  Blocks that are mostly bases
-  // (VT lines, FASTA) go through the line coder of line_deflate.hpp: 670 MB/s per thread and 9 % SMALLER than level 6
-  // on VT lines; everything else (ED lines: numbers, where a real match finder pays) through zlib at level 4.  The
-  // choice depends on the block's bytes alone, so the file still does not depend on threads, batches or GPUs.
-  // SIGA_GZIP_LEVEL=<1..9> sends every block through zlib at that level (6 = the reference's setting).
+  // in milliseconds the deflate of the VT lines was the longest phase of `siga overlap`.  The writer's own coder
+  // (line_deflate.hpp: matches against the line above, field by field) makes 650 MB/s per thread on VT lines for a
+  // stream 9 % SMALLER than level 6, and 300 MB/s on ED lines at level 4's size.
+  // SIGA_GZIP_LEVEL=<1..9> sends every block through zlib at that level instead (6 = the reference's setting).
   static int gzip_level(bool* forced = nullptr) {
     static const int env_level = [] {
       const char* env = getenv("SIGA_GZIP_LEVEL");
@@ -1042,20 +1070,12 @@ class OutFile {
     if (forced) *forced = env_level != 0;
     return env_level ? env_level : 4;
   }
-  static bool mostly_bases(const char* in, size_t n) {  // every 13th byte looked at
-    size_t seen = 0, bases = 0;
-    for (size_t i = 0; i < n; i += 13, ++seen) {
-      const char c = in[i];
-      bases += c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N';
-    }
-    return seen >= 64 && 2 * bases >= seen;
-  }
   static void deflate_block(const char* in, size_t n, bool last, std::string* out, uLong* crc) {
     *crc = ldef::crc32_fast(0, (const unsigned char*)in, n,
                             [](uint32_t c, const unsigned char* p, size_t k) { return (uint32_t)crc32(c, (const Bytef*)p, (uInt)k); });
     bool forced = false;
     const int level = gzip_level(&forced);
-    if (!forced && mostly_bases(in, n)) {
+    if (!forced) {
       ldef::deflate_lines((const unsigned char*)in, n, last, out);
       return;
     }
@@ -1198,36 +1218,101 @@ struct PhaseTimer {  // SIGA_TIMING=1: phase times on stderr
 };
 
 // ReadInfo{name,length} of the edge converter (src/overlap_builder.cpp:333-343) as lengths + rank of each name under
-// std::string operator< (equal names, equal rank): sorted chunks merged pairwise, all in parallel
+// std::string operator< (equal names, equal rank).  A sample sort on the host threads: names enter as (first eight bytes,
+// big endian; index) pairs -- the file image is only gone back to on a tie --, splitters from a sample cut them into
+// buckets of equal names' ranges, the buckets are sorted side by side, and the ranks follow from the distinct names
+// counted per bucket.  (Round 2 merged sorted runs pairwise: the last merges ran on one thread, 1.3 s for 20 M names.)
 static void name_ranks(const ReadStore& rs, unsigned nt, std::vector<uint32_t>* lengths, std::vector<uint32_t>* ranks) {
   const size_t n = rs.size();
   lengths->resize(n);
   ranks->resize(n);
-  std::vector<uint32_t> order(n);
-  auto less = [&](uint32_t a, uint32_t b) { return rs.name(a) < rs.name(b); };
-  size_t runs = 1;
-  while (runs < nt && n / (runs * 2) >= 4096) runs *= 2;
-  const size_t step = (n + runs - 1) / std::max<size_t>(runs, 1);
-  parallel_for(runs, nt, [&](size_t r) {
-    const size_t b = std::min(n, r * step), e = std::min(n, b + step);
+  if (n == 0) return;
+  struct Key {
+    uint64_t k;
+    uint32_t i;
+  };
+  auto less = [&](const Key& a, const Key& b) { return a.k != b.k ? a.k < b.k : rs.name(a.i) < rs.name(b.i); };
+  auto same = [&](const Key& a, const Key& b) { return a.k == b.k && rs.name(a.i) == rs.name(b.i); };
+  std::vector<Key> keys(n), sorted(n);
+  const size_t chunks = std::max<size_t>(1, std::min<size_t>((size_t)nt * 4, n / 4096));
+  const size_t step = (n + chunks - 1) / chunks;
+  parallel_for(chunks, nt, [&](size_t c) {
+    const size_t b = std::min(n, c * step), e = std::min(n, b + step);
     for (size_t i = b; i < e; ++i) {
-      order[i] = (uint32_t)i;
       (*lengths)[i] = (uint32_t)(rs.offs[i + 1] - rs.offs[i]);
+      const std::string_view nm = rs.name(i);
+      uint64_t k = 0;
+      for (size_t j = 0; j < 8; ++j) k = (k << 8) | (j < nm.size() ? (unsigned char)nm[j] : 0u);
+      keys[i] = {k, (uint32_t)i};
     }
-    std::stable_sort(order.begin() + b, order.begin() + e, less);
   });
-  for (size_t width = step; width < n; width *= 2) {
-    const size_t pairs = (n + 2 * width - 1) / (2 * width);
-    parallel_for(pairs, nt, [&](size_t p) {
-      const size_t b = p * 2 * width, m = std::min(n, b + width), e = std::min(n, b + 2 * width);
-      if (m < e) std::inplace_merge(order.begin() + b, order.begin() + m, order.begin() + e, less);
-    });
+  // splitters: every bucket takes the names in [splitter b-1, splitter b)
+  const size_t nbuckets = chunks > 1 ? std::min<size_t>((size_t)nt * 8, 1024) : 1;
+  std::vector<Key> splitters;
+  if (nbuckets > 1) {
+    const size_t nsample = std::min(n, nbuckets * 64);
+    std::vector<Key> sample(nsample);
+    for (size_t j = 0; j < nsample; ++j) sample[j] = keys[(size_t)((unsigned __int128)j * n / nsample)];
+    std::sort(sample.begin(), sample.end(), less);
+    for (size_t b = 1; b < nbuckets; ++b) splitters.push_back(sample[b * nsample / nbuckets]);
   }
-  uint32_t rk = 0;
-  for (size_t k = 0; k < n; ++k) {
-    if (k > 0 && rs.name(order[k]) != rs.name(order[k - 1])) ++rk;
-    (*ranks)[order[k]] = rk;
+  auto bucket_of = [&](const Key& x) {  // splitters <= x
+    return (size_t)(std::upper_bound(splitters.begin(), splitters.end(), x, less) - splitters.begin());
+  };
+  std::vector<uint32_t> which(n);
+  std::vector<size_t> count(chunks * nbuckets, 0);
+  parallel_for(chunks, nt, [&](size_t c) {
+    const size_t b = std::min(n, c * step), e = std::min(n, b + step);
+    size_t* cnt = &count[c * nbuckets];
+    for (size_t i = b; i < e; ++i) cnt[which[i] = (uint32_t)bucket_of(keys[i])]++;
+  });
+  std::vector<size_t> bstart(nbuckets + 1, 0);
+  {
+    size_t at = 0;  // bucket-major, chunk-minor: a chunk's share of a bucket starts at count[c][b] afterwards
+    for (size_t b = 0; b < nbuckets; ++b) {
+      bstart[b] = at;
+      for (size_t c = 0; c < chunks; ++c) {
+        const size_t k = count[c * nbuckets + b];
+        count[c * nbuckets + b] = at;
+        at += k;
+      }
+    }
+    bstart[nbuckets] = at;
   }
+  parallel_for(chunks, nt, [&](size_t c) {
+    const size_t b = std::min(n, c * step), e = std::min(n, b + step);
+    size_t* at = &count[c * nbuckets];
+    for (size_t i = b; i < e; ++i) sorted[at[which[i]]++] = keys[i];
+  });
+  std::vector<uint32_t> distinct(nbuckets, 0);  // names of a bucket that differ from their predecessor IN the bucket
+  parallel_for(nbuckets, nt, [&](size_t b) {
+    Key* lo = sorted.data() + bstart[b];
+    Key* hi = sorted.data() + bstart[b + 1];
+    std::sort(lo, hi, less);
+    uint32_t d = 0;
+    for (Key* q = lo + 1; q < hi; ++q) d += same(q[-1], q[0]) ? 0u : 1u;
+    distinct[b] = d;
+  });
+  // rank of a bucket's first name: the distinct names before it (buckets hold disjoint ranges of names)
+  std::vector<uint32_t> first(nbuckets, 0);
+  {
+    uint32_t rk = 0;
+    bool any = false;
+    for (size_t b = 0; b < nbuckets; ++b) {
+      if (bstart[b] == bstart[b + 1]) continue;
+      if (any) ++rk;  // its first name is a new one
+      first[b] = rk;
+      rk += distinct[b];
+      any = true;
+    }
+  }
+  parallel_for(nbuckets, nt, [&](size_t b) {
+    uint32_t rk = first[b];
+    for (size_t k = bstart[b]; k < bstart[b + 1]; ++k) {
+      if (k > bstart[b] && !same(sorted[k - 1], sorted[k])) ++rk;
+      (*ranks)[sorted[k].i] = rk;
+    }
+  });
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1868,12 +1953,21 @@ int sigah_correct_file(const char* reads_path, const char* prefix, const char* o
 }
 
 // test hook: parse a reads file with the parallel loader (mode 0) or the record-at-a-time DNASeqReader (mode 1) and dump
-// "name\tcomment\tseq\tquality\n" per read; returns the number of reads or -1
+// "name\tcomment\tseq\tquality\n" per read; mode 2: the parallel loader and the edge converter's read table, "rank\tlength\n"
+// per read; returns the number of reads or -1
 int64_t sigah_parse_file(const char* path, int mode, const char* out_path, int threads) {
   FILE* f = fopen(out_path, "wb");
   if (!f) return -1;
   int64_t n = -1;
-  if (mode == 0) {
+  if (mode == 2) {
+    sigah::ReadStore rs;
+    if (sigah::LoadReads(path, &rs, (unsigned)std::max(threads, 1))) {
+      std::vector<uint32_t> lengths, ranks;
+      sigah::name_ranks(rs, (unsigned)std::max(threads, 1), &lengths, &ranks);
+      n = (int64_t)rs.size();
+      for (size_t i = 0; i < rs.size(); ++i) fprintf(f, "%u\t%u\n", ranks[i], lengths[i]);
+    }
+  } else if (mode == 0) {
     sigah::ReadStore rs;
     if (sigah::LoadReads(path, &rs, (unsigned)std::max(threads, 1))) {
       n = (int64_t)rs.size();

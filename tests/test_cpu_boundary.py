@@ -374,3 +374,38 @@ def test_line_coder_blocks_inflate_to_the_text(tmp_path):
     assert subprocess.run([sys.executable, "-c", code, ref, src], env=dict(os.environ, SIGA_GZIP_LEVEL="6")).returncode == 0
     assert gzip.open(ref, "rb").read() == vt
     assert len(open(ref, "rb").read()) > len(open(str(tmp_path / "vt_1.gz"), "rb").read())
+
+
+def test_host_read_table_ranks_names_in_string_order(tmp_path):
+    """Hit2OverlapConverter's ReadInfo table (src/overlap_builder.cpp:333-343,358,365: edges are kept by comparing read NAMES
+    with std::string's operator<): the host ranks all names with a sample sort on (first eight bytes, index) pairs.  Names that
+    tie in their first eight bytes, names shorter than that, duplicates, bytes above 0x7f (unsigned order) and a set large
+    enough for many buckets must rank exactly as Python sorts the byte strings."""
+    rng = np.random.default_rng(2)
+    n = 120_000
+    names = []
+    for i in range(n):
+        kind = i % 6
+        if kind == 0:
+            names.append(b"r%d" % rng.integers(0, 50_000))           # duplicates, lengths 2..6
+        elif kind == 1:
+            names.append(b"sample_A/lane3/read%d" % i)               # long common prefix: every compare is a tie-break
+        elif kind == 2:
+            names.append(bytes(rng.integers(33, 127, size=rng.integers(1, 12), dtype=np.uint8)).replace(b">", b"x"))
+        elif kind == 3:
+            names.append(b"\xc3\xa9" + b"%d" % rng.integers(0, 1000))  # bytes >= 0x80 sort after ASCII
+        elif kind == 4:
+            names.append(b"read%07d" % (i // 2))                      # ties at exactly eight bytes and beyond
+        else:
+            names.append(b"x" * int(rng.integers(1, 20)))             # prefixes of each other
+    lens = rng.integers(1, 40, size=n)
+    fa = str(tmp_path / "names.fa")
+    with open(fa, "wb") as f:
+        f.write(b"".join(b">%s some comment\n%s\n" % (nm, b"A" * int(l)) for nm, l in zip(names, lens)))
+    out = str(tmp_path / "table.txt")
+    for threads in (1, 5):
+        assert host.read_table(fa, out, threads=threads) == n
+        got = np.loadtxt(out, dtype=np.int64)
+        order = {nm: k for k, nm in enumerate(sorted(set(names)))}
+        assert got[:, 0].tolist() == [order[nm] for nm in names]
+        assert got[:, 1].tolist() == lens.tolist()

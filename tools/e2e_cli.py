@@ -34,6 +34,20 @@ def run(args):
 
 t_index = run(["index", "-t", "64", "reads.fa"])
 t_overlap = run(["overlap", "-m", "45", "-t", "8", "reads.fa"])
+for extra in filter(None, os.environ.get("E2E_AGAIN", "").split(";")):  # the same run with other settings: "A=1,B=2;C=3"
+    os.rename(os.path.join(d, "reads.asqg.gz"), os.path.join(d, "first.asqg.gz"))
+    keep = dict(env)
+    env.update(kv.split("=", 1) for kv in extra.split(","))
+    print("again with", extra)
+    run(["overlap", "-m", "45", "-t", "8", "reads.fa"])
+    env.clear()
+    env.update(keep)
+    a = subprocess.run(["gzip", "-dc", os.path.join(d, "reads.asqg.gz")], capture_output=True).stdout
+    b = subprocess.run(["gzip", "-dc", os.path.join(d, "first.asqg.gz")], capture_output=True).stdout
+    print("same ASQG text as the first run:", a == b)
+    del a, b
+    os.remove(os.path.join(d, "reads.asqg.gz"))
+    os.rename(os.path.join(d, "first.asqg.gz"), os.path.join(d, "reads.asqg.gz"))
 if GPUS > 1:
     os.rename(os.path.join(d, "reads.asqg.gz"), os.path.join(d, "one.asqg.gz"))
     env["SIGA_DEVICE_MAP"] = ",".join(["0"] * GPUS) if os.environ.get("E2E_REHEARSE") else ""
