@@ -130,6 +130,12 @@ int  sigax_build_strand(const char* seqs, const uint64_t* offs, uint64_t n_reads
                         uint8_t** runs, uint64_t* n_runs, uint32_t** sai, uint64_t* n_symbols);
 void sigax_free(void* p);
 
+/* The index is here to stay (a service, a benchmark: many more reads than it holds will be asked of it): builds the
+ * extractor's row tables now and returns when they are in place.  Without this call they are built in the background once
+ * the index has been asked for as many reads as it holds -- one pass of `siga overlap` over the indexed reads
+ * (src/overlap.cpp:41-47) never pays their build.  No-op when they are there already or do not fit. */
+int  sigax_index_prepare(sigax_index*);
+
 /* Self-check of an open index: are the BWT rows of strand `which` (0 forward, 1 reverse) in the suffix order `siga index`
  * produces (SuffixArrayBuilder "sais2": src/suffix_array_builder.cpp:472-674; SURVEY.md App. C: one '$' smaller than
  * ACGT, comparisons continuing past it, end of text smallest)?  Every pair of adjacent rows is compared on the device.

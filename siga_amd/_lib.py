@@ -50,7 +50,7 @@ class RunInfo(C.Structure):
 
 # every symbol include/sigax.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "sigax_last_error", "sigax_device_count", "sigax_stream_create", "sigax_stream_destroy", "sigax_index_open", "sigax_index_open_mem", "sigax_index_clone", "sigax_index_close",
+    "sigax_last_error", "sigax_device_count", "sigax_stream_create", "sigax_stream_destroy", "sigax_index_open", "sigax_index_open_mem", "sigax_index_prepare", "sigax_index_clone", "sigax_index_close",
     "sigax_index_info_get", "sigax_index_set_reads", "sigax_index_check_order", "sigax_occ_batch", "sigax_kmer_count_batch",
     "sigax_correct_batch", "sigax_correct_device", "sigax_overlap_batch", "sigax_result_free", "sigax_batch_create", "sigax_batch_destroy", "sigax_batch_upload",
     "sigax_batch_set_device_reads", "sigax_batch_set_subbatches", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
@@ -79,6 +79,7 @@ def lib():
     L.sigax_stream_destroy.restype = None
     L.sigax_index_open.argtypes = [cp, cp, cp, cp, ci, pvp]
     L.sigax_index_open_mem.argtypes = [vp, u64, vp, u64, u64, u64, vp, vp, ci, pvp]
+    L.sigax_index_prepare.argtypes = [vp]
     L.sigax_index_clone.argtypes = [vp, ci, pvp]
     L.sigax_index_close.argtypes = [vp]
     L.sigax_index_close.restype = None

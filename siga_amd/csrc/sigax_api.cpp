@@ -103,7 +103,8 @@ struct sigax_index {
   std::thread* tab_thread;
   std::atomic<int>* tab_state;
   FmStrand tab_st[2];
-  u64 tab_bytes, tab_plan, n_runs;
+  u64 tab_bytes, tab_plan, reads_asked;
+  bool tab_tried;  // the build has been started once (it is not tried again when memory was short)
   bool tab_text;
   bool tab_direct;   // direct maps instead of row tables (.sai tables present, ACGT-only reads)
   u32 tab_syms;      // symbols a row-table entry carries (plan)
@@ -640,7 +641,8 @@ static void publish_tables(sigax_index* ix) {
 
 // start (or do) the build: allocate here, fill on a side thread unless `sync`
 static void start_row_tables(sigax_index* ix, bool sync) {
-  if (ix->tab_plan == 0) return;
+  if (ix->tab_plan == 0 || ix->tab_tried) return;
+  ix->tab_tried = true;
   if (!alloc_row_tables(ix)) return;
   if (sync) {
     fill_row_tables(ix, ix->tab_st, &ix->tab_bytes);
@@ -656,11 +658,25 @@ static void start_row_tables(sigax_index* ix, bool sync) {
   });
 }
 
+// When are they built?  The build walks the whole index (C3: 1.8 s, 45 GB) and saves ~20 ns per read afterwards: it pays
+// on an index that stays open -- a service, bench.py -- and does not in one pass of `siga overlap` over the reads the
+// index was made of (BASELINE configs[2]'s read set through the CLI: 7.2 s with the tables, 3.6 s without).  So: small
+// indexes (and SIGAX_TABLES_SYNC=1) at once; the others in the background once the index has been asked for as many
+// reads as it holds (enqueue()), or at once when the caller says the index is here to stay (sigax_index_prepare).
 static void build_rowend(sigax_index* ix) {
   ix->tab_state = new std::atomic<int>(0);
   plan_row_tables(ix);
-  // small indexes (and SIGAX_TABLES_SYNC=1) at once; the others when the second run is enqueued (enqueue())
   if (ix->n_symbols < (1ull << 26) || getenv("SIGAX_TABLES_SYNC") != nullptr) start_row_tables(ix, true);
+}
+// the tables in place before this returns (caller holds enqueue_mu)
+static void row_tables_now(sigax_index* ix) {
+  if (ix->tab_thread) {  // a build in flight: wait for it
+    ix->tab_thread->join();
+    delete ix->tab_thread;
+    ix->tab_thread = nullptr;
+  }
+  publish_tables(ix);
+  start_row_tables(ix, true);  // (no-op when they were built, or tried, before)
 }
 
 // SIGAX_VERBOSE: where the time of opening an index goes
@@ -894,6 +910,14 @@ extern "C" int sigax_index_open(const char* bwt_path, const char* rbwt_path, con
 
 // Replica of an open index on another GPU of the node, copied device to device (xGMI between MI355X peers) instead of
 // being decoded and uploaded again: SURVEY.md 8(e) "index broadcast at start-up".
+extern "C" int sigax_index_prepare(sigax_index* ix) {
+  if (!ix) return fail(SIGAX_E_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(ix->device));
+  std::lock_guard<std::mutex> lock(*ix->enqueue_mu);
+  row_tables_now(ix);
+  return SIGAX_OK;
+}
+
 extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index** out) {
   if (!src || !out) return fail(SIGAX_E_ARG, "NULL argument");
   *out = nullptr;
@@ -1012,13 +1036,7 @@ extern "C" int sigax_index_check_order(sigax_index* ix, int which, uint64_t* n_b
   if (ix->st[which].C[1] != ix->n_strings) return fail(SIGAX_E_STATE, "reads with non-ACGT bases: stretches are not reads, order not checkable");
   {
     std::lock_guard<std::mutex> lock(*ix->enqueue_mu);
-    if (ix->tab_thread) {  // a build in flight: wait for it
-      ix->tab_thread->join();
-      delete ix->tab_thread;
-      ix->tab_thread = nullptr;
-    }
-    publish_tables(ix);
-    if (!ix->st[which].text && ix->tab_plan) start_row_tables(ix, true);
+    row_tables_now(ix);
   }
   if (!ix->st[which].text) return fail(SIGAX_E_STATE, "no extractor tables on this index (memory short or turned off)");
   // The check reads the suffix array.  An index that runs on direct maps has none: a bare row table of this strand is
@@ -1409,7 +1427,9 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   sigax_index* ix = b->ix;
   std::lock_guard<std::mutex> lock(*ix->enqueue_mu);  // one batch's launch sequence at a time on the shared streams
   publish_tables(ix);
-  if (++ix->n_runs == 2) start_row_tables(ix, false);
+  // a whole pass over the indexed reads has been asked for before this run: the index is being reused
+  if (ix->reads_asked >= std::max<u64>(ix->n_strings, 1)) start_row_tables(ix, false);
+  ix->reads_asked += b->n_reads;
   const uint32_t n = b->n_reads;
   const bool edges = (b->flags & SIGAX_EDGES) != 0;
   if (edges && (!ix->d_sai[0] || !ix->d_read_len))

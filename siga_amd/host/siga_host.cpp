@@ -245,9 +245,22 @@ struct FileImage {
   size_t size() const { return map ? map_size : owned.size(); }
 };
 
+// bytes that are written before they are read: no zero fill (std::vector::resize ran 3 GB of it on one thread)
+struct RawChars {
+  std::unique_ptr<char[]> p;
+  size_t n = 0;
+  void resize(size_t k) {  // contents undefined
+    p.reset(new char[k ? k : 1]);
+    n = k;
+  }
+  char* data() { return p.get(); }
+  const char* data() const { return p.get(); }
+  size_t size() const { return n; }
+};
+
 struct ReadStore {
   FileImage file;
-  std::vector<char> seqs;
+  RawChars seqs;
   std::vector<uint64_t> offs;                 // n + 1
   std::vector<uint64_t> head_off;             // raw header (after '>' / '@'), a span of `file`
   std::vector<uint32_t> head_len, name_len;   // name = head[0, name_len); comment = head[name_len + 1, head_len)
@@ -346,6 +359,7 @@ static void parse_fasta_chunk(const char* base, size_t b, size_t e, bool last_ch
   bool have_name = false;
   uint64_t hoff = 0;
   uint32_t hlen = 0;
+  o->seqs.reserve(o->seqs.size() + (e - b));  // a chunk's bases are fewer than its bytes: no regrowth
   size_t seq_start = o->seqs.size();
   size_t p = b;
   auto emit = [&] {
@@ -1358,8 +1372,11 @@ void OverlapBuilder::preload(const std::string& input, size_t threads) const {
   const unsigned nt = host_threads(threads);
   auto p = std::make_shared<Preloaded>();
   p->path = input;
+  PhaseTimer pt;
   p->ok = LoadReads(input, &p->reads, nt);
+  pt.lap("  reads parsed");
   if (p->ok) name_ranks(p->reads, nt, &p->lengths, &p->ranks);
+  pt.lap("  names ranked");
   _pre = p;
 }
 
@@ -1542,6 +1559,32 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
   for (size_t w = 0; w < devs.size(); ++w) workers.emplace_back(worker, w);
   // ordered post-processing (OverlapPostProcess, src/overlap_builder.cpp:291-329): VT lines of batch b
   std::vector<std::pair<sigax_edge*, uint64_t>> edges;
+  // The ED lines come after the last VT line, but their TEXT does not have to wait: while the GPUs work on the batches
+  // that follow, the host threads have time, so a batch's edge records are formatted as soon as its VT lines are out
+  // (up to 4 GiB of text held; beyond that the records wait and are formatted at the end, 16 bytes against ~45 each).
+  std::vector<std::vector<std::string>> ed_text;
+  size_t ed_held = 0;
+  const size_t ed_hold_max = (size_t)4 << 30, ed_chunk = 16384;
+  auto format_edges = [&](const sigax_edge* e, uint64_t cnt, std::vector<std::string>* parts) {
+    parts->assign((cnt + ed_chunk - 1) / ed_chunk, std::string());
+    parallel_for(parts->size(), nt, [&](size_t c) {
+      const uint64_t cb = c * ed_chunk, ce = std::min<uint64_t>(cnt, cb + ed_chunk);
+      std::string& o = (*parts)[c];
+      o.reserve((ce - cb) * 56);
+      // a target's name is three dependent misses away (header offset, name length, the bytes in the file image):
+      // asked for sixteen and eight edges ahead
+      for (uint64_t i = cb; i < ce; ++i) {
+        if (i + 16 < ce) {
+          const uint32_t t = e[i + 16].target;
+          __builtin_prefetch(&reads.head_off[t]);
+          __builtin_prefetch(&reads.name_len[t]);
+          __builtin_prefetch(&reads.offs[t]);
+        }
+        if (i + 8 < ce) __builtin_prefetch(reads.file.data() + reads.head_off[e[i + 8].target]);
+        write_edge(o, e[i], reads);
+      }
+    });
+  };
   const size_t vt_chunk = 4096;
   for (size_t b = 0; b < nbatch; ++b) {
     BatchOut r;
@@ -1566,6 +1609,14 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
     if (pt.on) fprintf(stderr, "[siga]   batch %zu: VT text %.3f s, deflate + write %.3f s\n", b, std::chrono::duration<double>(tv1 - tv0).count(),
                        std::chrono::duration<double>(std::chrono::steady_clock::now() - tv1).count());
     edges.emplace_back(r.edges, r.n_edges);
+    ed_text.emplace_back();
+    if (ed_held < ed_hold_max) {
+      format_edges(r.edges, r.n_edges, &ed_text.back());
+      for (const std::string& p : ed_text.back()) ed_held += p.size();
+      if (ed_text.back().empty()) ed_text.back().emplace_back();  // "formatted, and nothing to say"
+      sigax_free(r.edges);
+      edges.back().first = nullptr;
+    }
   }
   for (auto& t : workers) t.join();
   drop_replicas();
@@ -1581,16 +1632,10 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
   }
   pt.lap("GPU batches + VT lines");
   // ED lines in hits order (Hit2OverlapConverter, src/overlap_builder.cpp:345-375 + :474-483)
-  const size_t ed_chunk = 16384;
-  for (auto& eb : edges) {
-    std::vector<std::string> parts((eb.second + ed_chunk - 1) / ed_chunk);
-    parallel_for(parts.size(), nt, [&](size_t c) {
-      const uint64_t cb = c * ed_chunk, ce = std::min<uint64_t>(eb.second, cb + ed_chunk);
-      std::string& o = parts[c];
-      o.reserve((ce - cb) * 56);
-      for (uint64_t i = cb; i < ce; ++i) write_edge(o, eb.first[i], reads);
-    });
-    out.write_parts(parts);
+  for (size_t b = 0; b < edges.size(); ++b) {
+    if (ed_text[b].empty()) format_edges(edges[b].first, edges[b].second, &ed_text[b]);
+    out.write_parts(ed_text[b]);
+    std::vector<std::string>().swap(ed_text[b]);
   }
   free_edges();
   if (!out.close()) {

@@ -106,16 +106,21 @@ class FMIndexPair:
         self._h = C.c_void_p(handle)
 
     @classmethod
-    def load(cls, prefix, device=0, with_sai=True):
+    def load(cls, prefix, device=0, with_sai=True, resident=True):
+        """resident: the index stays open for many more reads than it holds (tests, bench.py): sigax_index_prepare builds the
+        extractor's row tables at once.  False = what one pass of `siga overlap` does: tables only after a full pass."""
         h = C.c_void_p()
         sai = (prefix + ".sai").encode() if with_sai else None
         rsai = (prefix + ".rsai").encode() if with_sai else None
         _check(_lib.lib().sigax_index_open((prefix + ".bwt").encode(), (prefix + ".rbwt").encode(), sai, rsai,
                                            device, C.byref(h)), "sigax_index_open")
-        return cls(h.value)
+        pair = cls(h.value)
+        if resident:
+            pair.prepare()
+        return pair
 
     @classmethod
-    def from_memory(cls, runs, rruns, n_symbols, n_strings, sai=None, rsai=None, device=0):
+    def from_memory(cls, runs, rruns, n_symbols, n_strings, sai=None, rsai=None, device=0, resident=True):
         runs = np.ascontiguousarray(runs, dtype=np.uint8)
         rruns = np.ascontiguousarray(rruns, dtype=np.uint8)
         h = C.c_void_p()
@@ -126,7 +131,10 @@ class FMIndexPair:
             ps, pr = sai.ctypes.data, rsai.ctypes.data
         _check(_lib.lib().sigax_index_open_mem(runs.ctypes.data, len(runs), rruns.ctypes.data, len(rruns), n_symbols,
                                                n_strings, ps, pr, device, C.byref(h)), "sigax_index_open_mem")
-        return cls(h.value)
+        pair = cls(h.value)
+        if resident:
+            pair.prepare()
+        return pair
 
     def close(self):
         if self._h:
@@ -154,6 +162,10 @@ class FMIndexPair:
         ranks = np.ascontiguousarray(ranks, dtype=np.uint32)
         _check(_lib.lib().sigax_index_set_reads(self._h, lengths.ctypes.data, ranks.ctypes.data, len(lengths)),
                "sigax_index_set_reads")
+
+    def prepare(self):
+        """sigax_index_prepare: the extractor's row tables in place now"""
+        _check(_lib.lib().sigax_index_prepare(self._h), "sigax_index_prepare")
 
     def check_order(self, which=0):
         """sigax_index_check_order: (pairs of adjacent BWT rows out of suffix order, first such row, undecided pairs)"""

@@ -84,3 +84,32 @@ def test_fullsize_every_read_against_oracle(c2):
     exp = expected_edges(want["blocks"], want["block_offs"], fwd.sai(), rev.sai(), np.full(N, L, dtype=np.uint32), c2["rank"])
     assert np.array_equal(edges_matrix(full["edges"]), exp)
     assert len(exp) > N  # about 1.1 irreducible edges per read at 30x
+
+
+def test_row_tables_come_with_reuse_not_with_the_first_pass(c2):
+    """An index opened through the plain C-ABI call builds the extractor's row tables only once it has been asked for as
+    many reads as it holds -- one pass of `siga overlap` (src/overlap.cpp:41-47) never pays for them -- or when the caller
+    says it is here to stay (sigax_index_prepare).  Same blocks and edges with the extractor walking (first pass) and
+    with the tables (after prepare); the tables show in the index's device bytes."""
+    sa = c2["sa"]
+    pair = sa.FMIndexPair.load(c2["prefix"], resident=False)
+    try:
+        pair.set_reads(np.full(N, L, dtype=np.uint32), c2["rank"])
+        bare = pair.info()["device_bytes"]
+        assert bare < c2["pair"].info()["device_bytes"]  # the fixture's pair was prepared at load
+        b = sa.OverlapBuilder(pair)
+        reads = (c2["reads"].reshape(-1), np.arange(0, (N + 1) * L, L, dtype=np.uint64))
+        first = b.overlap(reads, M, edges=True)
+        assert pair.info()["device_bytes"] == bare  # a whole pass, and no tables
+        full = c2.get("full") or _run(c2, 0, N)
+        for k in ("block_offs", "blocks", "substring", "edges"):
+            assert first[k].tobytes() == full[k].tobytes(), k
+        assert first["stats"]["n_occ_find"] + first["stats"]["n_occ_extract"] == full["stats"]["n_occ_find"] + full["stats"]["n_occ_extract"]
+        second = b.overlap(reads, M, edges=True)  # the index is being reused: the build starts beside this run
+        pair.prepare()                             # ... and is waited for here
+        assert pair.info()["device_bytes"] == c2["pair"].info()["device_bytes"]
+        third = b.overlap(reads, M, edges=True)
+        for k in ("block_offs", "blocks", "substring", "edges"):
+            assert second[k].tobytes() == full[k].tobytes() and third[k].tobytes() == full[k].tobytes(), k
+    finally:
+        pair.close()
