@@ -1198,9 +1198,9 @@ static void write_vertex(std::string& o, std::string_view name, std::string_view
 
 // EdgeRecord << (src/asqg.cpp:228-237, src/coord.cpp:4-80) with OverlapBlock::overlap's coordinates
 // (src/overlap_builder.cpp:158-175)
-static void write_edge(std::string& o, const sigax_edge& e, const ReadStore& reads) {
+static void write_edge(std::string& o, const sigax_edge& e, const ReadStore& reads, const uint32_t* lengths) {
   const std::string_view qn = reads.name(e.query), tn = reads.name(e.target);
-  uint64_t ql = reads.offs[e.query + 1] - reads.offs[e.query], tl = reads.offs[e.target + 1] - reads.offs[e.target], len = e.length;
+  uint64_t ql = lengths[e.query], tl = lengths[e.target], len = e.length;
   uint64_t s0 = ql - len, e0 = ql - 1, s1 = 0, e1 = len - 1;
   if (e.af & 1u) { uint64_t t = s0; s0 = ql - e0 - 1; e0 = ql - t - 1; }
   if (e.af & 2u) { uint64_t t = s1; s1 = tl - e1 - 1; e1 = tl - t - 1; }
@@ -1565,6 +1565,7 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
   std::vector<std::vector<std::string>> ed_text;
   size_t ed_held = 0;
   const size_t ed_hold_max = (size_t)4 << 30, ed_chunk = 16384;
+  const uint32_t* read_len = pre->lengths.data();
   auto format_edges = [&](const sigax_edge* e, uint64_t cnt, std::vector<std::string>* parts) {
     parts->assign((cnt + ed_chunk - 1) / ed_chunk, std::string());
     parallel_for(parts->size(), nt, [&](size_t c) {
@@ -1578,10 +1579,10 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
           const uint32_t t = e[i + 16].target;
           __builtin_prefetch(&reads.head_off[t]);
           __builtin_prefetch(&reads.name_len[t]);
-          __builtin_prefetch(&reads.offs[t]);
+          __builtin_prefetch(&read_len[t]);
         }
         if (i + 8 < ce) __builtin_prefetch(reads.file.data() + reads.head_off[e[i + 8].target]);
-        write_edge(o, e[i], reads);
+        write_edge(o, e[i], reads, read_len);
       }
     });
   };

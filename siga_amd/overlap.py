@@ -115,8 +115,7 @@ class FMIndexPair:
         _check(_lib.lib().sigax_index_open((prefix + ".bwt").encode(), (prefix + ".rbwt").encode(), sai, rsai,
                                            device, C.byref(h)), "sigax_index_open")
         pair = cls(h.value)
-        if resident:
-            pair.prepare()
+        pair._prepare_pending = bool(resident)  # at set_reads() (the longest read is known then) or the first batch
         return pair
 
     @classmethod
@@ -132,8 +131,7 @@ class FMIndexPair:
         _check(_lib.lib().sigax_index_open_mem(runs.ctypes.data, len(runs), rruns.ctypes.data, len(rruns), n_symbols,
                                                n_strings, ps, pr, device, C.byref(h)), "sigax_index_open_mem")
         pair = cls(h.value)
-        if resident:
-            pair.prepare()
+        pair._prepare_pending = bool(resident)  # at set_reads() (the longest read is known then) or the first batch
         return pair
 
     def close(self):
@@ -162,9 +160,12 @@ class FMIndexPair:
         ranks = np.ascontiguousarray(ranks, dtype=np.uint32)
         _check(_lib.lib().sigax_index_set_reads(self._h, lengths.ctypes.data, ranks.ctypes.data, len(lengths)),
                "sigax_index_set_reads")
+        if getattr(self, "_prepare_pending", False):
+            self.prepare()
 
     def prepare(self):
         """sigax_index_prepare: the extractor's row tables in place now"""
+        self._prepare_pending = False
         _check(_lib.lib().sigax_index_prepare(self._h), "sigax_index_prepare")
 
     def check_order(self, which=0):
@@ -207,6 +208,8 @@ class OverlapBuilder:
     def overlap(self, seqs, min_overlap, read_base=0, edges=False, _flags=None):
         """Batched OverlapBuilder::overlap.  Returns dict(block_offs, blocks, substring, edges, stats)."""
         buf, offs = pack_reads(seqs)
+        if getattr(self.fmi, "_prepare_pending", False):
+            self.fmi.prepare()
         res = _lib.Result()
         if isinstance(buf, np.ndarray):
             buf = C.c_char_p(buf.ctypes.data) if buf.size else b""
