@@ -3,10 +3,11 @@
 //
 // zlib spends its time hashing every position of four-letter text in which a 32 KiB window (200 reads) holds next to
 // nothing to match; what there IS to match in such text sits one line up: the tag, the running name prefix, the
-// trailing fields.  So the match finder here looks in exactly one place -- the same column of the previous line
-// (distance = length of the previous line) -- eight bytes at a time, and everything else goes out as literals under
-// one dynamic Huffman code per block (pairs of literals per table lookup).  Any inflate reads the result; on VT lines
-// it is smaller than zlib's level 6 and an order of magnitude faster per thread (tools/deflate_probe.cpp).
+// trailing fields, the numbers of an ED line that repeat.  So the match finder here looks in exactly one place -- field
+// j of the line above, for every field j of a line -- and everything else goes out as literals under one dynamic
+// Huffman code per block (pairs of literals per table lookup).  Any inflate reads the result.  Measured per thread
+// (tools/deflate_probe.cpp): VT lines 650 MB/s at 0.270 of the text (zlib -6: 10 MB/s at 0.295, -4: 60 MB/s at 0.308),
+// ED lines 300 MB/s at 0.191 (zlib -4: 95 MB/s at 0.187).
 #pragma once
 #include <immintrin.h>
 
@@ -218,6 +219,7 @@ inline bool match_pays(const unsigned char* in, size_t s, size_t run) {
 }
 inline void find_matches(const unsigned char* in, size_t n, std::vector<Match>* ms) {
   ms->clear();
+  if (n >= ((size_t)1 << 32)) return;  // positions are kept in 32 bits (the writer's blocks are 1 MiB): literals only
   Fields fa, fb;
   Fields *cur = &fa, *prev = &fb;
   prev->n = 0;
