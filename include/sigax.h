@@ -129,6 +129,11 @@ int  sigax_index_set_reads(sigax_index*, const uint32_t* lengths, const uint32_t
 int  sigax_build_strand(const char* seqs, const uint64_t* offs, uint64_t n_reads, int reverse, int device,
                         uint8_t** runs, uint64_t* n_runs, uint32_t** sai, uint64_t* n_symbols);
 void sigax_free(void* p);
+/* Brackets several builds (the two strands of one `siga index`): between open (1) and close (0) the builders' device
+ * workspace is kept and handed from one call to the next instead of going back to the driver -- hipMalloc hands out
+ * cleared memory, and clearing the tens of GB a strand's sort works in again for the next strand cost more than its
+ * kernels.  Optional; nests; without it every call returns its workspace when it ends. */
+void sigax_build_session(int open);
 
 /* The index is here to stay (a service, a benchmark: many more reads than it holds will be asked of it): builds the
  * extractor's row tables now and returns when they are in place.  Without this call they are built in the background once

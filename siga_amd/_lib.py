@@ -54,7 +54,7 @@ SYMBOLS = [
     "sigax_index_info_get", "sigax_index_set_reads", "sigax_index_check_order", "sigax_occ_batch", "sigax_kmer_count_batch",
     "sigax_correct_batch", "sigax_correct_device", "sigax_overlap_batch", "sigax_result_free", "sigax_batch_create", "sigax_batch_destroy", "sigax_batch_upload",
     "sigax_batch_set_device_reads", "sigax_batch_set_subbatches", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
-    "sigax_batch_download", "sigax_batch_download_edges", "sigax_batch_size_hint", "sigax_batch_kernel_ms", "sigax_batch_run_info", "sigax_build_strand", "sigax_free",
+    "sigax_batch_download", "sigax_batch_download_edges", "sigax_batch_size_hint", "sigax_batch_kernel_ms", "sigax_batch_run_info", "sigax_build_strand", "sigax_build_session", "sigax_free",
 ]
 
 _lib = None
@@ -110,6 +110,8 @@ def lib():
     L.sigax_build_strand.argtypes = [vp, vp, u64, ci, ci, pvp, C.POINTER(u64), pvp, C.POINTER(u64)]
     L.sigax_free.argtypes = [vp]
     L.sigax_free.restype = None
+    L.sigax_build_session.argtypes = [ci]
+    L.sigax_build_session.restype = None
     _lib = L
     return L
 

@@ -727,6 +727,10 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
   ix->wide = n_symbols >= 0xFFFFFFF0ull || getenv("SIGAX_FORCE_WIDE") != nullptr;
   const uint8_t* rr[2] = {runs, rruns};
   u64 nr[2] = {n_runs, n_rruns};
+  struct DecodeSession {  // the second strand is decoded in the first one's scratch memory
+    DecodeSession() { sigax_build_session(1); }
+    ~DecodeSession() { sigax_build_session(0); }
+  } decode_session;
   for (int s = 0; s < 2; ++s) {
     u64 C[5], total[5], gb = 0, sb = 0;
     int rc = sigax_decode_strand(rr[s], nr[s], n_symbols, ix->wide, &ix->d_gran[s], &gb, &ix->d_super[s], &sb, C, total);

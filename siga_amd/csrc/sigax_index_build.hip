@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -49,27 +50,114 @@ namespace {
   } while (0)
 
 // frees everything it was given when it goes out of scope (every early return of the builder)
+// Device memory of the builders.  hipMalloc hands out CLEARED memory and hipFree waits for the device: with one
+// hipMalloc / hipFree pair per buffer the second strand of `siga index` at BASELINE configs[2] took 3.0 s for 0.85 s of
+// kernels, the first -- on memory the process had not dirtied yet -- 0.8 s (profiles/r03_index_kernel_stats.csv).  So a
+// block that is released goes to a per-process cache and is handed out again (best fit on the same device, at most
+// half as large again as asked for); the cache is emptied when the last pool or build session (sigax_build_session:
+// the two strands of one `siga index`) ends, or when an allocation fails.  Nothing here relies on cleared memory:
+// SIGAX_POOL_POISON=1 fills every block with 0xA5 before it is handed out (the index-build tests run with it).
+namespace devcache {
+struct Block {
+  void* p;
+  size_t bytes;
+  int device;
+};
+static std::mutex mu;
+static std::vector<Block> spare;
+static int users = 0;
+static void trim_locked() {
+  for (const Block& b : spare) hipFree(b.p);
+  spare.clear();
+}
+static void enter() {
+  std::lock_guard<std::mutex> g(mu);
+  ++users;
+}
+static void leave() {
+  std::lock_guard<std::mutex> g(mu);
+  if (--users <= 0) {
+    users = 0;
+    trim_locked();
+  }
+}
+}  // namespace devcache
+
 struct DevPool {
-  std::vector<void*> ptrs;
+  std::vector<devcache::Block> live;
+  int device = 0;
+  DevPool() {
+    (void)hipGetDevice(&device);
+    devcache::enter();
+  }
+  DevPool(const DevPool&) = delete;
+  DevPool& operator=(const DevPool&) = delete;
   ~DevPool() {
-    for (void* p : ptrs)
-      if (p) hipFree(p);
+    {
+      std::lock_guard<std::mutex> g(devcache::mu);
+      for (const devcache::Block& b : live)
+        if (b.p) devcache::spare.push_back(b);
+    }
+    devcache::leave();
   }
   template <typename T> hipError_t alloc(T** out, size_t count) {
+    size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    bytes = bytes < ((size_t)1 << 20) ? (bytes + 255) & ~(size_t)255 : (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16));
-    if (e == hipSuccess) ptrs.push_back(p);
+    size_t got = bytes;
+    {
+      std::lock_guard<std::mutex> g(devcache::mu);
+      size_t best = (size_t)-1;
+      for (size_t k = 0; k < devcache::spare.size(); ++k) {
+        const devcache::Block& b = devcache::spare[k];
+        if (b.device != device || b.bytes < bytes || b.bytes > bytes + bytes / 2 + ((size_t)1 << 20)) continue;
+        if (best == (size_t)-1 || b.bytes < devcache::spare[best].bytes) best = k;
+      }
+      if (best != (size_t)-1) {
+        p = devcache::spare[best].p;
+        got = devcache::spare[best].bytes;
+        devcache::spare.erase(devcache::spare.begin() + (long)best);
+      }
+    }
+    hipError_t e = hipSuccess;
+    if (!p) {
+      e = hipMalloc(&p, bytes);
+      if (e != hipSuccess) {  // memory short: what the cache holds goes back first
+        (void)hipGetLastError();
+        {
+          std::lock_guard<std::mutex> g(devcache::mu);
+          devcache::trim_locked();
+        }
+        e = hipMalloc(&p, bytes);
+      }
+    }
+    if (e == hipSuccess) {
+      static const bool poison = getenv("SIGAX_POOL_POISON") != nullptr;
+      if (poison) e = hipMemset(p, 0xA5, got);
+      live.push_back({p, got, device});
+    } else {
+      p = nullptr;
+    }
     *out = (T*)p;
     return e;
   }
   void release(void* p) {
-    for (void*& q : ptrs)
-      if (q == p) {
-        hipFree(q);
-        q = nullptr;
+    if (!p) return;
+    for (devcache::Block& q : live)
+      if (q.p == p) {
+        // whatever still reads or writes the block has been waited for by the callers (they synchronise before they
+        // release); the next user's work is ordered after it on the same (null) stream anyway
+        std::lock_guard<std::mutex> g(devcache::mu);
+        devcache::spare.push_back(q);
+        q.p = nullptr;
       }
   }
 };
+
+extern "C" void sigax_build_session(int open) {
+  if (open) devcache::enter();
+  else devcache::leave();
+}
 
 // ---- the packed text ------------------------------------------------------------------------------------------
 // symbol i occupies stream bits [3i, 3i+3), most significant first; codes: 0 end of text, 1 '$' (and non-ACGT), 2..5 ACGT

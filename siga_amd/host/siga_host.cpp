@@ -1843,7 +1843,12 @@ int sigah_index_build_dev(const char* seqs, const uint64_t* offs, uint64_t n_rea
     if (do_fwd && do_rev) return sigah_index_build(seqs, offs, n_reads, prefix, threads, err, errcap);
   }
   std::string p(prefix), e;
-  // the files of one strand are written on a side thread while the other strand is sorted
+  // the files of one strand are written on a side thread while the other strand is sorted; the second sort works in the
+  // device memory of the first
+  struct Session {
+    Session() { sigax_build_session(1); }
+    ~Session() { sigax_build_session(0); }
+  } session;
   std::thread writer;
   bool write_ok = true;
   auto join_writer = [&] {

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the builders' device workspace comes from a cache of reused blocks (sigax_index_build.hip: DevPool); in the tests every
+# block is filled with 0xA5 before it is handed out, so that nothing can lean on hipMalloc's cleared memory unnoticed
+os.environ.setdefault("SIGAX_POOL_POISON", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -16,8 +16,9 @@ with open(os.path.join(d, "reads.fa"), "wb") as f:
 PY
 cd /tmp && export TMPDIR=/tmp
 SIGA=$OLDPWD/siga_amd/lib/siga
-( cd $D && SIGA_TIMING=1 SIGAX_BUILD_TIMING=1 rocprofv3 --kernel-trace --stats -d $OUT/trace -o idx -- $SIGA index -t 64 reads.fa ) > $OUT/run.log 2>&1 || true
+( cd $D && SIGA_CLEAN_EXIT=1 SIGA_TIMING=1 SIGAX_BUILD_TIMING=1 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- $SIGA index -t 64 reads.fa ) > $OUT/run.log 2>&1 || true
 tail -30 $OUT/run.log
+ls -R $OUT/trace | head -20
 F=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 head -25 "$F" | cut -c1-200
 cp "$F" $OUT/kernel_stats.csv
