@@ -679,6 +679,32 @@ static void row_tables_now(sigax_index* ix) {
   start_row_tables(ix, true);  // (no-op when they were built, or tried, before)
 }
 
+// The index's own streams.  The finder is the critical path of a step: its stream gets the higher priority.
+// SIGAX_CU_SPLIT=K (an experiment, off by default): the finder's stream is confined to all but K of the CUs and the
+// filter/extract and tail streams to those K (CU mask bits interleave over XCDs and shader engines, so a run of mask
+// bits is an even share of every XCD) -- no priorities then, hipExtStreamCreateWithCUMask takes none.
+static hipError_t pipeline_streams(sigax_index* ix) {
+  const char* env = getenv("SIGAX_CU_SPLIT");
+  const int k = env ? atoi(env) : 0;
+  if (k > 0 && k < ix->n_cu) {
+    const int words = (ix->n_cu + 31) / 32;
+    std::vector<uint32_t> lo((size_t)words, 0u), hi((size_t)words, 0u);
+    for (int c = 0; c < ix->n_cu; ++c) (c < ix->n_cu - k ? lo : hi)[(size_t)c / 32] |= 1u << (c % 32);
+    hipError_t e = hipExtStreamCreateWithCUMask(&ix->s_find, (uint32_t)words, lo.data());
+    if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ix->s_fx, (uint32_t)words, hi.data());
+    if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ix->s_tail, (uint32_t)words, hi.data());
+    if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ix->s_ord, (uint32_t)words, hi.data());
+    return e;
+  }
+  int prio_least = 0, prio_greatest = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_find, hipStreamNonBlocking, prio_greatest);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_fx, hipStreamNonBlocking, prio_least);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_tail, hipStreamNonBlocking, prio_greatest);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_ord, hipStreamNonBlocking, prio_greatest);
+  return e;
+}
+
 // SIGAX_VERBOSE: where the time of opening an index goes
 struct OpenClock {
   bool on;
@@ -709,13 +735,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
   ix->cap_seen = new std::atomic<uint32_t>(0);
   if (hipDeviceGetAttribute(&ix->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ix->n_cu <= 0) ix->n_cu = 256;
   {
-    // the finder is the critical path of a step: its stream gets the higher priority
-    int prio_least = 0, prio_greatest = 0;
-    hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_find, hipStreamNonBlocking, prio_greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_fx, hipStreamNonBlocking, prio_least);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_tail, hipStreamNonBlocking, prio_greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_ord, hipStreamNonBlocking, prio_greatest);
+    const hipError_t e = pipeline_streams(ix);
     if (e != hipSuccess) {
       sigax_index_close(ix);
       return fail(SIGAX_E_DEVICE, "creating the pipeline streams: %s", hipGetErrorString(e));
@@ -942,12 +962,7 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
   ix->n_cu = src->n_cu;
   (void)hipDeviceGetAttribute(&ix->n_cu, hipDeviceAttributeMultiprocessorCount, device);
   {
-    int prio_least = 0, prio_greatest = 0;
-    hipError_t e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_find, hipStreamNonBlocking, prio_greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_fx, hipStreamNonBlocking, prio_least);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_tail, hipStreamNonBlocking, prio_greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&ix->s_ord, hipStreamNonBlocking, prio_greatest);
+    const hipError_t e = pipeline_streams(ix);
     if (e != hipSuccess) {
       sigax_index_close(ix);
       return fail(SIGAX_E_DEVICE, "creating the pipeline streams: %s", hipGetErrorString(e));
@@ -1567,6 +1582,8 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.read_end = re;
     fa.stage_bytes = 0;  // set by launch_find
     fa.two_step = (ix->st[0].gran2 && ix->st[1].gran2) ? 1u : 0u;
+    static const char* env_mu = getenv("SIGAX_FIND_MASK_UPPER");  // A/B aid: 0 = ten loads for every lane
+    fa.mask_upper = (env_mu && env_mu[0] == '0') ? 0u : 1u;
     {
       static const char* env_coop = getenv("SIGAX_FIND_COOP");
       static const char* env_cmin = getenv("SIGAX_COOP_MIN_SYMBOLS");

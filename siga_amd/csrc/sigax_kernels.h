@@ -49,6 +49,7 @@ struct FindArgs {
   uint32_t read_begin, read_end;     // this launch's sub-batch
   uint32_t stage_bytes;              // dynamic LDS per workgroup that may hold the workgroup's reads (set by launch_find)
   uint32_t two_step;                 // both strands carry the two-step table (u32 positions only)
+  uint32_t mask_upper;               // per-lane two-step finder: lanes whose upper position lies in the lower one's line do not load it again
   uint32_t coop, coop_stage_bytes;   // cooperative two-step finder (k_find_c2): lines staged through LDS; bytes for 64 reads
   uint32_t coop_grid;                // ... its grid cap (persistent workgroups walk the tiles), 0 = one workgroup per tile
   const uint32_t* perm;              // locality order of the batch: slot -> read (a permutation inside every sub-batch), or NULL

@@ -679,6 +679,32 @@ __device__ __forceinline__ void find_step2_loads(const void* base, u32 offa, u32
       : "v"(offa), "v"(offa_c), "v"(offb), "v"(offb_c), "s"(base)
       : "memory");
 }
+// The same with the upper position's five loads issued only for the lanes in `two` (a wave mask): five chains in six have
+// both positions in one line, and a load instruction costs the CU's L1 one tag lookup per ACTIVE lane -- the per-lane
+// finder's time goes with the CUs it runs on (tools/cu_split.sh), not with what the memory behind them can deliver.
+// The other lanes' b is undefined: the caller copies a.
+__device__ __forceinline__ void find_step2_loads_masked(const void* base, u32 offa, u32 offa_c, u32 offb, u32 offb_c, u64 two, Gran2& a,
+                                                        Gran2& b) {
+  u64 saved;
+  asm volatile(
+      "global_load_dwordx4 %0, %11, %15" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %1, %12, %15" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %2, %11, %15 offset:80" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %3, %11, %15 offset:96" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %4, %11, %15 offset:112" SIGAX_FIND_POLICY "\n\t"
+      "s_and_saveexec_b64 %10, %16\n\t"
+      "global_load_dwordx4 %5, %13, %15" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %6, %14, %15" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %7, %13, %15 offset:80" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %8, %13, %15 offset:96" SIGAX_FIND_POLICY "\n\t"
+      "global_load_dwordx4 %9, %13, %15 offset:112" SIGAX_FIND_POLICY "\n\t"
+      "s_mov_b64 exec, %10\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(a.s), "=&v"(a.pc), "=&v"(a.p5), "=&v"(a.p6), "=&v"(a.p7), "=&v"(b.s), "=&v"(b.pc), "=&v"(b.p5), "=&v"(b.p6),
+        "=&v"(b.p7), "=&s"(saved)
+      : "v"(offa), "v"(offa_c), "v"(offb), "v"(offb_c), "s"(base), "s"(two)
+      : "memory", "scc");
+}
 // The same through LDS, cooperatively (the finder for tables beyond the translation reach of per-lane gathers): eight
 // lanes fetch the eight 16-byte pieces of ONE 128-byte line with one instruction that writes LDS directly
 // (global_load_lds_dwordx4: destination = wave-uniform base + lane x 16), so a wave instruction touches 8 lines instead
@@ -1005,6 +1031,7 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
           pu = (up > nn || up < lo0) ? nn : up;
           two_lines = (pl >> 6) != (pu >> 6);
         }
+        const u64 two_mask = COOP ? 0ull : __ballot(two_lines);
         if (COOP) {
           // all 64 lanes take part in the loads (an idle chain asks for line 0)
           find_step2_dma(reinterpret_cast<const uint32_t*>(PI2), (u32)(pl >> 6), (u32)(pu >> 6), on ? c : 1u,
@@ -1013,7 +1040,12 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
         if (on) {
           if (!COOP) {
             const u32 oa = (u32)(pl >> 6) * 128u, ob = (u32)(pu >> 6) * 128u;
-            find_step2_loads(PI2, oa, oa + 16u * c, ob, ob + 16u * c, ga, gb);
+            if (A.mask_upper) {
+              find_step2_loads_masked(PI2, oa, oa + 16u * c, ob, ob + 16u * c, two_mask, ga, gb);
+              if (!two_lines) gb = ga;
+            } else {
+              find_step2_loads(PI2, oa, oa + 16u * c, ob, ob + 16u * c, ga, gb);
+            }
           }
           const Rank2 lr = rank2_from(ga, (u32)pl & 63u, c), ur = rank2_from(gb, (u32)pu & 63u, c);
           // counts in the index's position type; with 64-bit positions the line's counters are relative to its superblock
@@ -1910,6 +1942,39 @@ __device__ __forceinline__ void fm_rank5p(const FmRef& s, typename PosOf<WIDE>::
   v[0] = (P)pc - (A + C + G + T);
 }
 
+// Both ends of a range at once: getOcc(c, lo - 1) and getOcc(c, hi) as fm_rank5p(lo) and fm_rank5p(hi1 = hi + 1).  A
+// narrow range has both positions in one granule, and the lanes for which that is so do not load it a second time
+// (find_step2_loads_masked says what a load costs the CU).
+template <bool WIDE>
+__device__ __forceinline__ void fm_rank5p_pair(const FmRef& s, typename PosOf<WIDE>::type lo, typename PosOf<WIDE>::type hi1,
+                                               typename PosOf<WIDE>::type l[5], typename PosOf<WIDE>::type u[5]) {
+  typedef typename PosOf<WIDE>::type P;
+  const u64 pl = (u64)lo > s.n ? s.n : (u64)lo, pu = (u64)hi1 > s.n ? s.n : (u64)hi1;
+  const uint4* q = s.g + (pl >> 7) * 4;
+  uint4 k0 = q[0], k1 = q[1], k2 = q[2], k3 = q[3];
+  auto count = [&](u64 pc, P v[5]) {
+    const int r = (int)(pc & 127u);
+    u32 a = k0.x, c = k1.x, g = k2.x, t = k3.x;
+    chunk_count(k0, r, a, c, g, t);
+    chunk_count(k1, r - 32, a, c, g, t);
+    chunk_count(k2, r - 64, a, c, g, t);
+    chunk_count(k3, r - 96, a, c, g, t);
+    P A = a, C = c, G = g, T = t;
+    if (WIDE) {
+      const u64* sb = s.super + (pc >> SIGAX_SUPER_SHIFT) * 4;
+      A += (P)sb[0]; C += (P)sb[1]; G += (P)sb[2]; T += (P)sb[3];
+    }
+    v[1] = A; v[2] = C; v[3] = G; v[4] = T;
+    v[0] = (P)pc - (A + C + G + T);
+  };
+  count(pl, l);
+  if ((pu >> 7) != (pl >> 7)) {
+    const uint4* qu = s.g + (pu >> 7) * 4;
+    k0 = qu[0]; k1 = qu[1]; k2 = qu[2]; k3 = qu[3];
+  }
+  count(pu, u);
+}
+
 // LEAN (32-lane launch, 32-bit positions, irreducible mode, two-step tables present -- the common case): only the
 // single-group rounds served by the two-step line are compiled in; an item that needs anything else (a branch, a range
 // across lines, the exhaustive output order) is queued for the 64-lane launch, which has everything.  Without the rarely
@@ -2095,8 +2160,7 @@ struct GFx {
     const bool qcomp = (af_of(e.src) & 4u) != 0;
     P l[5] = {0, 0, 0, 0, 0}, u[5] = {0, 0, 0, 0, 0};
     if (mine) {
-      fm_rank5p<WIDE>(ix, e.c1lo, l);
-      fm_rank5p<WIDE>(ix, (P)(e.c1hi + 1), u);
+      fm_rank5p_pair<WIDE>(ix, e.c1lo, (P)(e.c1hi + 1), l, u);
     }
     sec_add(pop(alive) + pop(gballot(mine && ((u64)e.c1lo >> 7) != (((u64)e.c1hi + 1ull) >> 7))));
     // OverlapBlock::ext (overlap_builder.cpp:181-187), complemented for QUERYCOMP blocks
@@ -2969,8 +3033,7 @@ struct GFx {
             // capped.updateR('$'): Occ('$') at both ends of the range = position minus the A,C,G,T before it
             const FmRef ix = ext_index(e[k].src);
             P l[5], u[5];
-            fm_rank5p<WIDE>(ix, e[k].c1lo, l);
-            fm_rank5p<WIDE>(ix, (P)(e[k].c1hi + 1), u);
+            fm_rank5p_pair<WIDE>(ix, e[k].c1lo, (P)(e[k].c1hi + 1), l, u);
             E br = e[k];
             apply_updateR(br, 0, ix.which, l, u);
             out_put(nout + i, br);
@@ -3295,7 +3358,12 @@ __device__ __forceinline__ u32 kmer_occ(const FmRef& f, const FmTables& tb, cons
         auto ld = [](const uint4& v) { v4u w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; return w; };
         Gran2 ga, gb;
         ga.s = ld(ql[0]); ga.pc = ld(ql[r]); ga.p5 = ld(ql[5]); ga.p6 = ld(ql[6]); ga.p7 = ld(ql[7]);
-        gb.s = ld(qu[0]); gb.pc = ld(qu[r]); gb.p5 = ld(qu[5]); gb.p6 = ld(qu[6]); gb.p7 = ld(qu[7]);
+        // the upper position's line only for the lanes where it is another one (find_step2_loads_masked says why)
+        if ((pl >> 6) != (pu >> 6)) {
+          gb.s = ld(qu[0]); gb.pc = ld(qu[r]); gb.p5 = ld(qu[5]); gb.p6 = ld(qu[6]); gb.p7 = ld(qu[7]);
+        } else {
+          gb = ga;
+        }
         nsec += (pl >> 6) != (pu >> 6) ? 4u : 2u;
         const Rank2 rl = rank2_from(ga, (u32)pl & 63u, r), ru = rank2_from(gb, (u32)pu & 63u, r);
         P l2 = (P)(e == 1 ? rl.pa : e == 2 ? rl.pc : e == 3 ? rl.pg : rl.pt);
@@ -3313,8 +3381,7 @@ __device__ __forceinline__ u32 kmer_occ(const FmRef& f, const FmTables& tb, cons
       }
     }
     P l[5], u[5];
-    fm_rank5p<WIDE>(f, lo, l);            // getOcc(c, lower - 1)
-    fm_rank5p<WIDE>(f, (P)(hi + 1), u);   // getOcc(c, upper)
+    fm_rank5p_pair<WIDE>(f, lo, (P)(hi + 1), l, u);  // getOcc(c, lower - 1), getOcc(c, upper)
     nsec += ((u64)lo >> 7) != (((u64)hi + 1ull) >> 7) ? 2u : 1u;
     P lr = r == 0 ? l[0] : r == 1 ? l[1] : r == 2 ? l[2] : r == 3 ? l[3] : l[4];
     P ur = r == 0 ? u[0] : r == 1 ? u[1] : r == 2 ? u[2] : r == 3 ? u[3] : u[4];
