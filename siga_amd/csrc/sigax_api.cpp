@@ -98,8 +98,8 @@ struct sigax_index {
   // The row tables of an index of 2^26 symbols and more are built by a side thread while the caller goes on (at BASELINE
   // configs[1] 0.1 s: more than the whole one-batch `siga overlap` spends on the GPU); runs enqueued before they are ready
   // use the forms without them -- same bytes out.  0 none / published, 1 being built, 2 built: tab_st waits for publishing.
-  // Nor are they started before the index sees its second run: a one-batch job (the CLI at configs[1]) would pay for
-  // tables it never uses.  tab_plan = bytes of the tables still to be allocated (sigax_batch_size_hint leaves them free).
+  // Nor are they started before the index has been asked for as many reads as it holds (build_rowend): one pass of the
+  // CLI would pay for tables that cost it more than they save.  tab_plan = bytes of the tables still to be allocated (sigax_batch_size_hint leaves them free).
   std::thread* tab_thread;
   std::atomic<int>* tab_state;
   FmStrand tab_st[2];
@@ -1010,7 +1010,7 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
     sigax_index_close(ix);
     return rc;
   }
-  build_rowend(ix);  // plans its own row tables; built on this device when its second run starts
+  build_rowend(ix);  // plans its own row tables; built on this device once it is reused (or prepared)
   *out = ix;
   return SIGAX_OK;
 }
@@ -1952,7 +1952,7 @@ extern "C" int sigax_batch_size_hint(sigax_index* ix, uint32_t max_read_len, uin
   HIP_TRY(hipSetDevice(ix->device));
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  free_b = free_b > ix->tab_plan ? free_b - ix->tab_plan : 0;  // the row tables are allocated when the second run starts
+  free_b = free_b > ix->tab_plan ? free_b - ix->tab_plan : 0;  // the row tables are allocated later (build_rowend)
   // slots per chain as the runs will size them; before any run has finished, half the worst case (the first runs try a
   // third and repeat themselves with what their chains needed)
   const uint32_t mo = (flags & SIGAX_DUPLICATE) ? max_read_len : min_overlap;
