@@ -1564,7 +1564,8 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
   // (up to 4 GiB of text held; beyond that the records wait and are formatted at the end, 16 bytes against ~45 each).
   std::vector<std::vector<std::string>> ed_text;
   size_t ed_held = 0;
-  const size_t ed_hold_max = (size_t)4 << 30, ed_chunk = 16384;
+  const char* env_hold = getenv("SIGA_ED_HOLD_BYTES");  // (tests: 0 = every batch's records wait for the end)
+  const size_t ed_hold_max = env_hold ? (size_t)strtoull(env_hold, nullptr, 10) : (size_t)4 << 30, ed_chunk = 16384;
   const uint32_t* read_len = pre->lengths.data();
   auto format_edges = [&](const sigax_edge* e, uint64_t cnt, std::vector<std::string>* parts) {
     parts->assign((cnt + ed_chunk - 1) / ed_chunk, std::string());

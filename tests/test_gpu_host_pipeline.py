@@ -32,6 +32,12 @@ def test_batches_and_gpus_do_not_change_the_file(name, m, tmp_path, monkeypatch)
     n = len(fx.reads)
     for tag, br, gpus in (("b7", max(n // 7, 1), 1), ("g2", None, 2), ("g3b", max(n // 11, 1), 3)):
         assert _asqg(tmp_path, tag, fx, m, monkeypatch, batch_reads=br, gpus=gpus) == one, tag
+    # the ED text is formatted behind each batch while it fits the holding budget, at the end otherwise: same file
+    monkeypatch.setenv("SIGA_ED_HOLD_BYTES", "0")
+    assert _asqg(tmp_path, "late", fx, m, monkeypatch, batch_reads=max(n // 5, 1)) == one
+    monkeypatch.setenv("SIGA_ED_HOLD_BYTES", "2000")  # ... and when the budget runs out half way
+    assert _asqg(tmp_path, "mixed", fx, m, monkeypatch, batch_reads=max(n // 5, 1)) == one
+    monkeypatch.delenv("SIGA_ED_HOLD_BYTES")
 
 
 def test_index_clone_answers_like_the_original():
