@@ -167,7 +167,12 @@ static int read_file(const char* path, std::vector<uint8_t>* out) {
     return fail(SIGAX_E_IO, "cannot stat %s", path);
   }
   const size_t n = st.st_size > 0 ? (size_t)st.st_size : 0;
-  out->resize(n);
+  try {
+    out->resize(n);
+  } catch (...) {  // no exception crosses the C boundary
+    close(fd);
+    return fail(SIGAX_E_IO, "%s: no memory for its %zu bytes", path, n);
+  }
   const unsigned nt = n >= (64u << 20) ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u) : 1u;
   std::vector<int> shortread(nt, 0);
   auto slice = [&](unsigned k) {
@@ -226,7 +231,11 @@ static int parse_sai(const std::vector<uint8_t>& buf, const char* path, std::vec
   if (!next(p, e, &magic) || magic != 0xCACA) return fail(SIGAX_E_IO, "%s: bad .sai magic", path);
   if (!next(p, e, &strings) || !next(p, e, &elems)) return fail(SIGAX_E_IO, "%s: truncated .sai header", path);
   if (elems > (u64)(e - p)) return fail(SIGAX_E_IO, "%s: truncated .sai body", path);  // every line takes bytes
-  out->resize(elems);
+  try {
+    out->resize(elems);
+  } catch (...) {
+    return fail(SIGAX_E_IO, "%s: no memory for %llu rows", path, elems);
+  }
   // one chunk, or as many as there are threads: [cut[k], cut[k+1]) starts right after a line end
   unsigned nt = elems >= (1u << 18) ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
   if (p < e && *p == '\n') ++p;  // the header's own line end
