@@ -26,15 +26,6 @@
 
 namespace sigah {
 
-static std::atomic<bool> g_exits_soon{false};
-void set_process_exits_soon(bool on) { g_exits_soon.store(on); }
-bool process_exits_soon() { return g_exits_soon.load(); }
-// what a function would destroy on its way out is handed to this instead when the process is about to exit
-template <class T>
-static void leave_to_exit(T&& thing) {
-  if (process_exits_soon()) new typename std::decay<T>::type(std::move(thing));  // never freed: _exit follows
-}
-
 // ------------------------------------------------------------------------------------------------------
 // bzip2 input (Utils::ifstream, src/utils.cpp:50-126: ".bz2" goes through a bzip2 filter).  The image has libbz2's shared
 // library but not its header: the three entry points of its streaming interface are bound at run time (the bz_stream layout
@@ -1654,8 +1645,6 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
     return false;
   }
   pt.lap("ED lines + close");
-  leave_to_exit(std::move(pre));
-  leave_to_exit(std::move(ed_text));
   return true;
 }
 
@@ -1881,12 +1870,8 @@ int sigah_index_build_dev(const char* seqs, const uint64_t* offs, uint64_t n_rea
       return -1;
     }
     join_writer();
-    writer = std::thread([ix, p, rev, &write_ok] {  // the strand's two files side by side
-      bool ok_sai = true;
-      std::thread sai([&] { ok_sai = ix->writeSAI(p + (rev ? ".rsai" : ".sai")); });
-      const bool ok_bwt = ix->writeBWT(p + (rev ? ".rbwt" : ".bwt"));
-      sai.join();
-      if (!(ok_sai && ok_bwt)) write_ok = false;
+    writer = std::thread([ix, p, rev, &write_ok] {
+      if (!(ix->writeSAI(p + (rev ? ".rsai" : ".sai")) && ix->writeBWT(p + (rev ? ".rbwt" : ".bwt")))) write_ok = false;
     });
   }
   join_writer();
@@ -1901,8 +1886,7 @@ int sigah_index_build_dev(const char* seqs, const uint64_t* offs, uint64_t n_rea
 int sigah_index_file_dev(const char* reads_path, const char* prefix, int device, int threads, int do_fwd, int do_rev, char* err,
                          uint64_t errcap) {
   sigah::PhaseTimer pt;
-  std::unique_ptr<sigah::ReadStore> store(new sigah::ReadStore());
-  sigah::ReadStore& rs = *store;
+  sigah::ReadStore rs;
   if (!sigah::LoadReads(reads_path, &rs, sigah::host_threads((size_t)std::max(threads, 1)))) {
     if (err && errcap) snprintf(err, errcap, "Failed to open input file %s", reads_path);
     return -1;
@@ -1910,7 +1894,6 @@ int sigah_index_file_dev(const char* reads_path, const char* prefix, int device,
   pt.lap("parse reads");
   int rc = sigah_index_build_dev(rs.seqs.data(), rs.offs.data(), rs.size(), prefix, device, threads, do_fwd, do_rev, err, errcap);
   pt.lap("suffix sort + index files");
-  if (sigah::process_exits_soon()) (void)store.release();  // 3 GB of pages: left to the exit
   return rc;
 }
 

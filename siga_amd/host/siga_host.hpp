@@ -15,13 +15,6 @@
 
 namespace sigah {
 
-// The `siga` commands leave with _exit once their output files are closed.  With this set, the library's file-level
-// entry points and OverlapBuilder::build leave the big things they built -- the parsed reads (gigabytes of pages to
-// unmap), the formatted text -- to that exit instead of taking them apart first (20 M reads: 0.3 s of a 3 s run).
-// Off by default: a long-lived caller gets everything released as usual.
-void set_process_exits_soon(bool on);
-bool process_exits_soon();
-
 // src/kseq.h: DNASeq
 struct DNASeq {
   std::string name, comment, seq, quality;

@@ -213,8 +213,8 @@ static int run_overlap(int argc, char** argv) {
   if (help || argc - optind != 1) return overlap_help();
   std::string input = argv[optind];
   if (prefix.empty()) prefix = sigah::Utils::stem(input);
-  sigah::FMIndex& fmi = *new sigah::FMIndex();  // not torn down: main leaves with _exit (tens of GB of device memory to free otherwise)
-  sigah::OverlapBuilder& builder = *new sigah::OverlapBuilder(&fmi, prefix, !exhaustive, !norc);
+  sigah::FMIndex fmi;
+  sigah::OverlapBuilder builder(&fmi, prefix, !exhaustive, !norc);
   builder.setGPUs(gpus);
   const auto t_load = std::chrono::steady_clock::now();
   // the index goes to the GPU while the host threads parse the reads
@@ -279,7 +279,7 @@ static int run_rmdup(int argc, char** argv) {
   if (help || argc - optind != 1) return rmdup_help();
   std::string input = argv[optind];
   if (prefix.empty()) prefix = sigah::Utils::stem(input);
-  sigah::FMIndex& fmi = *new sigah::FMIndex();  // not torn down: main leaves with _exit
+  sigah::FMIndex fmi;
   if (!sigah::FMIndex::load(prefix, fmi, device)) {
     fprintf(stderr, "Failed to load FMIndex from %s: %s\n", input.c_str(), sigax_last_error());
     return -1;
@@ -356,7 +356,7 @@ static int run_correct(int argc, char** argv) {
     fprintf(stderr, "Failed to do error correction for reads %s: algorithm %s is not built\n", input.c_str(), algorithm.c_str());
     return -1;
   }
-  sigah::FMIndex& fmi = *new sigah::FMIndex();  // not torn down: main leaves with _exit
+  sigah::FMIndex fmi;
   if (!sigah::FMIndex::load(prefix, fmi, device)) {
     fprintf(stderr, "Failed to load FMIndex from %s: %s\n", prefix.c_str(), sigax_last_error());
     return -1;
@@ -371,7 +371,6 @@ static int run_correct(int argc, char** argv) {
 
 int main(int argc, char** argv) {
   if (argc < 2) return usage();
-  sigah::set_process_exits_soon(getenv("SIGA_CLEAN_EXIT") == nullptr);
   const auto t0 = std::chrono::steady_clock::now();
   std::string cmd = argv[1];
   int rc = 256;
