@@ -1870,8 +1870,12 @@ int sigah_index_build_dev(const char* seqs, const uint64_t* offs, uint64_t n_rea
       return -1;
     }
     join_writer();
-    writer = std::thread([ix, p, rev, &write_ok] {
-      if (!(ix->writeSAI(p + (rev ? ".rsai" : ".sai")) && ix->writeBWT(p + (rev ? ".rbwt" : ".bwt")))) write_ok = false;
+    writer = std::thread([ix, p, rev, &write_ok] {  // the strand's two files side by side
+      bool ok_sai = true;
+      std::thread sai([&] { ok_sai = ix->writeSAI(p + (rev ? ".rsai" : ".sai")); });
+      const bool ok_bwt = ix->writeBWT(p + (rev ? ".rbwt" : ".bwt"));
+      sai.join();
+      if (!(ok_sai && ok_bwt)) write_ok = false;
     });
   }
   join_writer();
