@@ -1194,6 +1194,8 @@ static CorrectArgs correct_args(sigax_index* ix, const unsigned char* d_seqs, co
   ensure_prefix_table(ix);
   ca.ptab = ix->d_ptab;
   ca.pk = ix->ptab_k;
+  ca.max_len = 0;  // unknown here: sigax_correct_batch sees the offsets and says
+  ca.only_deferred = 0;
   return ca;
 }
 
@@ -1236,6 +1238,8 @@ extern "C" int sigax_correct_batch(sigax_index* ix, const char* seqs, const char
   }
   CorrectArgs ca = correct_args(ix, d_seqs, d_quals, d_offs, n_reads, kmer_size, kmer_threshold, kmer_rounds, count_offset, d_out,
                                 d_valid, d_stat);
+  for (uint32_t i = 0; i < n_reads; ++i) ca.max_len = std::max<uint32_t>(ca.max_len, (uint32_t)std::min<u64>(offs[i + 1] - offs[i], 0xFFFFFFFFull));
+  ca.max_len = std::max(ca.max_len, 1u);
   launch_correct(ca, ix->wide, 0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());

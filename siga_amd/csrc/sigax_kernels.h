@@ -156,6 +156,8 @@ struct CorrectArgs {
   unsigned long long* dstat;  // [0] reads too long, [1] rank-table sectors asked for, [2] k-mer lookups (4 x u64)
   const void* ptab;           // intervals of all pk-mers (launch_prefix_build), or NULL
   uint32_t pk;
+  uint32_t max_len;           // upper bound of the batch's read lengths, 0 = unknown (launch_correct picks the kernel form)
+  uint32_t only_deferred;     // set by launch_correct: this launch takes the reads the small form marked (valid = 3)
 };
 void launch_correct(const CorrectArgs& a, bool wide, hipStream_t st);
 // table of the intervals of all pk-mers on strand s: prefix_table_bytes(wide, pk) bytes

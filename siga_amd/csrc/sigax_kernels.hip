@@ -3264,13 +3264,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? (LEA
 // -------------------------------------------------------------------------------------------------------
 #define CORRECT_LMAX 1024
 
-struct CorrectSh {
-  unsigned char seq[CORRECT_LMAX];    // current sequence (bytes as read)
-  unsigned char score[CORRECT_LMAX];  // phred per base (DNASeq::score, src/kseq.h:34-40)
-  unsigned char minph[CORRECT_LMAX];  // min phred of the window starting here (src/correct_processor.cpp:95-103)
-  unsigned char redo[CORRECT_LMAX];   // window must be recounted
-  unsigned short pref[CORRECT_LMAX + 1];  // solid windows before this one
-  u32 cnt[CORRECT_LMAX];              // occurrences of the window's k-mer (saturated)
+// One wave's read in LDS.  LMAX = the longest read the instantiation takes: 10 KB per wave at 1024 is what holds the
+// kernel to three workgroups per CU; reads of up to 512 bases run in a 5 KB form (four per CU with the registers held to
+// 128), longer ones are left to a second launch of the 1024 form (launch_correct).
+template <int LMAX>
+struct CorrectShT {
+  unsigned char seq[LMAX];    // current sequence (bytes as read)
+  unsigned char score[LMAX];  // phred per base (DNASeq::score, src/kseq.h:34-40)
+  unsigned char minph[LMAX];  // min phred of the window starting here (src/correct_processor.cpp:95-103)
+  unsigned char redo[LMAX];   // window must be recounted
+  unsigned short pref[LMAX + 1];  // solid windows before this one
+  u32 cnt[LMAX];              // occurrences of the window's k-mer (saturated)
 };
 
 // Interval::occurrences of the k-mer starting at `s` in sh.seq, with base `ovpos` replaced by rank `ovrank`.
@@ -3395,8 +3399,9 @@ __device__ __forceinline__ u32 kmer_occ(const FmRef& f, const FmTables& tb, cons
   return c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)c;
 }
 
-template <bool WIDE>
-__global__ __launch_bounds__(256) void k_correct(CorrectArgs A) {
+template <bool WIDE, int LMAX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMAX <= 512 ? 4 : 3))) void k_correct(CorrectArgs A) {
+  typedef CorrectShT<LMAX> CorrectSh;
   __shared__ FmTables tb;
   __shared__ CorrectSh shm[4];
   __shared__ Find2TablesT<WIDE> t2s;
@@ -3415,8 +3420,17 @@ __global__ __launch_bounds__(256) void k_correct(CorrectArgs A) {
     const u64 b0 = A.offs[rd];
     const u32 n = uni((u32)(A.offs[rd + 1] - b0));
     u32 valid = 0;
-    if (n > CORRECT_LMAX) {
-      if (lane == 0) { A.valid[rd] = 2; atomicAdd(&A.dstat[0], 1ull); }
+    if (A.only_deferred && A.valid[rd] != 3) continue;  // the second launch: what the first one left
+    if (n > (u32)LMAX) {
+      // too long for this form: for the 1024 form when another launch follows, for good otherwise
+      if (lane == 0) {
+        if (LMAX < CORRECT_LMAX) {
+          A.valid[rd] = 3;
+        } else {
+          A.valid[rd] = 2;
+          atomicAdd(&A.dstat[0], 1ull);
+        }
+      }
       continue;
     }
     for (u32 i = lane; i < n; i += 64) {
@@ -3725,12 +3739,22 @@ void launch_suffix_order_check(const FmStrand& s, const u32* sai, u32* isai_tmp,
   hipLaunchKernelGGL(k_suffix_order_check, dim3(nblk(s.n - 1, 256)), dim3(256), 0, st, s, sai, (const u32*)isai_tmp, read_len, n_strings, bad3);
 }
 
-void launch_correct(const CorrectArgs& a, bool wide, hipStream_t st) {
-  if (a.n_reads == 0) return;
-  unsigned g = (unsigned)((a.n_reads + 3) / 4);
+void launch_correct(const CorrectArgs& a0, bool wide, hipStream_t st) {
+  if (a0.n_reads == 0) return;
+  unsigned g = (unsigned)((a0.n_reads + 3) / 4);
   if (g > 4096) g = 4096;
-  if (wide) hipLaunchKernelGGL(k_correct<true>, dim3(g), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k_correct<false>, dim3(g), dim3(256), 0, st, a);
+  CorrectArgs a = a0;
+  a.only_deferred = 0;
+  // reads of up to 512 bases in the small form; it marks longer ones (valid = 3) for the 1024 form, which is launched
+  // behind it unless the caller knows there are none (max_len: an upper bound of the batch's read lengths, 0 = unknown)
+  if (a0.max_len == 0 || a0.max_len <= 512) {
+    if (wide) hipLaunchKernelGGL((k_correct<true, 512>), dim3(g), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_correct<false, 512>), dim3(g), dim3(256), 0, st, a);
+    if (a0.max_len != 0) return;
+    a.only_deferred = 1;
+  }
+  if (wide) hipLaunchKernelGGL((k_correct<true, CORRECT_LMAX>), dim3(g), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_correct<false, CORRECT_LMAX>), dim3(g), dim3(256), 0, st, a);
 }
 
 static unsigned find_lds_budget() {

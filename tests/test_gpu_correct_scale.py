@@ -25,3 +25,71 @@ def test_correct_at_scale_matches_oracle(k, N, tmp_path):
     host.correct_file(fa, prefix, str(tmp_path / "g.ec"), k=k)
     assert open(tmp_path / "g.ec", "rb").read() == open(tmp_path / "o.ec", "rb").read()
     assert st["written"] > 0.9 * N and st["changed"] > 0.5 * N
+
+
+def test_correct_reads_of_all_lengths_in_both_kernel_forms(tmp_path):
+    """k_correct comes in two forms: reads of up to 512 bases in a 5 KB-per-wave form that runs five waves per SIMD, longer
+    ones (up to 1024) in the 10 KB form.  A batch whose longest read the caller knows (sigax_correct_batch: the host path) gets
+    one launch of the right form; a device-resident batch (sigax_correct_device: offsets on the device) gets the small form
+    followed by the large one for the reads the small one marked.  Reads of 40..1000 bases with substitutions: the host path
+    against the oracle, the device path against the host path; a read of 1100 bases is refused by both."""
+    import ctypes as C
+    import torch
+    from oracle import pyoracle as po
+    from siga_amd import _lib, host
+    from siga_amd.overlap import FMIndexPair
+    rng = np.random.default_rng(21)
+    G = 60000
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=G)
+    lens = np.concatenate([rng.integers(40, 1001, size=1500), [512, 513, 1000, 1024, 31, 30]])
+    reads = []
+    for L in lens:
+        p = int(rng.integers(0, G - L))
+        r = genome[p:p + L].copy()
+        flips = rng.random(L) < 0.01
+        r[flips] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(flips.sum()))
+        reads.append(r)
+    # coverage for the k-mer counts: every read twice more, error-free
+    clean = [genome[int(p):int(p) + 300].copy() for p in rng.integers(0, G - 300, size=6000)]
+    allr = reads + clean
+    fa = str(tmp_path / "reads.fa")
+    with open(fa, "wb") as f:
+        f.write(b"".join(b">r%d\n%s\n" % (i, bytes(r)) for i, r in enumerate(allr)))
+    prefix = str(tmp_path / "reads")
+    host.index_file_gpu(fa, prefix)
+    st = po.correct(po.Index.load(prefix + ".bwt"), fa, str(tmp_path / "o.ec"), k=31)
+    host.correct_file(fa, prefix, str(tmp_path / "g.ec"), k=31)
+    want = open(tmp_path / "o.ec", "rb").read()
+    assert open(tmp_path / "g.ec", "rb").read() == want and st["changed"] > 500
+    # the device-resident call on the same reads: small form, then the large one for what it marked
+    pair = FMIndexPair.load(prefix, with_sai=False)
+    try:
+        L = _lib.lib()
+        seqs = np.concatenate(allr)
+        offs = np.concatenate([[0], np.cumsum([len(r) for r in allr])]).astype(np.uint64)
+        n = len(allr)
+        out_b = np.zeros(len(seqs), dtype=np.uint8)
+        val_b = np.zeros(n, dtype=np.uint8)
+        assert L.sigax_correct_batch(pair.handle, seqs.tobytes(), None, offs.ctypes.data, n, 31, 3, 10, 1, out_b.ctypes.data,
+                                     val_b.ctypes.data) == 0, _lib.last_error()
+        dev = torch.device("cuda", 0)
+        d_seqs = torch.from_numpy(seqs).to(dev)
+        d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+        d_out = torch.zeros(len(seqs), dtype=torch.uint8, device=dev)
+        d_val = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
+        d_stat = torch.zeros(4, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        assert L.sigax_correct_device(pair.handle, d_seqs.data_ptr(), None, d_offs.data_ptr(), n, 31, 3, 10, 1, d_out.data_ptr(),
+                                      d_val.data_ptr(), d_stat.data_ptr(), None) == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        assert d_out.cpu().numpy().tobytes() == out_b.tobytes()
+        assert d_val[:n].cpu().numpy().tobytes() == val_b.tobytes() and int(d_stat[0]) == 0
+        # beyond the large form
+        big = np.concatenate([seqs[:1100], seqs[:200]])
+        boffs = np.array([0, 1100, 1300], dtype=np.uint64)
+        o2 = np.zeros(1300, dtype=np.uint8)
+        v2 = np.zeros(2, dtype=np.uint8)
+        assert L.sigax_correct_batch(pair.handle, big.tobytes(), None, boffs.ctypes.data, 2, 31, 3, 10, 1, o2.ctypes.data, v2.ctypes.data) != 0
+        assert "longer than" in _lib.last_error() and v2[0] == 2
+    finally:
+        pair.close()
