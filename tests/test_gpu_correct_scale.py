@@ -34,7 +34,6 @@ def test_correct_reads_of_all_lengths_in_both_kernel_forms(tmp_path):
     followed by the large one for the reads the small one marked.  Reads of 40..1000 bases with substitutions: the host path
     against the oracle, the device path against the host path; a read of 1100 bases is refused by both."""
     import ctypes as C
-    import torch
     from oracle import pyoracle as po
     from siga_amd import _lib, host
     from siga_amd.overlap import FMIndexPair
@@ -72,18 +71,35 @@ def test_correct_reads_of_all_lengths_in_both_kernel_forms(tmp_path):
         val_b = np.zeros(n, dtype=np.uint8)
         assert L.sigax_correct_batch(pair.handle, seqs.tobytes(), None, offs.ctypes.data, n, 31, 3, 10, 1, out_b.ctypes.data,
                                      val_b.ctypes.data) == 0, _lib.last_error()
-        dev = torch.device("cuda", 0)
-        d_seqs = torch.from_numpy(seqs).to(dev)
-        d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
-        d_out = torch.zeros(len(seqs), dtype=torch.uint8, device=dev)
-        d_val = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
-        d_stat = torch.zeros(4, dtype=torch.int64, device=dev)
-        torch.cuda.synchronize()
-        assert L.sigax_correct_device(pair.handle, d_seqs.data_ptr(), None, d_offs.data_ptr(), n, 31, 3, 10, 1, d_out.data_ptr(),
-                                      d_val.data_ptr(), d_stat.data_ptr(), None) == 0, _lib.last_error()
-        torch.cuda.synchronize()
-        assert d_out.cpu().numpy().tobytes() == out_b.tobytes()
-        assert d_val[:n].cpu().numpy().tobytes() == val_b.tobytes() and int(d_stat[0]) == 0
+        # device buffers through the HIP runtime the library itself runs on (torch brings a second copy of it)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        hip.hipFree.argtypes = [C.c_void_p]
+
+        def dbuf(nbytes, src=None):
+            q = C.c_void_p()
+            assert hip.hipMalloc(C.byref(q), nbytes) == 0
+            if src is not None:
+                assert hip.hipMemcpy(q, src.ctypes.data, nbytes, 1) == 0  # host to device
+            else:
+                assert hip.hipMemset(q, 0, nbytes) == 0
+            return q
+
+        d_seqs, d_offs = dbuf(len(seqs) + 16, None), dbuf(offs.nbytes, offs)
+        assert hip.hipMemcpy(d_seqs, seqs.ctypes.data, len(seqs), 1) == 0
+        d_out, d_val, d_stat = dbuf(len(seqs) + 16), dbuf(n + 16), dbuf(32)
+        assert hip.hipDeviceSynchronize() == 0
+        assert L.sigax_correct_device(pair.handle, d_seqs, None, d_offs, n, 31, 3, 10, 1, d_out, d_val, d_stat, None) == 0, _lib.last_error()
+        assert hip.hipDeviceSynchronize() == 0
+        out_d, val_d, stat_d = np.zeros(len(seqs), dtype=np.uint8), np.zeros(n, dtype=np.uint8), np.zeros(4, dtype=np.uint64)
+        assert hip.hipMemcpy(out_d.ctypes.data, d_out, len(seqs), 2) == 0 and hip.hipMemcpy(val_d.ctypes.data, d_val, n, 2) == 0
+        assert hip.hipMemcpy(stat_d.ctypes.data, d_stat, 32, 2) == 0
+        for q in (d_seqs, d_offs, d_out, d_val, d_stat):
+            hip.hipFree(q)
+        assert out_d.tobytes() == out_b.tobytes()
+        assert val_d.tobytes() == val_b.tobytes() and int(stat_d[0]) == 0
         # beyond the large form
         big = np.concatenate([seqs[:1100], seqs[:200]])
         boffs = np.array([0, 1100, 1300], dtype=np.uint64)
