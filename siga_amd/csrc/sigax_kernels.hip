@@ -3263,6 +3263,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? (LEA
 // reference's left-to-right scan would take first is applied.
 // -------------------------------------------------------------------------------------------------------
 #define CORRECT_LMAX 1024
+#ifndef SIGAX_CORRECT_WAVES
+#define SIGAX_CORRECT_WAVES 6  // waves per SIMD the small form is held to at least: 80 registers, no scratch (4: 85 registers, five waves, 38.5 M reads/s; 6: 41.0 M)
+#endif
 
 // One wave's read in LDS.  LMAX = the longest read the instantiation takes: 10 KB per wave at 1024 is what holds the
 // kernel to three workgroups per CU; reads of up to 512 bases run in a 5 KB form (four per CU with the registers held to
@@ -3400,7 +3403,8 @@ __device__ __forceinline__ u32 kmer_occ(const FmRef& f, const FmTables& tb, cons
 }
 
 template <bool WIDE, int LMAX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMAX <= 512 ? 4 : 3))) void k_correct(CorrectArgs A) {
+// (64-bit positions: held to four, which gives 96 registers and five waves; six would spill)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMAX <= 512 ? (WIDE ? 4 : SIGAX_CORRECT_WAVES) : 3))) void k_correct(CorrectArgs A) {
   typedef CorrectShT<LMAX> CorrectSh;
   __shared__ FmTables tb;
   __shared__ CorrectSh shm[4];
