@@ -217,27 +217,41 @@ inline bool match_pays(const unsigned char* in, size_t s, size_t run) {
   }
   return quarter_bits > 52u;
 }
+// The line a line is compared with: the nearest of the four before it that starts with the same byte (the record above in
+// FASTA -- header against header, two lines up -- and FASTQ, four lines up; in ASQG text every line starts like the one
+// before), else the line before.
 inline void find_matches(const unsigned char* in, size_t n, std::vector<Match>* ms) {
   ms->clear();
   if (n >= ((size_t)1 << 32)) return;  // positions are kept in 32 bits (the writer's blocks are 1 MiB): literals only
-  Fields fa, fb;
-  Fields *cur = &fa, *prev = &fb;
-  prev->n = 0;
+  Fields ring[5];
+  int have = 0;   // lines before this one that are in the ring (at most 4)
+  int cur = 0;    // ring slot of the current line
   size_t covered = 0;  // text below this position is inside a match already
   for (size_t ls = 0; ls < n;) {
-    const size_t le = split_line(in, n, ls, cur);
-    const int nf = std::min(cur->n, prev->n);
+    Fields& c = ring[cur];
+    const size_t le = split_line(in, n, ls, &c);
+    const Fields* ref = nullptr;
+    for (int back = 1; back <= have; ++back) {
+      const Fields& f = ring[(cur + 5 - back) % 5];
+      if (in[f.at[0]] == in[ls]) {
+        ref = &f;
+        break;
+      }
+    }
+    if (!ref && have) ref = &ring[(cur + 4) % 5];
+    const int nf = ref ? std::min(c.n, ref->n) : 0;
     for (int j = 0; j < nf; ++j) {
-      const size_t s = cur->at[j];
+      const size_t s = c.at[j];
       if (s < covered) continue;
-      const size_t src = prev->at[j], d = s - src;
+      const size_t src = ref->at[j], d = s - src;
       if (d > 32768) break;
       const size_t run = common_run(in, n, s, src);
       if (!match_pays(in, s, run)) continue;
       ms->push_back({(uint32_t)s, (uint32_t)run, (uint32_t)d});
       covered = s + run;
     }
-    std::swap(cur, prev);
+    cur = (cur + 1) % 5;
+    if (have < 4) ++have;
     ls = le + 1;
   }
 }
