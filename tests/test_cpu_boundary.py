@@ -326,7 +326,7 @@ def test_line_coder_blocks_inflate_to_the_text(tmp_path):
     line's same column, one dynamic Huffman code per block, CRC-32 by carry-less multiplication) instead of zlib.  Whatever
     the text looks like -- VT lines with names that grow a digit, FASTA, lines longer than deflate's 32 KiB window, one
     endless line, a single base repeated (one literal symbol), runs longer than the longest match, no line end at the end,
-    block edges inside a line -- gzip must give the text back, as ONE member, and the bytes must not depend on how the text
+    block edges inside a line, FASTQ records (lines matched four lines up) -- gzip must give the text back, as ONE member, and the bytes must not depend on how the text
     was handed over.  SIGA_GZIP_LEVEL=6 sends everything through zlib (the reference's setting) and reads back the same."""
     import gzip
     import zlib
@@ -345,6 +345,7 @@ def test_line_coder_blocks_inflate_to_the_text(tmp_path):
         "vt": b"".join(b"VT\tr%d\t%s\tSS:i:%d\n" % (i, read(i), i % 7 == 0) for i in range(9_990, 30_000)),
         "vt_ragged": b"".join(b"VT\tread/%d\t%s\tSS:i:0\n" % (i, read(i, 30 + (i * 37) % 220)) for i in range(20_000)),
         "fasta": b"".join(b">r%d some comment\n%s\n" % (i, read(i)) for i in range(20_000)),
+        "fastq": b"".join(b"@r%d/1\n%s\n+\n%s\n" % (i, read(i), bytes(33 + (j * 7 + i) % 40 for j in range(150))) for i in range(12_000)),
         "long_lines": b"".join(b">c%d\n%s\n" % (i, bases(40_000 + 1000 * i)) for i in range(12)),
         "one_line": bases(1_500_000),
         "same_base": b"A" * 2_200_000,
