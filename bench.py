@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--min-overlap", type=int, default=45)
     ap.add_argument("--seed", type=int, default=None, help="default: 1 at N = 1 (configs[1]), 2 at N > 1 (configs[2])")
-    ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU restatement (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=400000, help="reads timed on the CPU restatement (0 = skip); 400 k = 4 s on 128 threads")
     ap.add_argument("--workdir", default=None)
     ap.add_argument("--subbatches", type=int, default=1,
                     help="sub-batches per step (0 = library default for one batch at a time: 4 at this size); sub-batch i's "
