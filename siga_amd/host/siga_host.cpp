@@ -1198,25 +1198,41 @@ static void write_vertex(std::string& o, std::string_view name, std::string_view
 
 // EdgeRecord << (src/asqg.cpp:228-237, src/coord.cpp:4-80) with OverlapBlock::overlap's coordinates
 // (src/overlap_builder.cpp:158-175)
-static void write_edge(std::string& o, const sigax_edge& e, const ReadStore& reads, const uint32_t* lengths) {
+// ... written through a raw pointer: the caller has room for the two names and 3 + 2 + 6 x 21 + 4 bytes more (22 M lines at
+// BASELINE configs[2]: the capacity check of every append was a third of the formatting)
+static inline char* put_u64(char* p, uint64_t v) {
+  char tmp[24];
+  int n = 0;
+  do {
+    tmp[n++] = (char)('0' + v % 10);
+    v /= 10;
+  } while (v);
+  while (n) *p++ = tmp[--n];
+  return p;
+}
+static const size_t kEdgeLineExtra = 3 + 2 + 6 * 21 + 4;
+static char* write_edge(char* p, const sigax_edge& e, const ReadStore& reads, const uint32_t* lengths) {
   const std::string_view qn = reads.name(e.query), tn = reads.name(e.target);
   uint64_t ql = lengths[e.query], tl = lengths[e.target], len = e.length;
   uint64_t s0 = ql - len, e0 = ql - 1, s1 = 0, e1 = len - 1;
   if (e.af & 1u) { uint64_t t = s0; s0 = ql - e0 - 1; e0 = ql - t - 1; }
   if (e.af & 2u) { uint64_t t = s1; s1 = tl - e1 - 1; e1 = tl - t - 1; }
-  o += "ED\t";
-  o.append(qn.data(), qn.size());
-  o += ' ';
-  o.append(tn.data(), tn.size());
-  o += ' ';
-  append_u64(o, s0); o += ' ';
-  append_u64(o, e0); o += ' ';
-  append_u64(o, ql); o += ' ';
-  append_u64(o, s1); o += ' ';
-  append_u64(o, e1); o += ' ';
-  append_u64(o, tl); o += ' ';
-  o += (e.af & 4u) ? '1' : '0';
-  o += " 0\n";
+  *p++ = 'E'; *p++ = 'D'; *p++ = '\t';
+  memcpy(p, qn.data(), qn.size());
+  p += qn.size();
+  *p++ = ' ';
+  memcpy(p, tn.data(), tn.size());
+  p += tn.size();
+  *p++ = ' ';
+  p = put_u64(p, s0); *p++ = ' ';
+  p = put_u64(p, e0); *p++ = ' ';
+  p = put_u64(p, ql); *p++ = ' ';
+  p = put_u64(p, s1); *p++ = ' ';
+  p = put_u64(p, e1); *p++ = ' ';
+  p = put_u64(p, tl); *p++ = ' ';
+  *p++ = (e.af & 4u) ? '1' : '0';
+  *p++ = ' '; *p++ = '0'; *p++ = '\n';
+  return p;
 }
 
 
@@ -1567,12 +1583,15 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
   const char* env_hold = getenv("SIGA_ED_HOLD_BYTES");  // (tests: 0 = every batch's records wait for the end)
   const size_t ed_hold_max = env_hold ? (size_t)strtoull(env_hold, nullptr, 10) : (size_t)4 << 30, ed_chunk = 16384;
   const uint32_t* read_len = pre->lengths.data();
+  uint32_t max_name = 0;
+  for (uint32_t l : reads.name_len) max_name = std::max(max_name, l);
   auto format_edges = [&](const sigax_edge* e, uint64_t cnt, std::vector<std::string>* parts) {
     parts->assign((cnt + ed_chunk - 1) / ed_chunk, std::string());
     parallel_for(parts->size(), nt, [&](size_t c) {
       const uint64_t cb = c * ed_chunk, ce = std::min<uint64_t>(cnt, cb + ed_chunk);
       std::string& o = (*parts)[c];
-      o.reserve((ce - cb) * 56);
+      o.resize((ce - cb) * (2 * (size_t)max_name + kEdgeLineExtra));  // room for the longest line there can be, times the lines
+      char* w = &o[0];
       // a target's name is three dependent misses away (header offset, name length, the bytes in the file image):
       // asked for sixteen and eight edges ahead
       for (uint64_t i = cb; i < ce; ++i) {
@@ -1583,8 +1602,10 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
           __builtin_prefetch(&read_len[t]);
         }
         if (i + 8 < ce) __builtin_prefetch(reads.file.data() + reads.head_off[e[i + 8].target]);
-        write_edge(o, e[i], reads, read_len);
+        w = write_edge(w, e[i], reads, read_len);
       }
+      o.resize((size_t)(w - &o[0]));
+      o.shrink_to_fit();  // the text may be held until the last batch is through: not with three times its size in reserve
     });
   };
   const size_t vt_chunk = 4096;
