@@ -410,3 +410,25 @@ def test_host_read_table_ranks_names_in_string_order(tmp_path):
         order = {nm: k for k, nm in enumerate(sorted(set(names)))}
         assert got[:, 0].tolist() == [order[nm] for nm in names]
         assert got[:, 1].tolist() == lens.tolist()
+
+
+@pytest.mark.slow
+def test_sai_writer_slices_join_up(tmp_path):
+    """The .sai text (src/suffix_array.cpp:17-44: magic, strings, elems, then "<read> 0" per row) is formatted in slices of
+    2^20 rows on several threads and written in order: on a read set of more than 2^20 reads the file must hold every read
+    once, in rows of that exact form, and the library must read it back (sizes agree with the .bwt)."""
+    n, L = (1 << 20) + 12345, 12
+    rng = np.random.default_rng(8)
+    reads = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(n, L))
+    fa = str(tmp_path / "many.fa")
+    with open(fa, "wb") as f:
+        f.write(b"".join(b">%d\n%s\n" % (i, bytes(r)) for i, r in enumerate(reads)))
+    prefix = str(tmp_path / "many")
+    host.index_file(fa, prefix, threads=4)
+    for ext in (".sai", ".rsai"):
+        lines = open(prefix + ext, "rb").read().split(b"\n")
+        assert lines[:3] == [b"51914", b"%d" % n, b"%d" % n] and lines[-1] == b"" and len(lines) == n + 4
+        rows = np.array([l.split(b" ") for l in lines[3:-1]])
+        assert rows.shape == (n, 2) and np.all(rows[:, 1] == b"0")
+        ids = rows[:, 0].astype(np.int64)
+        assert np.array_equal(np.sort(ids), np.arange(n))
