@@ -440,7 +440,15 @@ static void parse_fastq(const char* base, size_t e, ChunkOut* o) {
 }
 
 static bool LoadReads(const std::string& path, ReadStore* rs, unsigned nt) {
+  const bool timing = getenv("SIGA_TIMING_LOADER") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    const auto t = std::chrono::steady_clock::now();
+    if (timing) fprintf(stderr, "[siga]     loader: %-20s %7.3f s\n", what, std::chrono::duration<double>(t - t_last).count());
+    t_last = t;
+  };
   if (!slurp(path, &rs->file)) return false;
+  lap("file image");
   const char* base = rs->file.data();
   const size_t size = rs->file.size();
   if (size == 0 || (base[0] != '@' && base[0] != '>')) return false;  // DNASeqReaderFactory::create (src/kseq.cpp:127-138)
@@ -483,6 +491,7 @@ static bool LoadReads(const std::string& path, ReadStore* rs, unsigned nt) {
       parse_fasta_chunk(base, 0, size, true, &outs[0]);
     }
   }
+  lap("chunks parsed");
   // concatenate up to the point where the serial reader would have given up
   size_t nchunks = 0, n = 0, nb = 0;
   for (; nchunks < outs.size(); ++nchunks) {
@@ -522,6 +531,7 @@ static bool LoadReads(const std::string& path, ReadStore* rs, unsigned nt) {
     if (!o.seqs.empty()) memcpy(rs->seqs.data() + bbase[c], o.seqs.data(), o.seqs.size());
   });
   rs->offs[n] = nb;
+  lap("joined");
   return true;
 }
 
@@ -2047,7 +2057,10 @@ int64_t sigah_parse_file(const char* path, int mode, const char* out_path, int t
   FILE* f = fopen(out_path, "wb");
   if (!f) return -1;
   int64_t n = -1;
-  if (mode == 2) {
+  if (mode == 3) {  // parse only (timing aid): nothing written
+    sigah::ReadStore rs;
+    if (sigah::LoadReads(path, &rs, (unsigned)std::max(threads, 1))) n = (int64_t)rs.size();
+  } else if (mode == 2) {
     sigah::ReadStore rs;
     if (sigah::LoadReads(path, &rs, (unsigned)std::max(threads, 1))) {
       std::vector<uint32_t> lengths, ranks;
