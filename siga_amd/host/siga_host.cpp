@@ -258,13 +258,31 @@ struct RawChars {
   size_t size() const { return n; }
 };
 
+// ... and the per-read tables likewise (every entry is written by the loader's join, on its threads)
+template <class T>
+struct RawVec {
+  std::unique_ptr<T[]> p;
+  size_t n = 0;
+  void resize(size_t k) {  // contents undefined
+    p.reset(new T[k ? k : 1]);
+    n = k;
+  }
+  T* data() { return p.get(); }
+  const T* data() const { return p.get(); }
+  size_t size() const { return n; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  const T* begin() const { return p.get(); }
+  const T* end() const { return p.get() + n; }
+};
+
 struct ReadStore {
   FileImage file;
   RawChars seqs;
-  std::vector<uint64_t> offs;                 // n + 1
-  std::vector<uint64_t> head_off;             // raw header (after '>' / '@'), a span of `file`
-  std::vector<uint32_t> head_len, name_len;   // name = head[0, name_len); comment = head[name_len + 1, head_len)
-  std::vector<uint64_t> qual_off;             // FASTQ: span of `file`, seq length long
+  RawVec<uint64_t> offs;                 // n + 1
+  RawVec<uint64_t> head_off;             // raw header (after '>' / '@'), a span of `file`
+  RawVec<uint32_t> head_len, name_len;   // name = head[0, name_len); comment = head[name_len + 1, head_len)
+  RawVec<uint64_t> qual_off;             // FASTQ: span of `file`, seq length long
   bool fastq = false;
   size_t size() const { return head_off.size(); }
   std::string_view name(size_t i) const { return std::string_view(file.data() + head_off[i], name_len[i]); }
