@@ -42,6 +42,27 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def kernels_sha():
+    """sha1 of the kernel sources: a PMC figure in profiles/traffic.json only counts for the kernels it was measured on"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("sigax_kernels.hip", "fm_layout.h"):
+        h.update(open(os.path.join(ROOT, "siga_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def traffic_entry(key):
+    """hbm_bytes_per_launch of profiles/traffic.json for `key`, or None when there is none or it was measured on other
+    kernel sources than the ones in the tree (entries carry the sha of the sources they were collected with)"""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+    except Exception:
+        return None
+    if not e or e.get("kernels_sha") != kernels_sha():
+        return None
+    return e.get("hbm_bytes_per_launch")
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +96,12 @@ def parse_args():
     ap.add_argument("--reuse-order", action="store_true",
                     help="A/B aid: set the reads once, so that the locality order is computed in the warm-up only (what round 2 timed)")
     ap.add_argument("--kmer", type=int, default=31, help="--workload correct: k-mer size (31 = code default, 41 = example script)")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the end_to_end leg (N = 1, error-free reads of at most 2 M: the reads as FASTA through the `siga overlap` "
+                         "CLI in a child process, after the timed region)")
+    ap.add_argument("--upload-steps", type=int, default=30,
+                    help="steps of the upload_inclusive leg after the timed region (every step's reads come from pinned host memory "
+                         "through sigax_batch_upload); 0 = skip")
     ap.add_argument("--error-rate", type=float, default=None,
                     help="substitutions per base: --workload correct default 0.01; --workload overlap default 0 (the BASELINE configs are "
                          "error-free), > 0 shows what uncorrected reads cost (branches in the extraction)")
@@ -189,6 +216,8 @@ def bench_overlap(args):
     info = pair.info()
     # ReadInfo{name,length}: names r<i>; rank of a name under std::string operator<
     pair.set_reads(np.full(n_total, L, dtype=np.uint32), rank_of_r_names(n_total))
+    # the index stays open for every step: row tables (set_reads did that) and the finder's deep start table for this -m
+    pair.prepare_overlap(args.min_overlap)
     log("index on GPU: %.1f MB, wide=%d (%.1f s since start)" % (info["device_bytes"] / 1e6, info["wide"], time.time() - t0))
 
     n_local = hi - lo
@@ -285,10 +314,16 @@ def bench_overlap(args):
                     land(j, t if (t is None or t.is_cuda) else None)
                 pending.append((i, gather_edges_async(local)))
 
-    def submit(k):
+    h_seqs = h_offs = None  # upload_inclusive leg: the shard in pinned host memory
+
+    def submit(k, upload=False):
         i = k % depth
         complete(i)  # the batch's previous run must be done before its workspace is reused
-        if not args.reuse_order:
+        if upload:
+            # what a product batch pays: the reads leave (pinned) host memory inside the step
+            rc = lib.sigax_batch_upload(batches[i], C.c_char_p(h_seqs.data_ptr()), h_offs.ctypes.data, n_local, C.c_void_p(streams[i].cuda_stream))
+            assert rc == 0, _lib.last_error()
+        elif not args.reuse_order:
             # a new set of reads as far as the library knows: the step pays for its own locality order, like a product batch
             rc = lib.sigax_batch_set_device_reads(batches[i], d_seqs.data_ptr(), d_offs.data_ptr(), n_local, n_local * L, L)
             assert rc == 0, _lib.last_error()
@@ -297,9 +332,9 @@ def bench_overlap(args):
             raise SystemExit("overlap step failed: " + _lib.last_error())
         inflight[i] = True
 
-    def run_steps(n, k0=0):
+    def run_steps(n, k0=0, upload=False):
         for k in range(k0, k0 + n):
-            submit(k)
+            submit(k, upload)
         for k in range(k0 + n, k0 + n + depth):  # complete in submission order
             complete(k % depth)
 
@@ -334,6 +369,26 @@ def bench_overlap(args):
     ri = rinfo.as_dict()
     nsub_step = max(1, ri["n_sub"])
 
+    # upload_inclusive: the same steps with every step's reads going up from pinned host memory through sigax_batch_upload
+    # (the PCIe-inclusive rate of the device path; the headline keeps the reads resident, as the metric's contract says)
+    upl = None
+    if world == 1 and args.upload_steps > 0:
+        h_seqs = torch.from_numpy(np.ascontiguousarray(shard).reshape(-1)).pin_memory()
+        h_offs = np.arange(0, (n_local + 1) * L, L, dtype=np.uint64)
+        k0 = depth + args.warmup + args.steps
+        run_steps(depth, k0, upload=True)  # the batch objects allocate their own read buffers here
+        torch.cuda.synchronize(dev)
+        t_u = time.perf_counter()
+        run_steps(args.upload_steps, k0 + depth, upload=True)
+        torch.cuda.synchronize(dev)
+        t_u = time.perf_counter() - t_u
+        upl = {"value": n_local * args.upload_steps / t_u, "unit": "reads/s", "steps": args.upload_steps, "ms_per_step": t_u / args.upload_steps * 1e3,
+               "bytes_up_per_step": int(n_local * L + 8 * (n_local + 1)),
+               "what": "the timed step with its reads uploaded from pinned host memory (sigax_batch_upload) inside the step, "
+                       "edge records back to pinned host memory as in the headline"}
+        for bt in batches:  # back to the resident reads for the legs below
+            assert lib.sigax_batch_set_device_reads(bt, d_seqs.data_ptr(), d_offs.data_ptr(), n_local, n_local * L, L) == 0
+
     # the same kernels with sub-batching off (no overlap between find and filter/extract): untimed extra steps
     iso = None
     if launches > 1 and args.isolated:
@@ -367,28 +422,28 @@ def bench_overlap(args):
         ach_fx = bytes_fx / nsub_step / (fx_ms * 1e-3) / 1e9 if fx_ms > 0 else 0.0
         lines_find = sec_f / 2 if two_step else sec_f  # memory requests: 128-byte lines / 64-byte granules
         glines = lines_find / launches / (find_ms * 1e-3) / 1e9 if find_ms > 0 else 0.0
-        traffic = fx_traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = "%d/%d/%d/%d" % (n_local, G, L, launches)
-                traffic = tj.get("k_find/" + key, {}).get("hbm_bytes_per_launch")
-                fx_traffic = tj.get("k_filter_extract_fast/" + key, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = fx_traffic = None
+        key = "%d/%d/%d/%d" % (n_local, G, L, launches)
+        traffic = traffic_entry("k_find/" + key)
+        fx_traffic = traffic_entry("k_filter_extract_fast/" + key)
         # What bounds the finder's gathers: the table one launch gathers from (one strand's two-step lines, or both strands'
         # granules) either stays in the 256 MiB Infinity Cache -- then the PMC "traffic" is L2-miss traffic and the ceiling
         # is what random rows of a cache-resident table read at -- or it does not, and the ceiling is HBM.
         per_strand = (info["n_symbols"] // 64 + 1) * 128 if two_step else (info["n_symbols"] // 128 + 1) * 64
         table_bytes = per_strand * (1 if ri["find_per_sub"] == 2 else 2)
-        cache_resident = table_bytes <= INFINITY_CACHE_BYTES * 5 // 4
-        bound = "l2-miss (Infinity-Cache-resident table)" if cache_resident else "hbm"
-        peak = CACHE_ROWS_GBS if cache_resident else HBM_PEAK_GBS
+        # `frac` is always against the HBM spec peak.  (Round 3 priced a 302 MB table against the guide's 7.65 TB/s for random
+        # rows of a cache-resident table; the table is larger than the 256 MiB cache and tools/ic_fit.sh shows the finder does
+        # not gain when it fits, so that ceiling was unsupported.)  The cache-rows figure is printed as a secondary field only
+        # when the table really fits.
+        cache_resident = table_bytes <= INFINITY_CACHE_BYTES
+        bound = "hbm"
+        peak = HBM_PEAK_GBS
         if job_world == 8 and args.reads_per_gpu == 2500000 and args.genome_per_gpu == 12500000 and L == 150 and args.seed == 2:
             named = "BASELINE configs[2]: "
         elif job_world == 1 and n_total == 1000000 and G == 5000000 and L == 150 and args.seed == 1:
             named = "BASELINE configs[1]: "
+        elif job_world == 8 and args.reads_per_gpu == 6250000 and args.genome_per_gpu == 28750000 and L == 250 and args.seed == 3:
+            named = "BASELINE configs[4] (chr1 stand-in: 50M x 250 bp from 230 Mb, 1.255e10 symbols, 64-bit positions)%s: " % (
+                ", first %d reads of the rank's 6.25 M per step" % args.max_local_reads if args.max_local_reads else "")
         else:
             named = ""
         out = {
@@ -408,7 +463,8 @@ def bench_overlap(args):
                        "algorithmic_bytes_per_read": bytes_step / max(n_local, 1),
                        "reference_formulation_bytes_per_read": (64 * (st["n_occ_find"] + st["n_occ_extract"]) + n_local * L + 64 * st["n_blocks"]) / max(n_local, 1),
                        "slow_path_reads": st["n_slow_reads"], "batches_in_flight": depth, "two_step_table": two_step,
-                       "finder": ("cooperative (lines through LDS)" if ri["coop"] else "per lane") + (", locality order" if ri["read_order"] else ""),
+                       "finder": ("cooperative (lines through LDS)" if ri["coop"] else "per lane") + (", locality order" if ri["read_order"] else "") +
+                                 (", chains start %d symbols in (deep start table)" % ri["deep_k"] if ri["deep_k"] else ", chains start 12 symbols in"),
                        "order_in_timed_region": not args.reuse_order,
                        "candidate_slots_per_chain": ri["cap"], "worst_case_slots_per_chain": ri["worst_cap"],
                        "candidate_arena_bytes": ri["arena_bytes"], "batch_workspace_bytes": ri["workspace_bytes"], "reruns": ri["reruns"],
@@ -418,7 +474,8 @@ def bench_overlap(args):
             "kernel_ms_per_step": dict({k: float(v) for k, v in zip(KERNELS, kavg)}, order_reads=order_avg),
             "launches_per_step": launches,
             "roofline": {"bound": bound, "kernel": "k_find", "achieved": ach_find, "peak": peak, "unit": "GB/s",
-                         "frac": ach_find / peak, "traffic": traffic, "frac_of_hbm_spec_peak": ach_find / HBM_PEAK_GBS,
+                         "frac": ach_find / peak, "traffic": traffic,
+                         "frac_of_cache_rows_ceiling": (ach_find / CACHE_ROWS_GBS) if cache_resident else None,
                          "table_bytes_per_launch": table_bytes,
                          "algorithmic_bytes_per_launch": bytes_find / launches, "avg_launch_ms": find_ms,
                          "request_rate": {"achieved": glines, "ceiling": GATHER_CEILING_GLINES, "unit": "G lines/s",
@@ -444,17 +501,85 @@ def bench_overlap(args):
                 "k_find_ms": ims, "achieved": bytes_find / (ims * 1e-3) / 1e9, "frac": bytes_find / (ims * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "request_rate_glines": lines_find / (ims * 1e-3) / 1e9,
                 "kernel_ms_per_step": {k: float(v) for k, v in zip(KERNELS, iso)}}
+        if upl is not None:
+            out["upload_inclusive"] = upl
+        if world > 1:
+            # what RCCL saw (the driver's SCALE record can be checked against it)
+            out["config"]["ranks"] = {"backend": args.backend, "world_size": dist.get_world_size(), "devices_visible": torch.cuda.device_count(),
+                                      "device_of_rank0": dev_index}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(prefix, reads, min(args.cpu_sample, n_total), args.min_overlap, st, lib, batch)
 
     for bt in batches:
         lib.sigax_batch_destroy(bt)
     pair.close()
+    if rank == 0 and world == 1 and job_world == 1 and not args.no_e2e and not args.error_rate and not by_pos and n_total <= 2000000:
+        if reads is None:
+            reads = draw(None)
+        out["end_to_end"] = end_to_end_cli(workdir, reads, args.min_overlap, out.get("cpu_baseline"),
+                                           named.startswith("BASELINE configs[1]") and args.min_overlap == 45)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+E2E_MD5_CONFIGS1 = "f47c833bc3fd5cc5f91daace91c5a345"  # ASQG text of BASELINE configs[1] at -m 45: the oracle's, rounds 1-3's
+
+
+def end_to_end_cli(workdir, reads, min_overlap, cpu, is_configs1):
+    """The product end to end ("incl. parse + ASQG write"): the workload's reads as FASTA (written here,
+    outside the clock) through `siga overlap -m M` -- the host C++ of siga_amd/host over the C-ABI -- as a child process,
+    one GPU: FMIndex::load x2 + .sai x2, parse, device batches, VT/ED text, gzip (src/overlap.cpp:41-47).  Wall time of the
+    child, its own phase times (SIGA_TIMING), md5 of the decompressed ASQG."""
+    import gzip
+    import hashlib
+    import re
+    from siga_amd import host
+    n = len(reads)
+    fa = os.path.join(workdir, "reads.fa")
+    with open(fa, "wb") as f:
+        for lo in range(0, n, 100000):
+            f.write(b"".join(b">r%d\n%s\n" % (i, bytes(r)) for i, r in zip(range(lo, min(n, lo + 100000)), reads[lo:lo + 100000])))
+    out = os.path.join(workdir, "reads.asqg.gz")
+    if os.path.exists(out):
+        os.remove(out)
+    env = dict(os.environ, SIGA_TIMING="1")
+    cmd = [host.CLI_PATH, "overlap", "-m", str(min_overlap), "-t", "8", "reads.fa"]
+    best = None
+    for _ in range(2):  # the first run pays the page-in of the binary and its libraries on a fresh box; report the second
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, cwd=workdir, env=env, capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": "siga overlap exited with %d: %s" % (r.returncode, r.stderr[-300:])}
+        first = best is None
+        best = (dt, r.stderr)
+        if first:
+            first_dt = dt
+    dt, err = best
+    phases = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"\[siga\]\s+(.*?)\s+([0-9.]+) s", err)}
+    h = hashlib.md5()
+    n_text = 0
+    with gzip.open(out, "rb") as f:
+        while True:
+            b = f.read(1 << 24)
+            if not b:
+                break
+            h.update(b)
+            n_text += len(b)
+    md5 = h.hexdigest()
+    res = {"command": "siga overlap -m %d -t 8 reads.fa  (child process, 1 GPU, %d reads as FASTA)" % (min_overlap, n),
+           "seconds": dt, "first_run_seconds": first_dt, "value": n / dt, "unit": "reads/s", "phases_s": phases,
+           "asqg_gz_bytes": os.path.getsize(out), "asqg_text_bytes": n_text, "asqg_md5": md5,
+           "asqg_md5_expected": E2E_MD5_CONFIGS1 if is_configs1 else None,
+           "asqg_md5_ok": (md5 == E2E_MD5_CONFIGS1) if is_configs1 else None}
+    if cpu:
+        res["vs_cpu_overlap_only"] = {"ratio": (n / dt) / cpu["value"],
+                                      "note": "end-to-end GPU reads/s (parse, index load, text and gzip included) over the CPU restatement's "
+                                              "OverlapBuilder::overlap-only reads/s on %d threads (no I/O on its side)" % cpu["cores"]}
+    return res
 
 
 def cpu_baseline(prefix, reads, sample, min_overlap, st, lib, batch):
@@ -479,11 +604,7 @@ def cpu_baseline(prefix, reads, sample, min_overlap, st, lib, batch):
 
 
 def correct_traffic(N, G, L, k):
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        return tj.get("k_correct/%d/%d/%d/%d" % (N, G, L, k), {}).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+    return traffic_entry("k_correct/%d/%d/%d/%d" % (N, G, L, k))
 
 
 def bench_correct(args):

@@ -140,6 +140,15 @@ void sigax_build_session(int open);
  * the index has been asked for as many reads as it holds -- one pass of `siga overlap` over the indexed reads
  * (src/overlap.cpp:41-47) never pays their build.  No-op when they are there already or do not fit. */
 int  sigax_index_prepare(sigax_index*);
+/* The same for an index that will serve overlap runs with this minimum overlap (the CLI's -m, src/overlap.cpp:44): besides
+ * the row tables, the block finder's DEEP START TABLE for K = min(min_overlap, 56) -- every distinct K-mer of the indexed
+ * reads with the state OverlapBlockFinder::find (src/overlap_builder.cpp:846-871) holds after consuming it, so that a
+ * chain starts where its output starts (nothing is pushed below minOverlap, :861) instead of walking there.  Serves every
+ * later run whose min_overlap is at least that K; runs with a smaller one, and chains whose K-mer is not in the reads,
+ * walk as before -- same bytes out.  Without this call the table is built in the background, for the min_overlap of the
+ * run at hand, once the index has been asked for as many reads as it holds.  No-op when it does not fit the free memory
+ * (32 bytes x 2 per distinct K-mer and strand) or min_overlap < 16. */
+int  sigax_index_prepare_overlap(sigax_index*, uint32_t min_overlap);
 
 /* Self-check of an open index: are the BWT rows of strand `which` (0 forward, 1 reverse) in the suffix order `siga index`
  * produces (SuffixArrayBuilder "sais2": src/suffix_array_builder.cpp:472-674; SURVEY.md App. C: one '$' smaller than
@@ -166,7 +175,10 @@ int  sigax_correct_batch(sigax_index*, const char* seqs, const char* quals, cons
 
 /* The same with every buffer in device memory, asynchronous on `stream` (a hipStream_t or NULL): d_offs u64[n_reads+1],
  * d_quals may be NULL, d_stat4 = 4 u64 of device scratch that receive {reads longer than the kernel supports (their
- * valid[] is 2), rank-table sectors asked for, k-mer lookups made, reserved}.  What a batching runtime and bench.py use. */
+ * valid[] is 2), rank-table sectors asked for, k-mer lookups made, reserved}.  What a batching runtime and bench.py use.
+ * The first correction call on an index allocates the table of all 13-mer intervals (537 MB, 1 GB with 64-bit positions:
+ * the one synchronous step; sigax_batch_size_hint leaves room for it) and builds it on `stream`, ahead of the call's own
+ * kernel; calls on other streams wait for that build through an event. */
 int  sigax_correct_device(sigax_index*, const void* d_seqs, const void* d_quals, const void* d_offs, uint64_t n_reads,
                           uint32_t kmer_size, int32_t kmer_threshold, uint32_t kmer_rounds, uint32_t count_offset,
                           void* d_out_seqs, void* d_valid, void* d_stat4, void* stream);
@@ -228,7 +240,7 @@ typedef struct sigax_run_info {
   uint32_t row_syms;      /* symbols an entry carries */
   uint32_t row_text;      /* the stretch text exists (extension rounds are read off it) */
   uint32_t row_direct;    /* ... reached through the direct maps (8 bytes per read) instead of a row table */
-  uint32_t reserved0;
+  uint32_t deep_k;        /* chains started from the deep start table with this K (0: from the 12-mer table or the first symbol) */
   uint64_t arena_bytes;   /* candidate arena of this batch object */
   uint64_t workspace_bytes; /* all device buffers of this batch object */
   uint64_t reruns;        /* runs of this batch object repeated so far because an arena was too small */

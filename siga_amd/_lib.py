@@ -41,7 +41,7 @@ class IndexInfo(C.Structure):
 
 class RunInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("n_sub", "find_per_sub", "two_step", "coop", "read_order", "cap", "worst_cap", "row_bits",
-                                          "row_syms", "row_text", "row_direct", "reserved0")] + \
+                                          "row_syms", "row_text", "row_direct", "deep_k")] + \
                [("arena_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64), ("reruns", C.c_uint64), ("order_ms", C.c_float)]
 
     def as_dict(self):
@@ -50,7 +50,7 @@ class RunInfo(C.Structure):
 
 # every symbol include/sigax.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "sigax_last_error", "sigax_device_count", "sigax_stream_create", "sigax_stream_destroy", "sigax_index_open", "sigax_index_open_mem", "sigax_index_prepare", "sigax_index_clone", "sigax_index_close",
+    "sigax_last_error", "sigax_device_count", "sigax_stream_create", "sigax_stream_destroy", "sigax_index_open", "sigax_index_open_mem", "sigax_index_prepare", "sigax_index_prepare_overlap", "sigax_index_clone", "sigax_index_close",
     "sigax_index_info_get", "sigax_index_set_reads", "sigax_index_check_order", "sigax_occ_batch", "sigax_kmer_count_batch",
     "sigax_correct_batch", "sigax_correct_device", "sigax_overlap_batch", "sigax_result_free", "sigax_batch_create", "sigax_batch_destroy", "sigax_batch_upload",
     "sigax_batch_set_device_reads", "sigax_batch_set_subbatches", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
@@ -80,6 +80,7 @@ def lib():
     L.sigax_index_open.argtypes = [cp, cp, cp, cp, ci, pvp]
     L.sigax_index_open_mem.argtypes = [vp, u64, vp, u64, u64, u64, vp, vp, ci, pvp]
     L.sigax_index_prepare.argtypes = [vp]
+    L.sigax_index_prepare_overlap.argtypes = [vp, u32]
     L.sigax_index_clone.argtypes = [vp, ci, pvp]
     L.sigax_index_close.argtypes = [vp]
     L.sigax_index_close.restype = None

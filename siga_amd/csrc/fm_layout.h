@@ -84,6 +84,24 @@
  * 16 bytes per entry (32 with 64-bit positions), 268 MB per strand: one gather instead of eleven dependent steps. */
 #define SIGAX_START_K 12
 
+/* Deep start table of the block finder (round 4; optional, built on the device once the index is known to stay open and the
+ * minimum overlap it is asked for is known): the same idea carried to where the finder's OUTPUT starts.  Below min-overlap
+ * symbols a chain emits nothing (src/overlap_builder.cpp:861: the '$' probe only counts from minOverlap on), so all a chain
+ * needs from its first K = min(min-overlap, 56) symbols is the state after them -- and a K-mer that occurs in the reads at
+ * all is one of at most n of them, not one of 4^K.  So: a hash table per strand (as primary index) of every distinct K-mer
+ * of that strand's text (found as the runs of equal K-symbol prefixes among adjacent rows of the row table: a K-mer's rows
+ * ARE its interval) with the state a chain holds after consuming it, computed by the same IntervalPair::init + updateL walk
+ * the finder does (k_deep_fill).  BASELINE configs[1], min-overlap 45: a chain starts 45 symbols in after ONE lookup
+ * instead of 12 symbols in and seventeen double steps; chains whose K-mer is not in the table (reads with errors: the
+ * reverse-complement chains' K-mers exist only if another read has them) start from the 12-mer table as before.
+ * Entry (32 bytes, 4 per 128-byte line, linear probing, load <= 0.5 when memory allows):
+ *   u64 k0   symbols 0..31 in the order the chain consumes them, symbol i at bits 2i (rank - 1)
+ *   u64 k1   symbols 32..55 likewise in bits 0..47; bits 48..63 = 0x8000 | K (never 0: an empty slot has k1 == 0)
+ *   16 bytes of payload: u32 positions { [0].lower, [1].lower, size, 0 }; u64 positions (below 2^40, what 288 GB hold):
+ *   [0].lower | [1].lower << 40 in the first 8 bytes and the next, [1].lower >> 24 | size << 16. */
+#define SIGAX_DEEP_KMAX 56
+#define SIGAX_DEEP_KMIN 16
+
 struct FmStrand {
   const uint32_t* granules;  /* n_granules x 16 u32 */
   const unsigned char* sa;    /* row table: n entries of sa_bits bits (+ 8 bytes of padding), or NULL */
@@ -94,6 +112,9 @@ struct FmStrand {
   const unsigned long long* super2;  /* [n_super][20], wide mode with two-step tables; else NULL */
   const unsigned long long* super;    /* [n_super][4] absolute A,C,G,T counts at each superblock start (wide mode) */
   const void* start;                  /* start table of the finder, or NULL */
+  const void* deep;                   /* deep start table (hash of this strand's K-mers), or NULL */
+  unsigned long long deep_slots;      /* its slots (32 bytes each) */
+  unsigned int deep_k, deep_pad;      /* its K */
   unsigned long long n;             /* symbols */
   unsigned long long C[5];           /* FMIndex::_pred (src/fmindex.cpp:156-160) */
   unsigned long long total[5];         /* symbol totals = Occ(c, n-1) */

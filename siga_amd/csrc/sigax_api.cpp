@@ -111,9 +111,23 @@ struct sigax_index {
   u32 max_read_len;  // longest read of sigax_index_set_reads (0: not told yet), an upper bound of the longest stretch
   void* d_super[2];
   void* d_start[2];  // start tables of the block finder (fm_layout.h) or NULL
+  // Deep start tables (fm_layout.h): built by sigax_index_prepare_overlap, or on a side thread once the index is being
+  // reused, for the min-overlap of the run at hand; deep_state 0 none / published, 1 being built, 2 built (deep_new waits
+  // for publishing under enqueue_mu).  d_slen = the stretches' lengths by '$' rank (kept from the row tables' build).
+  void* d_deep[2];
+  u64 deep_slots[2], deep_bytes;
+  uint32_t deep_k;
+  uint32_t* d_slen[2];
+  std::thread* deep_thread;
+  std::atomic<int>* deep_state;
+  void* deep_new[2];
+  u64 deep_new_slots[2], deep_new_bytes;
+  uint32_t deep_new_k;
+  bool deep_tried;
   uint32_t ptab_k;
   void* d_ptab;      // intervals of all 12-mers of the forward index: `siga correct`'s k-mer lookups start there (built by the
   bool ptab_tried;   // first correction call; SIGAX_KMER_PREFIX=0: never)
+  hipEvent_t ptab_ev;  // recorded behind the table's build on the first call's stream
   uint32_t* d_sai[2];
   u64 n_sai;
   uint32_t* d_read_len;
@@ -290,7 +304,9 @@ static int parse_sai(const std::vector<uint8_t>& buf, const char* path, std::vec
     bool irregular = nt > 1 && lines[nt] != elems;
     if (!irregular) {
       run(parse);
-      for (unsigned k = 0; k < nt; ++k) irregular = irregular || bad[k] == 3;
+      // numbers left over in a chunk, or a chunk that ran dry (pairs split across lines with the line count intact): some
+      // other layout of a token stream that operator>> (src/suffix_array.cpp:57-95) may still accept -- the serial parse decides
+      for (unsigned k = 0; k < nt; ++k) irregular = irregular || bad[k] == 3 || (nt > 1 && bad[k] == 1);
     }
     if (!irregular) break;
     nt = 1;  // once more, serially
@@ -400,7 +416,15 @@ extern "C" void sigax_index_close(sigax_index* ix) {
     delete ix->tab_thread;
   }
   delete ix->tab_state;
+  if (ix->deep_thread) {
+    ix->deep_thread->join();
+    delete ix->deep_thread;
+  }
+  delete ix->deep_state;
   for (int s = 0; s < 2; ++s) {
+    if (ix->d_deep[s]) hipFree(ix->d_deep[s]);
+    if (ix->deep_new[s]) hipFree(ix->deep_new[s]);
+    if (ix->d_slen[s]) hipFree(ix->d_slen[s]);
     if (ix->d_gran[s]) hipFree(ix->d_gran[s]);
     if (ix->d_gran2[s]) hipFree(ix->d_gran2[s]);
     if (ix->d_super2[s]) hipFree(ix->d_super2[s]);
@@ -414,6 +438,7 @@ extern "C" void sigax_index_close(sigax_index* ix) {
   if (ix->d_read_len) hipFree(ix->d_read_len);
   if (ix->d_name_rank) hipFree(ix->d_name_rank);
   if (ix->d_ptab) hipFree(ix->d_ptab);
+  if (ix->ptab_ev) hipEventDestroy(ix->ptab_ev);
   if (ix->s_find) hipStreamDestroy(ix->s_find);
   if (ix->s_fx) hipStreamDestroy(ix->s_fx);
   if (ix->s_tail) hipStreamDestroy(ix->s_tail);
@@ -557,12 +582,17 @@ static void fill_row_tables(sigax_index* ix, FmStrand out[2], u64* out_bytes) {
   u32 maxlen[2] = {0, 0};
   RowTabGeom g[2];
   const bool direct = ix->tab_direct;
-  u32* slen[2] = {nullptr, nullptr};  // direct maps: the stretches' lengths by '$' rank (scratch)
+  // the stretches' lengths by '$' rank: what the direct maps are composed from, and what the deep start table's build reads
+  // a row's remaining symbols off (kept with the index: 4 bytes per read and strand)
+  u32* slen[2] = {nullptr, nullptr};
   u32* isai = nullptr;
-  if (direct) {
-    for (int s = 0; s < 2 && e == hipSuccess; ++s) e = hipMalloc((void**)&slen[s], std::max<u64>(n_stretch, 1) * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&isai, std::max<u64>(n_stretch, 1) * 4);
+  if (ix->tab_text) {
+    for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+      if (!ix->d_slen[s]) e = hipMalloc((void**)&ix->d_slen[s], std::max<u64>(n_stretch, 1) * 4);
+      slen[s] = ix->d_slen[s];
+    }
   }
+  if (direct && e == hipSuccess) e = hipMalloc((void**)&isai, std::max<u64>(n_stretch, 1) * 4);
   for (int s = 0; s < 2 && e == hipSuccess; ++s) {
     e = hipMemsetAsync(d_max, 0, 8, sb);
     if (e != hipSuccess) break;
@@ -603,8 +633,6 @@ static void fill_row_tables(sigax_index* ix, FmStrand out[2], u64* out_bytes) {
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(sb);
   }
-  for (int s = 0; s < 2; ++s)
-    if (slen[s]) hipFree(slen[s]);
   if (isai) hipFree(isai);
   if (sb) (void)hipStreamDestroy(sb);
   if (info) hipFree(info);
@@ -618,6 +646,7 @@ static void fill_row_tables(sigax_index* ix, FmStrand out[2], u64* out_bytes) {
     out[s].sa = direct ? nullptr : (const unsigned char*)ix->d_sa[s];
     out[s].xmap = direct ? (const u64*)ix->d_xmap[s] : nullptr;
     if (direct) *out_bytes += 8 * ix->n_strings;
+    if (ix->d_slen[s]) *out_bytes += 4 * n_stretch;
     out[s].text = ix->tab_text ? (const unsigned char*)ix->d_text[s] : nullptr;
     out[s].sa_bits = g[s].sa_bits;
     out[s].ld_bits = g[s].ld_bits;
@@ -674,6 +703,7 @@ static void start_row_tables(sigax_index* ix, bool sync) {
 // reads as it holds (enqueue()), or at once when the caller says the index is here to stay (sigax_index_prepare).
 static void build_rowend(sigax_index* ix) {
   ix->tab_state = new std::atomic<int>(0);
+  ix->deep_state = new std::atomic<int>(0);
   plan_row_tables(ix);
   if (ix->n_symbols < (1ull << 26) || getenv("SIGAX_TABLES_SYNC") != nullptr) start_row_tables(ix, true);
 }
@@ -686,6 +716,140 @@ static void row_tables_now(sigax_index* ix) {
   }
   publish_tables(ix);
   start_row_tables(ix, true);  // (no-op when they were built, or tried, before)
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// Deep start tables of the block finder (fm_layout.h, sigax_index_prepare_overlap).  Needs the row tables and the
+// stretch text (the distinct K-mers are read off them); an accelerator like those: when memory is short, the index has no
+// row tables, or a K-mer's walk does not come out at its own rows, there is no table and every chain walks.
+// SIGAX_FIND_DEEP=0 never builds them; SIGAX_DEEP_K=k overrides K (tests); SIGAX_DEEP_LOAD=percent sets the load factor.
+// ------------------------------------------------------------------------------------------------------
+static uint32_t deep_k_for(uint32_t min_overlap) {
+  static const char* env = getenv("SIGAX_FIND_DEEP");
+  if (env && env[0] == '0') return 0;
+  static const char* envk = getenv("SIGAX_DEEP_K");
+  uint32_t k = envk ? (uint32_t)atoi(envk) : std::min<uint32_t>(min_overlap, SIGAX_DEEP_KMAX);
+  if (k > min_overlap || k > SIGAX_DEEP_KMAX) k = std::min<uint32_t>(min_overlap, SIGAX_DEEP_KMAX);
+  if (k < (envk ? 2u : (uint32_t)SIGAX_DEEP_KMIN)) return 0;
+  return k;
+}
+// Tables for K from the strands' row tables `st` (a snapshot taken under enqueue_mu).  `share` = the part of the free
+// memory they may take, in per cent.  On success tab[] / slots[] / *bytes are set; on any failure nothing is left allocated.
+static bool build_deep_tables(sigax_index* ix, const FmStrand st[2], uint32_t K, unsigned share, void* tab[2], u64 slots[2], u64* bytes) {
+  tab[0] = tab[1] = nullptr;
+  slots[0] = slots[1] = 0;
+  *bytes = 0;
+  if (K == 0 || !st[0].sa || !st[1].sa || !st[0].text || !st[1].text || !ix->d_slen[0] || !ix->d_slen[1]) return false;
+  const bool verbose = getenv("SIGAX_VERBOSE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  const u64 n_stretch = ix->st[0].C[1];
+  static const char* envl = getenv("SIGAX_DEEP_LOAD");
+  hipStream_t sb = nullptr;
+  u64* d_cnt = nullptr;  // [0] distinct K-mers, [1] errors
+  u64* list = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_cnt, 16);
+  bool ok = e == hipSuccess;
+  u64 distinct[2] = {0, 0};
+  for (int s = 0; s < 2 && ok; ++s) {
+    u64 h[2] = {0, 0};
+    ok = hipMemsetAsync(d_cnt, 0, 16, sb) == hipSuccess;
+    if (!ok) break;
+    launch_deep_scan(st[s], ix->d_slen[s], n_stretch, K, d_cnt, nullptr, 0, sb);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, sb) == hipSuccess &&
+         hipStreamSynchronize(sb) == hipSuccess;
+    distinct[s] = h[0];
+  }
+  if (ok) {
+    // both strands' tables + the larger list must fit `share` per cent of what is free now
+    size_t mfree = 0, mtotal = 0;
+    (void)hipMemGetInfo(&mfree, &mtotal);
+    unsigned load = envl ? (unsigned)std::min(95, std::max(5, atoi(envl))) : 50u;
+    for (;;) {
+      for (int s = 0; s < 2; ++s) slots[s] = std::max<u64>(64, distinct[s] * 100 / load + 16);
+      const u64 need = (slots[0] + slots[1]) * deep_entry_bytes() + std::max(distinct[0], distinct[1]) * 8;
+      if (need <= (u64)mfree / 100 * share) break;
+      if (envl || load >= 80) { ok = false; break; }
+      load += 15;  // 50, 65, 80 per cent: longer probe sequences before no table at all
+    }
+    if (!ok && verbose) fprintf(stderr, "[sigax] deep start tables (K = %u, %llu + %llu K-mers) do not fit %u %% of the free memory\n", K,
+                                distinct[0], distinct[1], share);
+  }
+  for (int s = 0; s < 2 && ok; ++s) {
+    u64 h[2] = {0, 0};
+    ok = hipMalloc((void**)&list, std::max<u64>(distinct[s], 1) * 8) == hipSuccess && hipMalloc(&tab[s], slots[s] * deep_entry_bytes()) == hipSuccess &&
+         hipMemsetAsync(tab[s], 0, slots[s] * deep_entry_bytes(), sb) == hipSuccess && hipMemsetAsync(d_cnt, 0, 16, sb) == hipSuccess;
+    if (!ok) break;
+    launch_deep_scan(st[s], ix->d_slen[s], n_stretch, K, d_cnt, list, distinct[s], sb);
+    launch_deep_fill(st[s], st[1 - s], ix->wide, ix->d_slen[s], n_stretch, K, list, distinct[s], tab[s], slots[s], d_cnt + 1, sb);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, sb) == hipSuccess &&
+         hipStreamSynchronize(sb) == hipSuccess;
+    if (ok && (h[0] != distinct[s] || h[1] != 0)) {
+      if (verbose) fprintf(stderr, "[sigax] deep start table of strand %d: %llu K-mers listed of %llu, %llu walks astray: no table\n", s, h[0], distinct[s], h[1]);
+      ok = false;
+    }
+    hipFree(list);
+    list = nullptr;
+    *bytes += slots[s] * deep_entry_bytes();
+  }
+  if (list) hipFree(list);
+  if (d_cnt) hipFree(d_cnt);
+  if (sb) (void)hipStreamDestroy(sb);
+  if (!ok) {
+    (void)hipGetLastError();
+    for (int s = 0; s < 2; ++s) {
+      if (tab[s]) hipFree(tab[s]);
+      tab[s] = nullptr;
+      slots[s] = 0;
+    }
+    *bytes = 0;
+    return false;
+  }
+  if (verbose)
+    fprintf(stderr, "[sigax] deep start tables: K = %u, %llu + %llu distinct K-mers, %.2f GB, %.3f s\n", K, distinct[0], distinct[1], *bytes / 1e9,
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  return true;
+}
+// (caller holds enqueue_mu) a finished background build becomes visible to the runs enqueued from now on
+static void publish_deep(sigax_index* ix) {
+  if (!ix->deep_state || ix->deep_state->load(std::memory_order_acquire) != 2) return;
+  if (ix->deep_thread) {
+    ix->deep_thread->join();
+    delete ix->deep_thread;
+    ix->deep_thread = nullptr;
+  }
+  if (ix->deep_new[0] && ix->deep_new[1]) {
+    for (int s = 0; s < 2; ++s) {
+      ix->d_deep[s] = ix->deep_new[s];
+      ix->deep_slots[s] = ix->deep_new_slots[s];
+      ix->deep_new[s] = nullptr;
+      ix->st[s].deep = ix->d_deep[s];
+      ix->st[s].deep_slots = ix->deep_slots[s];
+      ix->st[s].deep_k = ix->deep_new_k;
+    }
+    ix->deep_k = ix->deep_new_k;
+    ix->deep_bytes = ix->deep_new_bytes;
+    ix->device_bytes += ix->deep_bytes;
+  }
+  ix->deep_state->store(0, std::memory_order_release);
+}
+// (caller holds enqueue_mu) the index is being reused and this run's min-overlap has no table: build one beside the runs
+static void start_deep_tables(sigax_index* ix, uint32_t min_overlap) {
+  if (ix->deep_tried || !ix->deep_state || ix->deep_state->load() != 0) return;
+  if (ix->deep_k != 0 && ix->deep_k <= min_overlap) return;
+  const uint32_t K = deep_k_for(min_overlap);
+  if (K == 0 || !ix->st[0].sa || !ix->st[0].text || !ix->st[1].sa || !ix->st[1].text) return;
+  ix->deep_tried = true;  // one background attempt per index; sigax_index_prepare_overlap may still replace the table
+  if (ix->deep_k != 0) return;  // a table for a larger K is in use by runs in flight: only prepare_overlap swaps tables
+  ix->deep_state->store(1);
+  FmStrand snap[2] = {ix->st[0], ix->st[1]};
+  ix->deep_new_k = K;
+  ix->deep_thread = new std::thread([ix, snap, K] {
+    (void)hipSetDevice(ix->device);
+    (void)build_deep_tables(ix, snap, K, 25, ix->deep_new, ix->deep_new_slots, &ix->deep_new_bytes);
+    ix->deep_state->store(2, std::memory_order_release);
+  });
 }
 
 // The index's own streams.  The finder is the critical path of a step: its stream gets the higher priority.
@@ -756,24 +920,28 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
   ix->wide = n_symbols >= 0xFFFFFFF0ull || getenv("SIGAX_FORCE_WIDE") != nullptr;
   const uint8_t* rr[2] = {runs, rruns};
   u64 nr[2] = {n_runs, n_rruns};
-  struct DecodeSession {  // the second strand is decoded in the first one's scratch memory
-    DecodeSession() { sigax_build_session(1); }
-    ~DecodeSession() { sigax_build_session(0); }
-  } decode_session;
-  for (int s = 0; s < 2; ++s) {
-    u64 C[5], total[5], gb = 0, sb = 0;
-    int rc = sigax_decode_strand(rr[s], nr[s], n_symbols, ix->wide, &ix->d_gran[s], &gb, &ix->d_super[s], &sb, C, total);
-    if (rc != SIGAX_OK) {
-      sigax_index_close(ix);
-      return rc;
-    }
-    ix->device_bytes += gb + sb;
-    ix->st[s].granules = (const uint32_t*)ix->d_gran[s];
-    ix->st[s].super = (const u64*)ix->d_super[s];
-    ix->st[s].n = n_symbols;
-    for (int k = 0; k < 5; ++k) {
-      ix->st[s].C[k] = C[k];
-      ix->st[s].total[k] = total[k];
+  {
+    // The second strand is decoded in the first one's scratch memory.  The session spans the two decodes only: its parked
+    // scratch blocks are invisible to hipMemGetInfo, and the optional tables below are planned from the free memory.
+    struct DecodeSession {
+      DecodeSession() { sigax_build_session(1); }
+      ~DecodeSession() { sigax_build_session(0); }
+    } decode_session;
+    for (int s = 0; s < 2; ++s) {
+      u64 C[5], total[5], gb = 0, sb = 0;
+      int rc = sigax_decode_strand(rr[s], nr[s], n_symbols, ix->wide, &ix->d_gran[s], &gb, &ix->d_super[s], &sb, C, total);
+      if (rc != SIGAX_OK) {
+        sigax_index_close(ix);
+        return rc;
+      }
+      ix->device_bytes += gb + sb;
+      ix->st[s].granules = (const uint32_t*)ix->d_gran[s];
+      ix->st[s].super = (const u64*)ix->d_super[s];
+      ix->st[s].n = n_symbols;
+      for (int k = 0; k < 5; ++k) {
+        ix->st[s].C[k] = C[k];
+        ix->st[s].total[k] = total[k];
+      }
     }
   }
   clk.lap("streams, upload + decode");
@@ -951,6 +1119,43 @@ extern "C" int sigax_index_prepare(sigax_index* ix) {
   return SIGAX_OK;
 }
 
+extern "C" int sigax_index_prepare_overlap(sigax_index* ix, uint32_t min_overlap) {
+  if (!ix) return fail(SIGAX_E_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(ix->device));
+  std::lock_guard<std::mutex> lock(*ix->enqueue_mu);
+  row_tables_now(ix);
+  // a background build in flight: let it finish, then see whether its table serves
+  if (ix->deep_thread) {
+    ix->deep_thread->join();
+    delete ix->deep_thread;
+    ix->deep_thread = nullptr;
+  }
+  publish_deep(ix);
+  const uint32_t K = deep_k_for(min_overlap);
+  if (K == 0 || (ix->deep_k != 0 && ix->deep_k <= min_overlap)) return SIGAX_OK;
+  if (ix->d_deep[0]) {
+    // a table for a larger K: runs in flight may still read it
+    HIP_TRY(hipDeviceSynchronize());
+    for (int s = 0; s < 2; ++s) {
+      hipFree(ix->d_deep[s]);
+      ix->d_deep[s] = nullptr;
+      ix->deep_slots[s] = 0;
+      ix->st[s].deep = nullptr;
+      ix->st[s].deep_slots = 0;
+      ix->st[s].deep_k = 0;
+    }
+    ix->device_bytes -= ix->deep_bytes;
+    ix->deep_bytes = 0;
+    ix->deep_k = 0;
+  }
+  FmStrand snap[2] = {ix->st[0], ix->st[1]};
+  ix->deep_new_k = K;
+  (void)build_deep_tables(ix, snap, K, 45, ix->deep_new, ix->deep_new_slots, &ix->deep_new_bytes);
+  ix->deep_state->store(2);
+  publish_deep(ix);
+  return SIGAX_OK;
+}
+
 extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index** out) {
   if (!src || !out) return fail(SIGAX_E_ARG, "NULL argument");
   *out = nullptr;
@@ -1007,6 +1212,9 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
     ix->st[s].sa = nullptr;
     ix->st[s].xmap = nullptr;
     ix->st[s].text = nullptr;
+    ix->st[s].deep = nullptr;  // the replica builds its own (sigax_index_prepare_overlap, or once it is reused)
+    ix->st[s].deep_slots = 0;
+    ix->st[s].deep_k = 0;
     ix->st[s].granules = (const uint32_t*)ix->d_gran[s];
     ix->st[s].super = (const u64*)ix->d_super[s];
     ix->st[s].gran2 = (const uint32_t*)ix->d_gran2[s];
@@ -1145,9 +1353,14 @@ extern "C" int sigax_kmer_count_batch(sigax_index* ix, const char* kmers, uint32
 }
 
 // the 12-mer table of the k-mer lookups, built on first use (an accelerator: without it every lookup walks all its steps)
-static void ensure_prefix_table(sigax_index* ix) {
+// Built by the first correction call ON THAT CALL'S STREAM (no device-wide wait: sigax_correct_device stays asynchronous;
+// the allocation itself is the one synchronous step); later calls on other streams wait for the build's event.
+static void ensure_prefix_table(sigax_index* ix, hipStream_t st) {
   std::lock_guard<std::mutex> lock(*ix->enqueue_mu);
-  if (ix->ptab_tried) return;
+  if (ix->ptab_tried) {
+    if (ix->d_ptab && ix->ptab_ev) (void)hipStreamWaitEvent(st, ix->ptab_ev, 0);
+    return;
+  }
   ix->ptab_tried = true;
   // 0 = none, 8 .. 14 = that many symbols.  Default 13 (537 MB): measured at BASELINE configs[3], k = 31, 28.1 / 31.3 / 29.5 M
   // reads/s with 12 / 13 / 14 symbols (21.1 M without) -- the 2 GB table of all 14-mers no longer sits in the caches
@@ -1160,11 +1373,13 @@ static void ensure_prefix_table(sigax_index* ix) {
     (void)hipGetLastError();
     return;
   }
-  launch_prefix_build(ix->st[0], ix->wide, tab, pk, nullptr);
+  launch_prefix_build(ix->st[0], ix->wide, tab, pk, st);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ptab_ev, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(ix->ptab_ev, st);
   if (e != hipSuccess) {
     (void)hipGetLastError();
+    (void)hipStreamSynchronize(st);
     hipFree(tab);
     return;
   }
@@ -1175,7 +1390,7 @@ static void ensure_prefix_table(sigax_index* ix) {
 
 static CorrectArgs correct_args(sigax_index* ix, const unsigned char* d_seqs, const unsigned char* d_quals, const u64* d_offs, u64 n_reads,
                                 uint32_t kmer_size, int32_t kmer_threshold, uint32_t kmer_rounds, uint32_t count_offset,
-                                unsigned char* d_out, unsigned char* d_valid, u64* d_stat) {
+                                unsigned char* d_out, unsigned char* d_valid, u64* d_stat, hipStream_t st) {
   CorrectArgs ca;
   ca.fwd = ix->st[0];
   ca.seqs = d_seqs;
@@ -1191,7 +1406,7 @@ static CorrectArgs correct_args(sigax_index* ix, const unsigned char* d_seqs, co
   ca.out = d_out;
   ca.valid = d_valid;
   ca.dstat = d_stat;
-  ensure_prefix_table(ix);
+  ensure_prefix_table(ix, st);
   ca.ptab = ix->d_ptab;
   ca.pk = ix->ptab_k;
   ca.max_len = 0;  // unknown here: sigax_correct_batch sees the offsets and says
@@ -1208,7 +1423,7 @@ extern "C" int sigax_correct_device(sigax_index* ix, const void* d_seqs, const v
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(hipMemsetAsync(d_stat4, 0, 32, st));
   CorrectArgs ca = correct_args(ix, (const unsigned char*)d_seqs, (const unsigned char*)d_quals, (const u64*)d_offs, n_reads, kmer_size,
-                                kmer_threshold, kmer_rounds, count_offset, (unsigned char*)d_out_seqs, (unsigned char*)d_valid, (u64*)d_stat4);
+                                kmer_threshold, kmer_rounds, count_offset, (unsigned char*)d_out_seqs, (unsigned char*)d_valid, (u64*)d_stat4, st);
   launch_correct(ca, ix->wide, st);
   HIP_TRY(hipGetLastError());
   return SIGAX_OK;
@@ -1237,7 +1452,7 @@ extern "C" int sigax_correct_batch(sigax_index* ix, const char* seqs, const char
     HIP_TRY(hipMemcpy(d_quals, quals, nb, hipMemcpyHostToDevice));
   }
   CorrectArgs ca = correct_args(ix, d_seqs, d_quals, d_offs, n_reads, kmer_size, kmer_threshold, kmer_rounds, count_offset, d_out,
-                                d_valid, d_stat);
+                                d_valid, d_stat, (hipStream_t)0);
   for (uint32_t i = 0; i < n_reads; ++i) ca.max_len = std::max<uint32_t>(ca.max_len, (uint32_t)std::min<u64>(offs[i + 1] - offs[i], 0xFFFFFFFFull));
   ca.max_len = std::max(ca.max_len, 1u);
   launch_correct(ca, ix->wide, 0);
@@ -1333,6 +1548,7 @@ struct sigax_batch {
   unsigned nsub_req;  // 0 = automatic
   unsigned find_per_sub;  // finder launches per sub-batch (2 = one per strand's two-step table)
   bool last_two_step, last_coop, last_perm, last_ordered;  // what the last enqueued run's finder did (sigax_batch_run_info)
+  uint32_t last_deep_k;
   sigax_stats last;
   u64 last_total_blocks, last_total_edges;
   bool finished;
@@ -1394,6 +1610,7 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
   b->nsub_req = 0;
   b->find_per_sub = 1;
   b->last_two_step = b->last_coop = b->last_perm = b->last_ordered = false;
+  b->last_deep_k = 0;
   {
     hipError_t e = hipSuccess;
     for (int i = 0; i < EV_COUNT && e == hipSuccess; ++i) e = hipEventCreate(&b->ev[i]);
@@ -1459,8 +1676,12 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   sigax_index* ix = b->ix;
   std::lock_guard<std::mutex> lock(*ix->enqueue_mu);  // one batch's launch sequence at a time on the shared streams
   publish_tables(ix);
+  publish_deep(ix);
   // a whole pass over the indexed reads has been asked for before this run: the index is being reused
-  if (ix->reads_asked >= std::max<u64>(ix->n_strings, 1)) start_row_tables(ix, false);
+  if (ix->reads_asked >= std::max<u64>(ix->n_strings, 1)) {
+    start_row_tables(ix, false);
+    if (!(b->flags & SIGAX_DUPLICATE)) start_deep_tables(ix, b->minov);
+  }
   ix->reads_asked += b->n_reads;
   const uint32_t n = b->n_reads;
   const bool edges = (b->flags & SIGAX_EDGES) != 0;
@@ -1591,6 +1812,9 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.cap = b->cap;
     fa.max_seen = ix->cap_seen->load();
     fa.start_ok = (ix->st[0].start && ix->st[1].start && b->minov >= (uint32_t)SIGAX_START_K) ? 1u : 0u;
+    static const bool deep_off = getenv("SIGAX_FIND_DEEP_USE") != nullptr && getenv("SIGAX_FIND_DEEP_USE")[0] == '0';  // A/B aid: built, not used
+    fa.deep_k = (!deep_off && ix->st[0].deep && ix->st[1].deep && ix->st[0].deep_k == ix->st[1].deep_k && ix->st[0].deep_k <= b->minov) ? ix->st[0].deep_k : 0u;
+    b->last_deep_k = fa.deep_k;
     fa.read_begin = rb;
     fa.read_end = re;
     fa.stage_bytes = 0;  // set by launch_find
@@ -1966,10 +2190,14 @@ extern "C" int sigax_batch_size_hint(sigax_index* ix, uint32_t max_read_len, uin
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   free_b = free_b > ix->tab_plan ? free_b - ix->tab_plan : 0;  // the row tables are allocated later (build_rowend)
-  // slots per chain as the runs will size them; before any run has finished, half the worst case (the first runs try a
-  // third and repeat themselves with what their chains needed)
+  // Slots per chain: the WORST case (one per overlap length).  A run sizes its arena by the longest chain seen so far and
+  // repeats itself with more when a chain outgrows that (sigax_batch_finish) -- up to the worst case, so that is what a
+  // batch of this many reads must be able to get: a hint from the typical size let a rerun's arena grow fail with
+  // SIGAX_E_DEVICE in the middle of a job on a memory-tight index (BASELINE configs[4]: 190 GB of tables).  The price is
+  // nil where memory is plentiful (the callers cap their batches at 2^20 reads) and 1 M -> 0.7 M reads per batch at configs[4].
   const uint32_t mo = (flags & SIGAX_DUPLICATE) ? max_read_len : min_overlap;
-  const u64 cap = ix->cap_seen->load() ? chain_cap(ix, max_read_len, mo, 0) : std::max<uint32_t>(chain_cap(ix, max_read_len, mo, 0), worst_cap(max_read_len, mo) / 2);
+  const u64 cap = worst_cap(max_read_len, mo);
+  if (!ix->ptab_tried) free_b = free_b > prefix_table_bytes(ix->wide, 13) ? free_b - prefix_table_bytes(ix->wide, 13) : 0;  // `siga correct`'s table, built at its first call
   // + the locality order's keys, values and sort space (40 bytes per read), the per-read queues and counters (~70)
   const u64 per_read = 4 * cap * cand_bytes(ix->wide) + max_read_len + ((flags & SIGAX_IRREDUCIBLE) ? 8 : 64) * (2 * 80 + 2 * 16 + 12) + 256;
   const u64 fixed = (2ull << 30) + (u64)32768 * (4 * (cap + 2) + 128) * SIGAX_ENT_BYTES;  // pools of the lane-group and general kernels
@@ -2024,6 +2252,7 @@ extern "C" int sigax_batch_run_info(sigax_batch* b, sigax_run_info* out) {
   out->row_syms = f.sa ? (f.sa_bits - f.ld_bits - f.t_bits) / 2u : 0u;
   out->row_text = f.text ? 1u : 0u;
   out->row_direct = f.xmap ? 1u : 0u;
+  out->deep_k = b->last_deep_k;
   out->arena_bytes = b->arena.bytes;
   DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->work64c, &b->work64d, &b->perm,
                    &b->ord_keys, &b->ord_tmp, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin, &b->fin_cnt, &b->substring, &b->block_offs,

@@ -46,6 +46,7 @@ struct FindArgs {
   uint32_t n_reads, minov, chain_mask, cap;  // chain_mask bit o = find o runs; cap = slots per chain, last = containment
   uint32_t max_seen;                 // chains no longer than this need not report their length (DS_MAX_CHAIN)
   uint32_t start_ok;                 // both strands carry the start table and min-overlap >= 12: chains may start twelve symbols in
+  uint32_t deep_k;                   // both strands carry the deep start table with this K <= min-overlap (fm_layout.h), or 0
   uint32_t read_begin, read_end;     // this launch's sub-batch
   uint32_t stage_bytes;              // dynamic LDS per workgroup that may hold the workgroup's reads (set by launch_find)
   uint32_t two_step;                 // both strands carry the two-step table (u32 positions only)
@@ -175,6 +176,17 @@ void launch_suffix_order_check(const FmStrand& s, const uint32_t* sai, uint32_t*
 // start table of the finder for chains whose primary index is `prim` (fm_layout.h): start_table_bytes(wide) bytes
 unsigned long long start_table_bytes(bool wide);
 void launch_start_build(const FmStrand& prim, const FmStrand& other, bool wide, void* tab, hipStream_t st);
+// deep start table of strand `prim` as primary index (fm_layout.h).  launch_deep_scan: *count (zeroed by the caller) += the
+// distinct K-mers of s's text = the runs of rows with equal K-symbol prefixes; with list != NULL each run's first row goes
+// to list[] (any order, at most list_cap).  launch_deep_fill: their states into tab (nslots entries of deep_entry_bytes(),
+// zeroed by the caller); *err (zeroed) counts K-mers whose walk did not come out at their own rows.  slen = the stretches'
+// lengths by '$' rank (launch_rows_fill).
+unsigned long long deep_entry_bytes();
+void launch_deep_scan(const FmStrand& s, const uint32_t* slen, unsigned long long n_stretch, uint32_t K, unsigned long long* count,
+                      unsigned long long* list, unsigned long long list_cap, hipStream_t st);
+void launch_deep_fill(const FmStrand& prim, const FmStrand& other, bool wide, const uint32_t* slen, unsigned long long n_stretch, uint32_t K,
+                      const unsigned long long* list, unsigned long long n_list, void* tab, unsigned long long nslots, unsigned long long* err,
+                      hipStream_t st);
 unsigned long long find_stage_capacity();  // bytes of reads a finder workgroup can stage in LDS
 void launch_filter_extract(const FxArgs& a, bool wide, unsigned grid, hipStream_t st);
 // qhint: items the four queues held last time (per sub-batch; ~0 = unknown), or NULL

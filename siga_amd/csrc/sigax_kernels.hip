@@ -585,6 +585,142 @@ __global__ __launch_bounds__(256) void k_start_build(FmStrand prim, FmStrand oth
 }
 
 // -------------------------------------------------------------------------------------------------------
+// Deep start table of the block finder (fm_layout.h): the distinct K-mers of a strand's text are the runs of equal
+// K-symbol prefixes among adjacent rows of its row table (k_deep_scan counts them, then lists each run's first row); one
+// lane per distinct K-mer then walks IntervalPair::init + K - 1 updateL steps (src/overlap_builder.cpp:91-122) with that
+// strand as primary index -- the arithmetic of k_start_build and of the finder itself -- and puts the state into the hash
+// table (k_deep_fill).  The walk must come out at the run's own first row: anything else (an index whose rows are not in
+// suffix order, a row table of a walk that did not end) raises *err and the host throws the table away.
+// -------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 deep_slot(u64 k0, u64 k1, u64 nslots) {
+  u64 h = (k0 ^ (k1 * 0x9E3779B97F4A7C15ull)) * 0xBF58476D1CE4E5B9ull;
+  h ^= h >> 31;
+  h *= 0x94D049BB133111EBull;
+  h ^= h >> 29;
+  return __umul64hi(h, nslots);
+}
+// the first K symbols of the suffix at row p in text order, symbol j at bits 2 j of f0 (j < 28) / 2 (j - 28) of f1; false
+// when the row's stretch ends before that
+__device__ __forceinline__ bool deep_row_kmer(const FmStrand& st, const u32* slen, u64 n_stretch, u64 p, u32 K, u64& f0, u64& f1) {
+  u32 ld, t;
+  row_lookup(st, p, ld, t);
+  f0 = f1 = 0;
+  if ((u64)ld >= n_stretch) return false;
+  if ((u64)t + K > (u64)slen[ld]) return false;
+  const u64 m56 = (1ull << 56) - 1ull;
+  f0 = text_bits(st, ld, t) & (K >= 28u ? m56 : ((1ull << (2u * K)) - 1ull));
+  if (K > 28u) f1 = text_bits(st, ld, t + 28u) & (K >= 56u ? m56 : ((1ull << (2u * (K - 28u))) - 1ull));
+  return true;
+}
+__global__ __launch_bounds__(256) void k_deep_scan(FmStrand st, const u32* slen, u64 n_stretch, u32 K, u64* count, u64* list, u64 list_cap) {
+  const u64 p = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u32 lane = threadIdx.x & 63u;
+  u64 f0 = 0, f1 = 0;
+  bool v = false;
+  if (p < st.n) v = deep_row_kmer(st, slen, n_stretch, p, K, f0, f1);
+  // the row before: the lane below has it, except for the wave's first lane
+  u64 g0 = __shfl_up(f0, 1, 64), g1 = __shfl_up(f1, 1, 64);
+  bool pv = __shfl_up((int)v, 1, 64) != 0;
+  if (lane == 0) {
+    pv = false;
+    if (p > 0 && p < st.n) pv = deep_row_kmer(st, slen, n_stretch, p - 1, K, g0, g1);
+  }
+  const bool first = v && (!pv || g0 != f0 || g1 != f1);
+  const u64 m = __ballot(first);
+  if (!m) return;
+  u64 base = 0;
+  if (lane == 0) base = atomicAdd(count, (u64)__popcll(m));
+  base = __shfl(base, 0, 64);
+  if (list != nullptr && first) {
+    const u64 i = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+    if (i < list_cap) list[i] = p;
+  }
+}
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_deep_fill(FmStrand prim, FmStrand other, const u32* slen, u64 n_stretch, u32 K, const u64* list, u64 n_list,
+                                                   u64* tab, u64 nslots, u64* err) {
+  typedef typename PosOf<WIDE>::type P;
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_list) return;
+  const u64 p = list[i];
+  u64 f0, f1;
+  if (!deep_row_kmer(prim, slen, n_stretch, p, K, f0, f1)) {
+    atomicAdd(err, 1ull);
+    return;
+  }
+  auto sym = [&](u32 j) -> u32 { return (u32)((j < 28u ? f0 >> (2u * j) : f1 >> (2u * (j - 28u))) & 3ull); };
+  const FmRef f = fm_ref(prim, 0);
+  // the chain consumes the K-mer from its last symbol backwards
+  u32 r = 1u + sym(K - 1u);
+  P lo0 = (P)prim.C[r], sz = (P)prim.total[r], lo1 = (P)other.C[r];
+  u64 k0 = (u64)(r - 1u), k1 = 0;
+  for (u32 c = 1; c < K; ++c) {
+    r = 1u + sym(K - 1u - c);
+    if (c < 32u) k0 |= (u64)(r - 1u) << (2u * c);
+    else k1 |= (u64)(r - 1u) << (2u * (c - 32u));
+    if (sz == 0) continue;
+    const u64 n = prim.n;
+    const u64 pl = (u64)lo0 > n ? n : (u64)lo0, pu0 = (u64)(P)(lo0 + sz), pu = pu0 > n ? n : pu0;
+    const Cnt4P<P> l = fm_rank4p<WIDE>(f, (P)pl), u = fm_rank4p<WIDE>(f, (P)pu);
+    const P da = u.a - l.a, dc = u.c - l.c, dg = u.g - l.g, dt = u.t - l.t;
+    const P dd = sz - (da + dc + dg + dt);
+    const P acc = r == 1 ? dd : r == 2 ? dd + da : r == 3 ? dd + da + dc : dd + da + dc + dg;
+    const P lc = r == 1 ? l.a : r == 2 ? l.c : r == 3 ? l.g : l.t;
+    const P dcur = r == 1 ? da : r == 2 ? dc : r == 3 ? dg : dt;
+    lo1 += acc;
+    lo0 = (P)prim.C[r] + lc;
+    sz = dcur;
+  }
+  if (sz == 0 || (u64)lo0 != p || (WIDE && (((u64)lo0 | (u64)lo1 | (u64)sz) >> 40) != 0)) {
+    atomicAdd(err, 1ull);
+    return;
+  }
+  k1 |= (u64)(0x8000u | K) << 48;
+  u64 slot = deep_slot(k0, k1, nslots);
+  for (u64 tries = 0; tries < nslots; ++tries) {
+    if (atomicCAS(&tab[slot * 4 + 1], 0ull, k1) == 0ull) {
+      tab[slot * 4] = k0;
+      if (WIDE) {
+        tab[slot * 4 + 2] = (u64)lo0 | ((u64)lo1 << 40);
+        tab[slot * 4 + 3] = ((u64)lo1 >> 24) | ((u64)sz << 16);
+      } else {
+        tab[slot * 4 + 2] = (u64)(u32)lo0 | ((u64)(u32)lo1 << 32);
+        tab[slot * 4 + 3] = (u64)(u32)sz;
+      }
+      return;
+    }
+    slot = slot + 1 == nslots ? 0 : slot + 1;
+  }
+  atomicAdd(err, 1ull);
+}
+// the chain's state after the K-mer (k0, k1 = its code with the tag of fm_layout.h), or false: not a K-mer of the text
+template <bool WIDE>
+__device__ __forceinline__ bool deep_lookup(const void* tab, u64 nslots, u64 k0, u64 k1, typename PosOf<WIDE>::type& lo0,
+                                            typename PosOf<WIDE>::type& lo1, typename PosOf<WIDE>::type& sz) {
+  typedef typename PosOf<WIDE>::type P;
+  const ulonglong2* q = reinterpret_cast<const ulonglong2*>(tab);
+  u64 slot = deep_slot(k0, k1, nslots);
+  for (;;) {
+    const ulonglong2 key = q[2 * slot], pay = q[2 * slot + 1];
+    if (key.y == 0ull) return false;  // an empty slot ends the probe sequence (the table is never full)
+    if (key.x == k0 && key.y == k1) {
+      if (WIDE) {
+        const u64 m40 = (1ull << 40) - 1ull;
+        lo0 = (P)(pay.x & m40);
+        lo1 = (P)((pay.x >> 40) | ((pay.y & 0xFFFFull) << 24));
+        sz = (P)((pay.y >> 16) & m40);
+      } else {
+        lo0 = (P)(u32)pay.x;
+        lo1 = (P)(u32)(pay.x >> 32);
+        sz = (P)(u32)pay.y;
+      }
+      return true;
+    }
+    slot = slot + 1 == nslots ? 0 : slot + 1;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
 // k_find: one lane per (read, orientation) chain; the four waves of a workgroup are the four chains of 64 reads.  Per step: two rank granules on the chain's primary index
 // (positions lower-1 and upper of IntervalPair::updateL, src/overlap_builder.cpp:95-122); the '$' probe of
 // src/overlap_builder.cpp:861-871 reuses them.  Blocks go to the chain's slots of the candidate arena in
@@ -932,7 +1068,37 @@ __device__ __forceinline__ void find_body(const FindArgs& A, FmTables& tb, SG& s
   P lo0 = 0, sz = 0, lo1 = 0;
   u32 s = 1;                  // this chain's current match length
   bool started = false;
-  if (STAGED && live && A.start_ok && L >= (u32)SIGAX_START_K) {
+  if (STAGED && A.deep_k != 0u) {
+    // the chain's first K = deep_k <= min-overlap symbols from the deep start table of its primary index (fm_layout.h): the
+    // state after them in one lookup, when they are all ACGT and the K-mer occurs in the indexed reads at all
+    const u32 K = A.deep_k;
+    const bool can = live && L >= K;
+    if (__ballot(can) != 0) {
+      u64 k0 = 0, k1 = 0;
+      bool acgt = can;
+      for (u32 i = 0; i < K; ++i) {
+        u32 r = 1u;
+        if (can) {
+          const u32 at = rdo + (fromStart ? i : L - 1u - i);
+          r = COOP ? rd_rank(rd, at) : base_rank(rd[at]);
+        }
+        if (comp) r = comp_rank(r);
+        acgt = acgt && r != 0u;
+        const u64 c = (u64)((r - 1u) & 3u);
+        if (i < 32u) k0 |= c << (2u * i);
+        else k1 |= c << (2u * (i - 32u));
+      }
+      if (acgt) {
+        k1 |= (u64)(0x8000u | K) << 48;
+        P a0 = 0, a1 = 0, az = 0;
+        if (deep_lookup<WIDE>(pf ? A.fwd.deep : A.rev.deep, pf ? A.fwd.deep_slots : A.rev.deep_slots, k0, k1, a0, a1, az)) {
+          lo0 = a0; lo1 = a1; sz = az; s = K;
+          started = true;
+        }
+      }
+    }
+  }
+  if (STAGED && live && !started && A.start_ok && L >= (u32)SIGAX_START_K) {
     // the chain's first twelve symbols from the start table of its primary index (fm_layout.h), when they are all ACGT
     const void* ST = pf ? A.fwd.start : A.rev.start;
     u32 code = 0;
@@ -3737,6 +3903,17 @@ void launch_start_build(const FmStrand& prim, const FmStrand& other, bool wide, 
   else hipLaunchKernelGGL(k_start_build<false>, dim3(g), dim3(256), 0, st, prim, other, tab);
 }
 
+unsigned long long deep_entry_bytes() { return 32; }
+void launch_deep_scan(const FmStrand& s, const u32* slen, u64 n_stretch, u32 K, u64* count, u64* list, u64 list_cap, hipStream_t st) {
+  if (s.n == 0) return;
+  hipLaunchKernelGGL(k_deep_scan, dim3(nblk(s.n, 256)), dim3(256), 0, st, s, slen, n_stretch, K, count, list, list_cap);
+}
+void launch_deep_fill(const FmStrand& prim, const FmStrand& other, bool wide, const u32* slen, u64 n_stretch, u32 K, const u64* list, u64 n_list,
+                      void* tab, u64 nslots, u64* err, hipStream_t st) {
+  if (n_list == 0) return;
+  if (wide) hipLaunchKernelGGL(k_deep_fill<true>, dim3(nblk(n_list, 256)), dim3(256), 0, st, prim, other, slen, n_stretch, K, list, n_list, (u64*)tab, nslots, err);
+  else hipLaunchKernelGGL(k_deep_fill<false>, dim3(nblk(n_list, 256)), dim3(256), 0, st, prim, other, slen, n_stretch, K, list, n_list, (u64*)tab, nslots, err);
+}
 void launch_suffix_order_check(const FmStrand& s, const u32* sai, u32* isai_tmp, const u32* read_len, u64 n_strings, u64* bad3, hipStream_t st) {
   if (n_strings == 0 || s.n < 2) return;
   hipLaunchKernelGGL(k_isai, dim3(nblk(n_strings, 256)), dim3(256), 0, st, sai, n_strings, isai_tmp);

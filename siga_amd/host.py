@@ -5,8 +5,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libsiga_host.so")
-CLI_PATH = os.path.join(HERE, "lib", "siga")
+# SIGA_HOST_LIB / SIGA_CLI: another build of the host side (tools/sanitize_host.sh runs the CPU tests on ASan/UBSan and TSan builds)
+LIB_PATH = os.environ.get("SIGA_HOST_LIB", os.path.join(HERE, "lib", "libsiga_host.so"))
+CLI_PATH = os.environ.get("SIGA_CLI", os.path.join(HERE, "lib", "siga"))
 _lib = None
 
 

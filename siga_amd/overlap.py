@@ -116,6 +116,7 @@ class FMIndexPair:
                                            device, C.byref(h)), "sigax_index_open")
         pair = cls(h.value)
         pair._prepare_pending = bool(resident)  # at set_reads() (the longest read is known then) or the first batch
+        pair._resident = bool(resident)
         return pair
 
     @classmethod
@@ -132,6 +133,7 @@ class FMIndexPair:
                                                n_strings, ps, pr, device, C.byref(h)), "sigax_index_open_mem")
         pair = cls(h.value)
         pair._prepare_pending = bool(resident)  # at set_reads() (the longest read is known then) or the first batch
+        pair._resident = bool(resident)
         return pair
 
     def close(self):
@@ -167,6 +169,12 @@ class FMIndexPair:
         """sigax_index_prepare: the extractor's row tables in place now"""
         self._prepare_pending = False
         _check(_lib.lib().sigax_index_prepare(self._h), "sigax_index_prepare")
+
+    def prepare_overlap(self, min_overlap):
+        """sigax_index_prepare_overlap: row tables + the block finder's deep start table for this minimum overlap"""
+        self._prepare_pending = False
+        self._deep_for = min(getattr(self, "_deep_for", 1 << 30), int(min_overlap))
+        _check(_lib.lib().sigax_index_prepare_overlap(self._h, int(min_overlap)), "sigax_index_prepare_overlap")
 
     def check_order(self, which=0):
         """sigax_index_check_order: (pairs of adjacent BWT rows out of suffix order, first such row, undecided pairs)"""
@@ -208,7 +216,9 @@ class OverlapBuilder:
     def overlap(self, seqs, min_overlap, read_base=0, edges=False, _flags=None):
         """Batched OverlapBuilder::overlap.  Returns dict(block_offs, blocks, substring, edges, stats)."""
         buf, offs = pack_reads(seqs)
-        if getattr(self.fmi, "_prepare_pending", False):
+        if getattr(self.fmi, "_resident", False) and _flags is None and min_overlap < getattr(self.fmi, "_deep_for", 1 << 30):
+            self.fmi.prepare_overlap(min_overlap)  # an index that stays open: tables for this minimum overlap (and larger ones)
+        elif getattr(self.fmi, "_prepare_pending", False):
             self.fmi.prepare()
         res = _lib.Result()
         if isinstance(buf, np.ndarray):

@@ -343,3 +343,101 @@ def test_batches_in_flight_on_one_index(sa):
         for bt, sp in zip(bts, streams):
             L.sigax_batch_destroy(bt)
             L.sigax_stream_destroy(0, sp)
+
+
+def _run_batch(sa, L, pair, seqs, m, flags):
+    """one run through the device-resident batch API -> (offs, blocks, substring, edges, stats dict, run-info dict)"""
+    import ctypes as C
+    from siga_amd import _lib
+    from siga_amd.overlap import pack_reads
+    buf, offs = pack_reads(seqs)
+    bt = C.c_void_p()
+    assert L.sigax_batch_create(pair.handle, len(seqs), len(buf), max(map(len, seqs)), C.byref(bt)) == 0, _lib.last_error()
+    try:
+        assert L.sigax_batch_upload(bt, buf, offs.ctypes.data, len(seqs), None) == 0, _lib.last_error()
+        assert L.sigax_batch_run(bt, 0, m, flags, None) == 0, _lib.last_error()
+        stats, ri = _lib.Stats(), _lib.RunInfo()
+        assert L.sigax_batch_finish(bt, None, C.byref(stats)) == 0, _lib.last_error()
+        assert L.sigax_batch_run_info(bt, C.byref(ri)) == 0, _lib.last_error()
+        return _batch_download(sa, L, bt) + (stats.as_dict(), ri.as_dict())
+    finally:
+        L.sigax_batch_destroy(bt)
+
+
+def _same_run(a, b):
+    assert np.array_equal(a[0], b[0])
+    assert a[1].tobytes() == b[1].tobytes()
+    assert np.array_equal(a[2], b[2])
+    assert a[3].tobytes() == b[3].tobytes()
+    for k in ("n_blocks", "n_edges", "n_candidate_blocks", "n_occ_find", "n_occ_extract", "n_substring"):
+        assert a[4][k] == b[4][k], k
+
+
+@pytest.mark.parametrize("name", ["toy", "ragged"])
+def test_deep_start_table_serves_the_runs_it_may(sa, name):
+    """The block finder's deep start table (sigax_index_prepare_overlap, fm_layout.h): chains start K = min(min-overlap, 56)
+    symbols in after one lookup.  A run whose min-overlap is at least the table's K uses it, a run below it walks, asking
+    for a smaller min-overlap replaces the table -- and every run gives the blocks, edges and rank-evaluation counts of the
+    index without the table (which the suite above pins to the oracle), with fewer table sectors asked for."""
+    from siga_amd import _lib
+    from siga_amd.overlap import name_ranks
+    fx = fixture(name)
+    reads = sa.overlap.read_sequences(fx.fa)
+    seqs = [r[2] for r in reads]
+    L = _lib.lib()
+    flags = _lib.SIGAX_IRREDUCIBLE | _lib.SIGAX_RC | _lib.SIGAX_EDGES
+    meta = (np.array([len(s) for s in seqs], dtype=np.uint32), name_ranks([r[0] for r in reads]))
+    plain = sa.FMIndexPair.load(fx.prefix, resident=False)
+    plain.set_reads(*meta)
+    pair = sa.FMIndexPair.load(fx.prefix, resident=False)
+    pair.set_reads(*meta)
+    big, small = (45, 20) if name == "toy" else (30, 16)
+    want = {m: _run_batch(sa, L, plain, seqs, m, flags) for m in (big, big + 5, small, small + 3, small - 4)}
+    assert all(w[5]["deep_k"] == 0 for w in want.values())
+    pair.prepare_overlap(big)
+    got = _run_batch(sa, L, pair, seqs, big, flags)
+    assert got[5]["deep_k"] == big
+    _same_run(got, want[big])
+    assert got[4]["n_sectors_find"] < want[big][4]["n_sectors_find"]
+    got = _run_batch(sa, L, pair, seqs, big + 5, flags)   # a larger min-overlap starts from the same table
+    assert got[5]["deep_k"] == big
+    _same_run(got, want[big + 5])
+    got = _run_batch(sa, L, pair, seqs, small, flags)     # a smaller one cannot
+    assert got[5]["deep_k"] == 0
+    _same_run(got, want[small])
+    pair.prepare_overlap(small)                           # ... until the table is replaced
+    for m in (small, small + 3, big):
+        got = _run_batch(sa, L, pair, seqs, m, flags)
+        assert got[5]["deep_k"] == small, m
+        _same_run(got, want[m])
+    got = _run_batch(sa, L, pair, seqs, small - 4, flags)
+    assert got[5]["deep_k"] == 0
+    _same_run(got, want[small - 4])
+    pair.prepare_overlap(8)                               # below 16 symbols the 12-mer table is all there is: no-op
+    assert _run_batch(sa, L, pair, seqs, small, flags)[5]["deep_k"] == small
+
+
+def test_deep_start_table_comes_with_reuse(sa):
+    """Without sigax_index_prepare_overlap the table is built in the background once the index has been asked for as many
+    reads as it holds, for the min-overlap of the run at hand; runs before it is there walk -- same bytes."""
+    import time
+    from siga_amd import _lib
+    from siga_amd.overlap import name_ranks
+    fx = fixture("toy")
+    reads = sa.overlap.read_sequences(fx.fa)
+    seqs = [r[2] for r in reads]
+    L = _lib.lib()
+    flags = _lib.SIGAX_IRREDUCIBLE | _lib.SIGAX_RC | _lib.SIGAX_EDGES
+    pair = sa.FMIndexPair.load(fx.prefix, resident=False)
+    pair.set_reads(np.array([len(s) for s in seqs], dtype=np.uint32), name_ranks([r[0] for r in reads]))
+    first = _run_batch(sa, L, pair, seqs, 45, flags)
+    assert first[5]["deep_k"] == 0
+    seen = 0
+    for _ in range(50):
+        got = _run_batch(sa, L, pair, seqs, 45, flags)
+        _same_run(got, first)
+        seen = got[5]["deep_k"]
+        if seen:
+            break
+        time.sleep(0.1)
+    assert seen == 45

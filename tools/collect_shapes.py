@@ -1,4 +1,4 @@
-"""Turn what tools/r3_shapes.sh left under gpurun_out/shapes/ (one rank's shard of the 8-GPU jobs of BASELINE configs[2] = c3
+"""Turn what tools/shapes.sh left under gpurun_out/shapes/ (one rank's shard of the 8-GPU jobs of BASELINE configs[2] = c3
 and configs[4] = c5, `bench.py --emulate-world 8`) into the committed summaries under profiles/:
 <R>_kernel_stats_<shape>.csv (rocprofv3 --kernel-trace --stats), <R>_bench_under_rocprof_<shape>.json (the bench line of that
 same run), <R>_bench_<shape>.json (the plain run with --isolated), <R>_pmc_<shape>.json (TCC size-class counters per kernel

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun -- bash tools/r3_shapes.sh c3|c5 [bench|kt|pmc ...]): one rank's shard of the 8-GPU jobs of
+# Runs on the GPU box (gpurun -- bash tools/shapes.sh c3|c5 [bench|kt|pmc ...]): one rank's shard of the 8-GPU jobs of
 # BASELINE configs[2] (c3) and configs[4] at full size (c5) on this GPU (bench.py --emulate-world 8): the bench line, the
 # rocprofv3 kernel-trace summary of the same command and the TCC size-class PMC passes, left under gpurun_out/shapes/ for
 # tools/collect_shapes.py.  Counters are collected in their own passes with --kernel-trace only.
@@ -7,7 +7,7 @@ shape=${1:-c3}; shift
 what=${@:-bench kt pmc}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/shapes; mkdir -p $O
+O=${SHAPES_OUT:-gpurun_out/shapes}; mkdir -p $O
 export SIGAX_TABLES_SYNC=1   # row tables at open: every profiled launch is a steady-state one
 if [ "$shape" = c3 ]; then
   A="--emulate-world 8 --cpu-sample 0"    # defaults = configs[2]: 2.5 M reads per rank from 20 M x 150 bp, 100 Mb, seed 2
