@@ -129,6 +129,38 @@ def self_launch(args):
     return subprocess.call(cmd)
 
 
+def make_sigax_comm(lib, rank, world, dev_index, dev):
+    """The library's own communicator for the edge gather (include/sigax.h: sigax_comm_*, RCCL bound at run time): rank 0's
+    unique id travels over the torch process group; whether every rank got its communicator is agreed on before anyone uses
+    it (MIN all-reduce), so a rank that could not falls back together with the others.  Returns the handle or None."""
+    import torch
+    import torch.distributed as dist
+    idbuf = (C.c_uint8 * 128)()
+    ok = 1
+    if rank == 0:
+        ok = 1 if lib.sigax_comm_unique_id(idbuf) == 0 else 0
+        if not ok:
+            log("sigax_comm_unique_id: " + lib.sigax_last_error().decode(errors="replace"))
+    t = torch.tensor(list(idbuf) + [ok], dtype=torch.uint8, device=dev)
+    dist.broadcast(t, src=0)
+    vals = t.cpu().tolist()
+    if vals[128] != 1:
+        return None
+    for i in range(128):
+        idbuf[i] = vals[i]
+    h = C.c_void_p()
+    rc = lib.sigax_comm_create(dev_index, rank, world, idbuf, C.byref(h))
+    if rc != 0:
+        log("rank %d sigax_comm_create: %s" % (rank, lib.sigax_last_error().decode(errors="replace")))
+    flag = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        if rc == 0:
+            lib.sigax_comm_destroy(h)
+        return None
+    return h
+
+
 def rank_of_r_names(n):
     from tests.golden.make_reads import rank_of_r_names as f
     return f(n)
@@ -220,6 +252,13 @@ def bench_overlap(args):
     pair.prepare_overlap(args.min_overlap)
     log("index on GPU: %.1f MB, wide=%d (%.1f s since start)" % (info["device_bytes"] / 1e6, info["wide"], time.time() - t0))
 
+    # N > 1 over RCCL: the edge gather goes through the library's own exchange step (sigax_gather_counts + sigax_gather_edges:
+    # ncclAllGather of counts, grouped ncclSend/ncclRecv of records); torch.distributed's gather stays as the fallback
+    # (gloo rehearsals, SIGA_BENCH_TORCH_GATHER=1, or a rank without its communicator)
+    comm = None
+    if world > 1 and args.backend == "nccl" and os.environ.get("SIGA_BENCH_TORCH_GATHER") != "1":
+        comm = make_sigax_comm(_lib.lib(), rank, world, dev_index, dev)
+        log("rank %d: edge gather through %s" % (rank, "sigax_gather_edges (RCCL, C-ABI)" if comm else "torch.distributed"))
     n_local = hi - lo
     d_seqs = torch.from_numpy(np.ascontiguousarray(shard).reshape(-1)).to(dev)
     d_offs = torch.arange(0, (n_local + 1) * L, L, dtype=torch.int64, device=dev)
@@ -256,6 +295,8 @@ def bench_overlap(args):
     inflight = [False] * depth
     pending = []  # edge gathers in flight: step k's gather runs beside step k+1's kernels
     last_edges = [0]
+    gather_buf = [None] * depth   # rank 0, sigax_gather_edges: device buffers the gathered records land in
+    gathered_total = [0]
     host_edges = [None] * depth   # pinned host buffers: where a step's edge records end up (rank 0)
     host_cap = [0]
 
@@ -303,6 +344,26 @@ def bench_overlap(args):
                 # and is waited for when this batch object is finished the next time (or by the final synchronize)
                 if ne:
                     land(i, torch.as_tensor(_EdgeView(d_edges.value, ne), device=dev))
+            elif comm is not None:
+                # the library's exchange step on the batch's own stream: counts (one host wait), then the records straight
+                # out of the batch's edge buffer (the batch's next run is ordered behind them on this stream) into rank 0's
+                # device buffer, and from there to pinned host memory
+                cnts = (C.c_uint64 * world)()
+                rc = lib.sigax_gather_counts(comm, ne, cnts, sp)
+                if rc != 0:
+                    raise SystemExit("sigax_gather_counts: " + _lib.last_error())
+                tot = sum(int(c) for c in cnts)
+                gathered_total[0] = tot
+                dout = None
+                if rank == 0:
+                    if gather_buf[i] is None or gather_buf[i].shape[0] < tot:
+                        gather_buf[i] = torch.empty((int(tot * 1.25) + 1024, 4), dtype=torch.int32, device=dev)
+                    dout = C.c_void_p(gather_buf[i].data_ptr())
+                rc = lib.sigax_gather_edges(comm, d_edges, cnts, 0, dout, sp)
+                if rc != 0:
+                    raise SystemExit("sigax_gather_edges: " + _lib.last_error())
+                if rank == 0 and tot:
+                    land(i, gather_buf[i][:tot])
             else:
                 # copy out of the batch's buffer (its next run overwrites it), then gather asynchronously
                 local = torch.as_tensor(_EdgeView(d_edges.value, ne), device=dev).clone() if ne else torch.zeros((0, 4), dtype=torch.int32, device=dev)
@@ -351,7 +412,9 @@ def bench_overlap(args):
     t_start = time.perf_counter()
     run_steps(args.steps, depth + args.warmup)
     total_edges = last_edges[0]
-    if world > 1:
+    if world > 1 and comm is not None:
+        total_edges = gathered_total[0]  # (the copies to pinned host memory are waited for by the synchronize below)
+    elif world > 1:
         total_edges = drain()  # every step's edge records have reached rank 0 before the clock stops
     torch.cuda.synchronize(dev)  # ... and its pinned host buffer
     if world > 1:
@@ -506,12 +569,17 @@ def bench_overlap(args):
         if world > 1:
             # what RCCL saw (the driver's SCALE record can be checked against it)
             out["config"]["ranks"] = {"backend": args.backend, "world_size": dist.get_world_size(), "devices_visible": torch.cuda.device_count(),
-                                      "device_of_rank0": dev_index}
+                                      "device_of_rank0": dev_index,
+                                      "edge_gather": "sigax_gather_counts + sigax_gather_edges (C-ABI; ncclAllGather + grouped ncclSend/ncclRecv)"
+                                                     if comm is not None else "torch.distributed all_gather + gather (%s)" % args.backend}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(prefix, reads, min(args.cpu_sample, n_total), args.min_overlap, st, lib, batch)
 
     for bt in batches:
         lib.sigax_batch_destroy(bt)
+    if comm is not None:
+        torch.cuda.synchronize(dev)
+        lib.sigax_comm_destroy(comm)
     pair.close()
     if rank == 0 and world == 1 and job_world == 1 and not args.no_e2e and not args.error_rate and not by_pos and n_total <= 2000000:
         if reads is None:

@@ -248,6 +248,30 @@ typedef struct sigax_run_info {
 } sigax_run_info;
 int  sigax_batch_run_info(sigax_batch*, sigax_run_info* out);
 
+/* ---- Multi-GPU: the one exchange step -----------------------------------------------------------------
+ * Reads shard across the GPUs of a node and the index is replicated (sigax_index_clone), so the path has exactly one
+ * exchange: the variable-length gather of a step's fixed-size edge records to one rank -- what replaces the serial
+ * hits -> ASQG pass of src/overlap_builder.cpp:466-483 when one process drives each GPU.  Over RCCL (xGMI between the
+ * MI355X of a node): ncclAllGather of the per-rank counts, then grouped ncclSend / ncclRecv of the 16-byte records.
+ * Gathered in rank order = read order: the ED order of a one-GPU run.  RCCL is bound at run time; without it these calls
+ * fail with SIGAX_E_DEVICE and nothing else in the library is affected.  (The C++ host's `siga overlap --gpus N` drives
+ * all GPUs from one process and copies each GPU's records to the host over that GPU's own PCIe link instead.) */
+typedef struct sigax_comm sigax_comm;
+#define SIGAX_COMM_ID_BYTES 128
+/* rank 0 makes the id (ncclGetUniqueId) and ships it to the other ranks by whatever means the launcher has */
+int  sigax_comm_unique_id(uint8_t id[SIGAX_COMM_ID_BYTES]);
+/* collective over all `world` ranks (ncclCommInitRank), each on its own `device` */
+int  sigax_comm_create(int device, int rank, int world, const uint8_t id[SIGAX_COMM_ID_BYTES], sigax_comm** out);
+void sigax_comm_destroy(sigax_comm*);
+/* The gather, two collectives.  sigax_gather_counts: every rank says how many records it holds; counts[world] (host)
+ * receives all ranks' counts before the call returns (ncclAllGather + one host wait on `stream`), so that the root can size
+ * its buffer.  sigax_gather_edges: with those counts, the transfer of the records is enqueued on `stream` (grouped ncclSend /
+ * ncclRecv); d_local = this rank's counts[rank] records in device memory (e.g. sigax_batch_device_outputs' d_edges), on
+ * `root` d_out (device, room for the sum of the counts) receives rank 0's records first; other ranks pass d_out = NULL. */
+int  sigax_gather_counts(sigax_comm*, uint64_t n_local, uint64_t* counts, void* stream);
+int  sigax_gather_edges(sigax_comm*, const sigax_edge* d_local, const uint64_t* counts, int root, sigax_edge* d_out,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,7 @@ SYMBOLS = [
     "sigax_correct_batch", "sigax_correct_device", "sigax_overlap_batch", "sigax_result_free", "sigax_batch_create", "sigax_batch_destroy", "sigax_batch_upload",
     "sigax_batch_set_device_reads", "sigax_batch_set_subbatches", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
     "sigax_batch_download", "sigax_batch_download_edges", "sigax_batch_size_hint", "sigax_batch_kernel_ms", "sigax_batch_run_info", "sigax_build_strand", "sigax_build_session", "sigax_free",
+    "sigax_comm_unique_id", "sigax_comm_create", "sigax_comm_destroy", "sigax_gather_counts", "sigax_gather_edges",
 ]
 
 _lib = None
@@ -113,6 +114,12 @@ def lib():
     L.sigax_free.restype = None
     L.sigax_build_session.argtypes = [ci]
     L.sigax_build_session.restype = None
+    L.sigax_comm_unique_id.argtypes = [vp]
+    L.sigax_comm_create.argtypes = [ci, ci, ci, vp, pvp]
+    L.sigax_comm_destroy.argtypes = [vp]
+    L.sigax_comm_destroy.restype = None
+    L.sigax_gather_counts.argtypes = [vp, u64, vp, vp]
+    L.sigax_gather_edges.argtypes = [vp, vp, vp, ci, vp, vp]
     _lib = L
     return L
 

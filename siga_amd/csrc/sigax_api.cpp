@@ -760,6 +760,7 @@ static bool build_deep_tables(sigax_index* ix, const FmStrand st[2], uint32_t K,
     ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, sb) == hipSuccess &&
          hipStreamSynchronize(sb) == hipSuccess;
     distinct[s] = h[0];
+    if (distinct[s] >= (1ull << 32) - 256) ok = false;  // (one launch of k_deep_fill, one lane per K-mer)
   }
   if (ok) {
     // both strands' tables + the larger list must fit `share` per cent of what is free now

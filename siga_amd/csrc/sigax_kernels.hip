@@ -613,34 +613,37 @@ __device__ __forceinline__ bool deep_row_kmer(const FmStrand& st, const u32* sle
   return true;
 }
 __global__ __launch_bounds__(256) void k_deep_scan(FmStrand st, const u32* slen, u64 n_stretch, u32 K, u64* count, u64* list, u64 list_cap) {
-  const u64 p = (u64)blockIdx.x * 256 + threadIdx.x;
   const u32 lane = threadIdx.x & 63u;
-  u64 f0 = 0, f1 = 0;
-  bool v = false;
-  if (p < st.n) v = deep_row_kmer(st, slen, n_stretch, p, K, f0, f1);
-  // the row before: the lane below has it, except for the wave's first lane
-  u64 g0 = __shfl_up(f0, 1, 64), g1 = __shfl_up(f1, 1, 64);
-  bool pv = __shfl_up((int)v, 1, 64) != 0;
-  if (lane == 0) {
-    pv = false;
-    if (p > 0 && p < st.n) pv = deep_row_kmer(st, slen, n_stretch, p - 1, K, g0, g1);
-  }
-  const bool first = v && (!pv || g0 != f0 || g1 != f1);
-  const u64 m = __ballot(first);
-  if (!m) return;
-  u64 base = 0;
-  if (lane == 0) base = atomicAdd(count, (u64)__popcll(m));
-  base = __shfl(base, 0, 64);
-  if (list != nullptr && first) {
-    const u64 i = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
-    if (i < list_cap) list[i] = p;
+  // waves walk the rows in strides of the grid (a launch holds fewer than 2^32 threads; BASELINE configs[4] has 1.3e10 rows)
+  for (u64 p0 = (u64)blockIdx.x * 256; p0 < st.n; p0 += (u64)gridDim.x * 256) {
+    const u64 p = p0 + threadIdx.x;
+    u64 f0 = 0, f1 = 0;
+    bool v = false;
+    if (p < st.n) v = deep_row_kmer(st, slen, n_stretch, p, K, f0, f1);
+    // the row before: the lane below has it, except for the wave's first lane
+    u64 g0 = __shfl_up(f0, 1, 64), g1 = __shfl_up(f1, 1, 64);
+    bool pv = __shfl_up((int)v, 1, 64) != 0;
+    if (lane == 0) {
+      pv = false;
+      if (p > 0 && p < st.n) pv = deep_row_kmer(st, slen, n_stretch, p - 1, K, g0, g1);
+    }
+    const bool first = v && (!pv || g0 != f0 || g1 != f1);
+    const u64 m = __ballot(first);
+    if (!m) continue;
+    u64 base = 0;
+    if (lane == 0) base = atomicAdd(count, (u64)__popcll(m));
+    base = __shfl(base, 0, 64);
+    if (list != nullptr && first) {
+      const u64 i = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+      if (i < list_cap) list[i] = p;
+    }
   }
 }
 template <bool WIDE>
 __global__ __launch_bounds__(256) void k_deep_fill(FmStrand prim, FmStrand other, const u32* slen, u64 n_stretch, u32 K, const u64* list, u64 n_list,
                                                    u64* tab, u64 nslots, u64* err) {
   typedef typename PosOf<WIDE>::type P;
-  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;  // (fewer than 2^32 distinct K-mers: the host checks)
   if (i >= n_list) return;
   const u64 p = list[i];
   u64 f0, f1;
@@ -3906,7 +3909,7 @@ void launch_start_build(const FmStrand& prim, const FmStrand& other, bool wide, 
 unsigned long long deep_entry_bytes() { return 32; }
 void launch_deep_scan(const FmStrand& s, const u32* slen, u64 n_stretch, u32 K, u64* count, u64* list, u64 list_cap, hipStream_t st) {
   if (s.n == 0) return;
-  hipLaunchKernelGGL(k_deep_scan, dim3(nblk(s.n, 256)), dim3(256), 0, st, s, slen, n_stretch, K, count, list, list_cap);
+  hipLaunchKernelGGL(k_deep_scan, dim3((unsigned)std::min<u64>((s.n + 255) / 256, 1u << 22)), dim3(256), 0, st, s, slen, n_stretch, K, count, list, list_cap);
 }
 void launch_deep_fill(const FmStrand& prim, const FmStrand& other, bool wide, const u32* slen, u64 n_stretch, u32 K, const u64* list, u64 n_list,
                       void* tab, u64 nslots, u64* err, hipStream_t st) {

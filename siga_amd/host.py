@@ -33,6 +33,8 @@ def lib():
         L.sigah_write_file.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64]
         L.sigah_correct_file.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                          C.c_int, C.c_char_p, C.c_uint64]
+        L.sigah_format_asqg.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int]
+        L.sigah_format_asqg.restype = C.c_int64
         L.sigah_rmdup_file.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_uint64]
         _lib = L
     return _lib
@@ -124,3 +126,15 @@ def stem(path):
     out = C.create_string_buffer(1024)
     lib().sigah_stem(path.encode(), out, 1024)
     return out.value.decode()
+
+
+def format_asqg(reads_path, substring, edges, min_overlap, out_path, threads=4):
+    """Test hook: the text side of OverlapBuilder::build without a GPU (loader, VT lines, raw-pointer ED formatter, output
+    stream) for given substring flags (uint8[n]) and edge records (EDGE_DTYPE[k]).  Returns the number of reads."""
+    sub = np.ascontiguousarray(substring, dtype=np.uint8)
+    ed = np.ascontiguousarray(edges)
+    assert ed.dtype.itemsize == 16
+    n = lib().sigah_format_asqg(reads_path.encode(), sub.ctypes.data, ed.ctypes.data, len(ed), min_overlap, out_path.encode(), threads)
+    if n < 0:
+        raise RuntimeError("sigah_format_asqg failed")
+    return int(n)

@@ -1282,6 +1282,33 @@ static char* write_edge(char* p, const sigax_edge& e, const ReadStore& reads, co
 }
 
 
+// ED text of `cnt` edge records in chunks of ed_chunk lines, one string per chunk, on nt threads: every chunk gets room for
+// the longest lines there can be (two names of max_name bytes + kEdgeLineExtra) and is written through a raw pointer.
+static void format_edge_text(const ReadStore& reads, const uint32_t* read_len, const sigax_edge* e, uint64_t cnt, unsigned nt, uint32_t max_name,
+                             size_t ed_chunk, std::vector<std::string>* parts) {
+  parts->assign((cnt + ed_chunk - 1) / ed_chunk, std::string());
+  parallel_for(parts->size(), nt, [&](size_t c) {
+    const uint64_t cb = c * ed_chunk, ce = std::min<uint64_t>(cnt, cb + ed_chunk);
+    std::string& o = (*parts)[c];
+    o.resize((ce - cb) * (2 * (size_t)max_name + kEdgeLineExtra));  // room for the longest line there can be, times the lines
+    char* w = &o[0];
+    // a target's name is three dependent misses away (header offset, name length, the bytes in the file image):
+    // asked for sixteen and eight edges ahead
+    for (uint64_t i = cb; i < ce; ++i) {
+      if (i + 16 < ce) {
+        const uint32_t t = e[i + 16].target;
+        __builtin_prefetch(&reads.head_off[t]);
+        __builtin_prefetch(&reads.name_len[t]);
+        __builtin_prefetch(&read_len[t]);
+      }
+      if (i + 8 < ce) __builtin_prefetch(reads.file.data() + reads.head_off[e[i + 8].target]);
+      w = write_edge(w, e[i], reads, read_len);
+    }
+    o.resize((size_t)(w - &o[0]));
+    o.shrink_to_fit();  // the text may be held until the last batch is through: not with three times its size in reserve
+  });
+}
+
 struct PhaseTimer {  // SIGA_TIMING=1: phase times on stderr
   bool on;
   std::chrono::steady_clock::time_point t;
@@ -1632,27 +1659,7 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
   uint32_t max_name = 0;
   for (uint32_t l : reads.name_len) max_name = std::max(max_name, l);
   auto format_edges = [&](const sigax_edge* e, uint64_t cnt, std::vector<std::string>* parts) {
-    parts->assign((cnt + ed_chunk - 1) / ed_chunk, std::string());
-    parallel_for(parts->size(), nt, [&](size_t c) {
-      const uint64_t cb = c * ed_chunk, ce = std::min<uint64_t>(cnt, cb + ed_chunk);
-      std::string& o = (*parts)[c];
-      o.resize((ce - cb) * (2 * (size_t)max_name + kEdgeLineExtra));  // room for the longest line there can be, times the lines
-      char* w = &o[0];
-      // a target's name is three dependent misses away (header offset, name length, the bytes in the file image):
-      // asked for sixteen and eight edges ahead
-      for (uint64_t i = cb; i < ce; ++i) {
-        if (i + 16 < ce) {
-          const uint32_t t = e[i + 16].target;
-          __builtin_prefetch(&reads.head_off[t]);
-          __builtin_prefetch(&reads.name_len[t]);
-          __builtin_prefetch(&read_len[t]);
-        }
-        if (i + 8 < ce) __builtin_prefetch(reads.file.data() + reads.head_off[e[i + 8].target]);
-        w = write_edge(w, e[i], reads, read_len);
-      }
-      o.resize((size_t)(w - &o[0]));
-      o.shrink_to_fit();  // the text may be held until the last batch is through: not with three times its size in reserve
-    });
+    format_edge_text(reads, read_len, e, cnt, nt, max_name, ed_chunk, parts);
   };
   const size_t vt_chunk = 4096;
   for (size_t b = 0; b < nbatch; ++b) {
@@ -2116,6 +2123,39 @@ int64_t sigah_parse_file(const char* path, int mode, const char* out_path, int t
   }
   fclose(f);
   return n;
+}
+
+// Test hook (CPU tests, sanitizer builds): the text side of OverlapBuilder::build without a GPU -- the reads of `path` through
+// the loader, VT lines (substring flags given) and the ED lines of the given edge records through the same formatters and
+// the same output stream (gz by name) build() uses.  Returns the number of reads, -1 on failure.
+int64_t sigah_format_asqg(const char* path, const uint8_t* substring, const sigax_edge* edges, uint64_t n_edges, uint64_t min_overlap,
+                          const char* out_path, int threads) {
+  const unsigned nt = (unsigned)std::max(threads, 1);
+  sigah::ReadStore rs;
+  if (!sigah::LoadReads(path, &rs, nt)) return -1;
+  std::vector<uint32_t> lengths, ranks;
+  sigah::name_ranks(rs, nt, &lengths, &ranks);
+  for (uint64_t i = 0; i < n_edges; ++i)
+    if (edges[i].query >= rs.size() || edges[i].target >= rs.size()) return -1;
+  sigah::OutFile out(out_path, nt);
+  if (!out.ok()) return -1;
+  out.write("HT\tVN:i:1\tOL:i:" + std::to_string((int)min_overlap) + "\tCN:i:1\n");
+  uint32_t maxLen = 0, max_name = 0;
+  for (uint32_t l : lengths) maxLen = std::max(maxLen, l);
+  for (uint32_t l : rs.name_len) max_name = std::max(max_name, l);
+  const size_t vt_chunk = 4096;
+  std::vector<std::string> parts((rs.size() + vt_chunk - 1) / vt_chunk);
+  sigah::parallel_for(parts.size(), nt, [&](size_t c) {
+    const size_t cb = c * vt_chunk, ce = std::min(rs.size(), cb + vt_chunk);
+    std::string& o = parts[c];
+    o.reserve((ce - cb) * (maxLen + 32));
+    for (size_t i = cb; i < ce; ++i) sigah::write_vertex(o, rs.name(i), rs.comment(i), rs.seq(i), substring && substring[i] != 0);
+  });
+  out.write_parts(parts);
+  std::vector<std::string> ed;
+  sigah::format_edge_text(rs, lengths.data(), edges, n_edges, nt, max_name, 1000, &ed);
+  out.write_parts(ed);
+  return out.close() ? (int64_t)rs.size() : -1;
 }
 
 // Utils::ofstream as used for <prefix>.asqg.gz: write `n` bytes in `pieces` write() calls (gz when the name ends with .gz)

@@ -432,3 +432,38 @@ def test_sai_writer_slices_join_up(tmp_path):
         assert rows.shape == (n, 2) and np.all(rows[:, 1] == b"0")
         ids = rows[:, 0].astype(np.int64)
         assert np.array_equal(np.sort(ids), np.arange(n))
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_asqg_text_formatters_without_a_gpu(tmp_path, gz):
+    """The text side of OverlapBuilder::build (src/overlap_builder.cpp:291-329,345-375,423-509) on the CPU: parallel loader,
+    VT lines with the comment tags, ED lines through the raw-pointer formatter sized for the longest names, the block-parallel
+    output stream -- for random edge records and substring flags, against the Python mirror's text.  (What the sanitizer
+    builds of tools/sanitize_host.sh exercise of the formatter: names of very different lengths, every flag combination.)"""
+    import gzip
+    import random
+    from siga_amd import host
+    from siga_amd.overlap import EDGE_DTYPE, format_asqg, read_sequences
+    rnd = random.Random(7)
+    n = 5000
+    recs = []
+    for i in range(n):
+        name = "r%d" % i if i % 3 else "read_with_a_much_longer_name_%d_%s" % (i, "x" * rnd.randrange(0, 60))
+        com = rnd.choice(["", " CR:i:%d" % rnd.randrange(100), " BX:Z:ACGT-1 EX:Z:foo", " free text here"])
+        seq = "".join(rnd.choice("ACGT") for _ in range(rnd.randrange(30, 200)))
+        recs.append(">%s%s\n%s\n" % (name, com, seq))
+    fa = str(tmp_path / "r.fa")
+    open(fa, "w").write("".join(recs))
+    reads = read_sequences(fa)
+    assert len(reads) == n
+    k = 20000
+    ed = np.zeros(k, dtype=EDGE_DTYPE)
+    for j in range(k):
+        q, t = rnd.randrange(n), rnd.randrange(n)
+        ed[j] = (q, t, rnd.randrange(1, min(len(reads[q][2]), len(reads[t][2])) + 1), rnd.randrange(8))
+    sub = np.array([rnd.random() < 0.1 for _ in range(n)], dtype=np.uint8)
+    out = str(tmp_path / ("o.asqg.gz" if gz else "o.asqg"))
+    assert host.format_asqg(fa, sub, ed, 45, out, threads=5) == n
+    got = (gzip.open(out, "rb") if gz else open(out, "rb")).read().decode("latin-1")
+    want = format_asqg(reads, {"substring": sub, "edges": ed}, 45)
+    assert got == want

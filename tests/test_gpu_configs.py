@@ -151,3 +151,73 @@ def test_c5_full_size_wide_index_one_shard_of_eight():
     N = 50000000
     info = _big_case("c5", N, 230000000, 250, 3, world=8, sample=50000)
     assert info["n_symbols"] == N * 251 >= 2**32 and info["wide"] == 1
+
+
+def test_pipeline_on_reads_with_errors_correct_index_rmdup_overlap(tmp_path):
+    """The reference's pipeline ORDER on reads with sequencing errors (examples/siga-ecoli-miseq.sh:64-85): `index --no-reverse`
+    -> `correct -k 31` -> `index` -> `rmdup` (what the extractor's own error message prescribes before an overlap,
+    src/overlap_builder.cpp:755-756) -> `index` -> `overlap -m 45`, every step through the CLI on the GPU, every file byte for
+    byte the oracle's run of the same step on the same input.  C2-shaped reads (150 bp, 30x) with 1 % substitutions: after
+    `correct` a few hundred wrong bases are left, so the overlap stage runs the branching extractor forms on real leftovers,
+    not only on the small random sets of test_gpu_random.py."""
+    from oracle import pyoracle as po
+    from siga_amd import host
+    from tests.golden.make_reads import fast_reads, substitute
+    N, G, L = 60000, 300000, 150
+    clean, _ = fast_reads(G, L, N, 31)
+    reads = substitute(clean, 0.01, 131)
+    cwd = str(tmp_path)
+    with open(os.path.join(cwd, "reads.fa"), "wb") as f:
+        f.write(b"".join(b">r%d\n%s\n" % (i, bytes(r)) for i, r in enumerate(reads)))
+
+    def cli(*args):
+        r = subprocess.run([host.CLI_PATH] + list(args), cwd=cwd, capture_output=True, text=True)
+        assert r.returncode == 0, " ".join(args) + ": " + r.stderr[-2000:]
+
+    def same(a, b):
+        x, y = open(os.path.join(cwd, a), "rb").read(), open(os.path.join(cwd, b), "rb").read()
+        assert x == y, "%s differs from %s (%d vs %d bytes)" % (a, b, len(x), len(y))
+        return len(x)
+
+    def oracle_index(fa, prefix):
+        seqs = [s for _, _, s in __import__("siga_amd").overlap.read_sequences(os.path.join(cwd, fa))]
+        fwd, rev = po.Index.build(seqs), po.Index.build(seqs, reverse=True)
+        fwd.save(os.path.join(cwd, prefix + ".bwt"), os.path.join(cwd, prefix + ".sai"))
+        rev.save(os.path.join(cwd, prefix + ".rbwt"), os.path.join(cwd, prefix + ".rsai"))
+        return fwd, rev
+
+    # 1. index for the corrector (forward strand only), 2. correct
+    cli("index", "-t", "8", "--no-reverse", "reads.fa")
+    assert not os.path.exists(os.path.join(cwd, "reads.rbwt"))
+    cli("correct", "-k", "31", "-t", "8", "reads.fa")
+    st = po.correct(po.Index.load(os.path.join(cwd, "reads.bwt")), os.path.join(cwd, "reads.fa"), os.path.join(cwd, "o.ec.fa"), k=31)
+    same("reads.ec.fa", "o.ec.fa")
+    assert st["changed"] > N // 2 and st["written"] > N * 0.9
+    # 3. index of the corrected reads == the oracle's builder
+    cli("index", "-t", "8", "reads.ec.fa")
+    ofwd, orev = oracle_index("reads.ec.fa", "o.ec")
+    for ext in (".bwt", ".rbwt", ".sai", ".rsai"):
+        same("reads.ec" + ext, "o.ec" + ext)
+    # 4. rmdup
+    cli("rmdup", "-t", "8", "reads.ec.fa")
+    po.rmdup(ofwd, orev, os.path.join(cwd, "reads.ec.fa"), os.path.join(cwd, "o.rmdup.fa"), os.path.join(cwd, "o.rmdup.dups.fa"))
+    same("reads.ec.rmdup.fa", "o.rmdup.fa")
+    same("reads.ec.rmdup.dups.fa", "o.rmdup.dups.fa")
+    # 5. index + overlap of what is left
+    cli("index", "-t", "8", "reads.ec.rmdup.fa")
+    cli("overlap", "-m", "45", "-t", "8", "reads.ec.rmdup.fa")
+    fwd, rev = oracle_index("reads.ec.rmdup.fa", "o.fin")
+    for ext in (".bwt", ".rbwt", ".sai", ".rsai"):
+        same("reads.ec.rmdup" + ext, "o.fin" + ext)
+    po.build_asqg_mt(fwd, rev, os.path.join(cwd, "reads.ec.rmdup.fa"), 45, os.path.join(cwd, "o.asqg"))
+    got = gzip.open(os.path.join(cwd, "reads.ec.rmdup.asqg.gz"), "rb").read()
+    want = open(os.path.join(cwd, "o.asqg"), "rb").read()
+    assert got == want
+    assert want.count(b"\nED\t") > N // 2
+    # the leftovers made the extractor branch: the same reads through the library, counting
+    import siga_amd
+    pair = siga_amd.FMIndexPair.load(os.path.join(cwd, "reads.ec.rmdup"))
+    seqs = [s for _, _, s in siga_amd.overlap.read_sequences(os.path.join(cwd, "reads.ec.rmdup.fa"))]
+    res = siga_amd.OverlapBuilder(pair).overlap(seqs, 45)
+    assert res["stats"]["n_blocks"] > N
+    pair.close()
