@@ -102,10 +102,13 @@ int  sigax_stream_create(int device, void** stream);
 void sigax_stream_destroy(int device, void* stream);
 
 /* FMIndex::load x2 + SuffixArray::load x2 (src/overlap.cpp:41-42, src/overlap_builder.cpp:466).  The .sai
- * paths may be NULL when SIGAX_EDGES is never requested. */
+ * paths may be NULL when SIGAX_EDGES is never requested.  rbwt_path NULL or "": the forward strand alone -- what
+ * `siga index --no-reverse` writes and `siga correct` loads (src/correct.cpp:41-47) -- serving sigax_occ_batch (which = 0),
+ * sigax_kmer_count_batch and sigax_correct_*; overlap runs on such an index fail with SIGAX_E_STATE. */
 int  sigax_index_open(const char* bwt_path, const char* rbwt_path, const char* sai_path, const char* rsai_path,
                       int device, sigax_index** out);
-/* Same from memory: RL units exactly as in the .bwt payload (src/rlstring.h:10-63), read ids of the .sai lines. */
+/* Same from memory: RL units exactly as in the .bwt payload (src/rlstring.h:10-63), read ids of the .sai lines
+ * (rruns NULL with n_rruns 0: forward strand only). */
 int  sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const uint8_t* rruns, uint64_t n_rruns,
                           uint64_t n_symbols, uint64_t n_strings, const uint32_t* sai, const uint32_t* rsai,
                           int device, sigax_index** out);

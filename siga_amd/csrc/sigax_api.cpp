@@ -128,6 +128,16 @@ struct sigax_index {
   void* d_ptab;      // intervals of all 12-mers of the forward index: `siga correct`'s k-mer lookups start there (built by the
   bool ptab_tried;   // first correction call; SIGAX_KMER_PREFIX=0: never)
   hipEvent_t ptab_ev;  // recorded behind the table's build on the first call's stream
+  // `siga correct`'s k-mer table: the deep start table of the forward strand for K = the corrector's k (fm_layout.h) -- every
+  // distinct k-mer of the reads with its number of occurrences, so FMIndex::Interval::occurrences (src/fmindex.h:80-86) of a
+  // k-mer is ONE lookup, and a k-mer that is not in the table does not occur.  Built by the first correction call with that k
+  // (ensure_kmer_table), from a forward row table + text of its own when the index has none.
+  void* d_ktab;
+  u64 ktab_slots, ktab_bytes;
+  uint32_t ktab_k, ktab_tried_k;
+  uint32_t csa_bits, cld_bits, ct_bits, ctext_stride;
+  void *d_csa, *d_ctext;  // forward row table + stretch text built for it (fwd_only indexes, or before the extractor's exist)
+  uint32_t* d_cslen;
   uint32_t* d_sai[2];
   u64 n_sai;
   uint32_t* d_read_len;
@@ -149,6 +159,7 @@ struct sigax_index {
   // it reported (sigax_batch_finish).
   std::atomic<uint32_t>* cap_seen;
   bool split_strands;  // two-step tables too large to gather from both at once: one finder launch per strand
+  bool fwd_only;       // opened without the reverse strand (what `siga correct` needs: src/correct.cpp loads <prefix>.bwt alone)
 };
 
 // RL units (src/rlstring.h:10-63) -> 64-byte rank granules (fm_layout.h), decoded on the device (sigax_index_build.hip)
@@ -439,6 +450,10 @@ extern "C" void sigax_index_close(sigax_index* ix) {
   if (ix->d_name_rank) hipFree(ix->d_name_rank);
   if (ix->d_ptab) hipFree(ix->d_ptab);
   if (ix->ptab_ev) hipEventDestroy(ix->ptab_ev);
+  if (ix->d_ktab) hipFree(ix->d_ktab);
+  if (ix->d_csa) hipFree(ix->d_csa);
+  if (ix->d_ctext) hipFree(ix->d_ctext);
+  if (ix->d_cslen) hipFree(ix->d_cslen);
   if (ix->s_find) hipStreamDestroy(ix->s_find);
   if (ix->s_fx) hipStreamDestroy(ix->s_fx);
   if (ix->s_tail) hipStreamDestroy(ix->s_tail);
@@ -896,6 +911,11 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
                                     int device, sigax_index** out) {
   if (!out || (!runs && n_runs) || (!rruns && n_rruns)) return fail(SIGAX_E_ARG, "NULL argument");
   *out = nullptr;
+  // Forward strand only (rruns == NULL, n_rruns == 0): the index `siga index --no-reverse` writes and `siga correct` reads
+  // (src/correct.cpp:41-47 loads <prefix>.bwt alone; examples/siga-ecoli-miseq.sh:64-70).  Serves Occ, k-mer counts and the
+  // corrector; overlap runs need both strands and fail with SIGAX_E_STATE.
+  const bool fwd_only = rruns == nullptr && n_rruns == 0 && n_symbols > 0;
+  const int nst = fwd_only ? 1 : 2;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(SIGAX_E_DEVICE, "no HIP device visible: the overlap path has no CPU fallback");
@@ -917,6 +937,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
   }
   ix->n_symbols = n_symbols;
   ix->n_strings = n_strings;
+  ix->fwd_only = fwd_only;
   // 64-bit positions when the BWT does not fit 32 bits (SIGAX_FORCE_WIDE=1 exercises that path on small inputs)
   ix->wide = n_symbols >= 0xFFFFFFF0ull || getenv("SIGAX_FORCE_WIDE") != nullptr;
   const uint8_t* rr[2] = {runs, rruns};
@@ -928,7 +949,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
       DecodeSession() { sigax_build_session(1); }
       ~DecodeSession() { sigax_build_session(0); }
     } decode_session;
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < nst; ++s) {
       u64 C[5], total[5], gb = 0, sb = 0;
       int rc = sigax_decode_strand(rr[s], nr[s], n_symbols, ix->wide, &ix->d_gran[s], &gb, &ix->d_super[s], &sb, C, total);
       if (rc != SIGAX_OK) {
@@ -946,7 +967,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
     }
   }
   clk.lap("streams, upload + decode");
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < 5 && !fwd_only; ++k) {
     if (ix->st[0].total[k] != ix->st[1].total[k]) {
       sigax_index_close(ix);
       return fail(SIGAX_E_IO, "forward and reverse BWT hold different symbol counts: not a .bwt/.rbwt pair");
@@ -975,7 +996,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
       if (e == hipSuccess) e = hipMalloc(&partial, scan_partials_needed(ng2) * 8);
       if (e == hipSuccess) e = hipMalloc(&total, 8);
       const u64 nsup2 = ((ng2 - 1) >> (SIGAX_SUPER_SHIFT - 6)) + 1;
-      for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+      for (int s = 0; s < nst && e == hipSuccess; ++s) {
         e = hipMalloc(&ix->d_gran2[s], ng2 * SIGAX_GRAN2_WORDS * 4);
         if (e != hipSuccess) break;
         ix->device_bytes += ng2 * SIGAX_GRAN2_WORDS * 4;
@@ -1019,7 +1040,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
   {
     const char* envs = getenv("SIGAX_FIND_START");
     const bool want = envs ? envs[0] != '0' : n_symbols >= (1ull << 22);
-    if (want && n_symbols > 0) {
+    if (want && n_symbols > 0 && !fwd_only) {
       hipError_t e = hipSuccess;
       for (int s = 0; s < 2 && e == hipSuccess; ++s) {
         e = hipMalloc(&ix->d_start[s], start_table_bytes(ix->wide));
@@ -1041,7 +1062,7 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
     }
   }
   clk.lap("start tables");
-  if (sai && rsai) {
+  if (sai && rsai && !fwd_only) {
     const uint32_t* ss[2] = {sai, rsai};
     for (int s = 0; s < 2; ++s)  // k_edges indexes the read tables with these ids
       for (u64 i = 0; i < n_strings; ++i)
@@ -1060,7 +1081,12 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
     ix->n_sai = n_strings;
   }
   clk.lap(".sai check + upload");
-  build_rowend(ix);  // after the .sai tables: with them the extractor's tables are direct maps (fm_layout.h)
+  if (fwd_only) {
+    ix->tab_state = new std::atomic<int>(0);  // no extractor, no row tables
+    ix->deep_state = new std::atomic<int>(0);
+  } else {
+    build_rowend(ix);  // after the .sai tables: with them the extractor's tables are direct maps (fm_layout.h)
+  }
   clk.lap("row tables (plan, start of build)");
   *out = ix;
   return SIGAX_OK;
@@ -1068,7 +1094,16 @@ extern "C" int sigax_index_open_mem(const uint8_t* runs, uint64_t n_runs, const 
 
 extern "C" int sigax_index_open(const char* bwt_path, const char* rbwt_path, const char* sai_path, const char* rsai_path,
                                 int device, sigax_index** out) {
-  if (!bwt_path || !rbwt_path || !out) return fail(SIGAX_E_ARG, "NULL argument");
+  if (!bwt_path || !out) return fail(SIGAX_E_ARG, "NULL argument");
+  if (!rbwt_path || !rbwt_path[0]) {  // forward strand only (sigax_index_open_mem says what that serves)
+    std::vector<uint8_t> fb;
+    int rc = read_file(bwt_path, &fb);
+    if (rc != SIGAX_OK) return rc;
+    u64 ns = 0, nsym = 0, nruns = 0;
+    const uint8_t* runs = nullptr;
+    if ((rc = parse_bwt(fb, bwt_path, &ns, &nsym, &runs, &nruns)) != SIGAX_OK) return rc;
+    return sigax_index_open_mem(runs, nruns, nullptr, 0, nsym, ns, nullptr, nullptr, device, out);
+  }
   std::vector<uint8_t> fb, rb;
   std::vector<uint32_t> sai, rsai;
   const bool have_sai = sai_path && rsai_path && sai_path[0] && rsai_path[0];
@@ -1190,6 +1225,7 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
   ix->n_meta = src->n_meta;
   ix->max_read_len = src->max_read_len;
   ix->split_strands = src->split_strands;
+  ix->fwd_only = src->fwd_only;
   const u64 ngran = src->n_symbols / SIGAX_GRANULE_SYMS + 1;
   const u64 nsuper = ((ngran - 1) >> (SIGAX_SUPER_SHIFT - 7)) + 1;
   const u64 ng2 = src->n_symbols / SIGAX_GRAN2_SYMS + 1;
@@ -1228,7 +1264,12 @@ extern "C" int sigax_index_clone(const sigax_index* src, int device, sigax_index
     sigax_index_close(ix);
     return rc;
   }
-  build_rowend(ix);  // plans its own row tables; built on this device once it is reused (or prepared)
+  if (ix->fwd_only) {
+    ix->tab_state = new std::atomic<int>(0);
+    ix->deep_state = new std::atomic<int>(0);
+  } else {
+    build_rowend(ix);  // plans its own row tables; built on this device once it is reused (or prepared)
+  }
   *out = ix;
   return SIGAX_OK;
 }
@@ -1324,6 +1365,7 @@ extern "C" int sigax_index_check_order(sigax_index* ix, int which, uint64_t* n_b
 
 extern "C" int sigax_occ_batch(sigax_index* ix, int which, const uint64_t* positions, uint64_t n, uint64_t* counts5) {
   if (!ix || (n && (!positions || !counts5)) || which < 0 || which > 1) return fail(SIGAX_E_ARG, "bad argument");
+  if (which == 1 && ix->fwd_only) return fail(SIGAX_E_STATE, "the index was opened without its reverse strand");
   HIP_TRY(hipSetDevice(ix->device));
   if (n == 0) return SIGAX_OK;
   u64 *d_pos = nullptr, *d_out = nullptr;
@@ -1389,6 +1431,130 @@ static void ensure_prefix_table(sigax_index* ix, hipStream_t st) {
   ix->device_bytes += prefix_table_bytes(ix->wide, pk);
 }
 
+// The corrector's k-mer table (see sigax_index): (re)built when a correction call comes with another k.  Synchronous (the
+// build takes 0.1 s at BASELINE configs[3]; it happens once per index and k); an accelerator: whatever fails leaves the
+// prefix-table + walk path in charge.  SIGAX_KMER_TABLE=0 turns it off.
+static void ensure_kmer_table(sigax_index* ix, uint32_t k) {
+  std::lock_guard<std::mutex> lock(*ix->enqueue_mu);
+  if (ix->ktab_k == k || ix->ktab_tried_k == k) return;
+  ix->ktab_tried_k = k;
+  static const char* env = getenv("SIGAX_KMER_TABLE");
+  if ((env && env[0] == '0') || k < 8 || k > SIGAX_DEEP_KMAX || ix->n_symbols == 0 || ix->st[0].C[1] >= 0xFFFFFFFFull) return;
+  const bool verbose = getenv("SIGAX_VERBOSE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (ix->d_ktab) {  // a table for another k: no correction call is running on it (the caller serialises calls that change k)
+    (void)hipDeviceSynchronize();
+    hipFree(ix->d_ktab);
+    ix->d_ktab = nullptr;
+    ix->device_bytes -= ix->ktab_bytes;
+    ix->ktab_k = 0;
+    ix->ktab_bytes = 0;
+  }
+  const u64 n_stretch = ix->st[0].C[1];
+  FmStrand f = ix->st[0];
+  hipStream_t sb = nullptr;
+  if (hipStreamCreateWithFlags(&sb, hipStreamNonBlocking) != hipSuccess) return;
+  bool ok = true;
+  const uint32_t* slen = ix->d_slen[0];
+  if (!(f.sa && f.text && slen)) {
+    // forward row table (bare entries) + text + stretch lengths of our own
+    if (!ix->d_csa) {
+      void* info = nullptr;
+      u32* d_max = nullptr;
+      uint32_t maxlen = 0;
+      ok = hipMalloc(&info, std::max<u64>(n_stretch, 1) * 8) == hipSuccess && hipMalloc((void**)&d_max, 8) == hipSuccess &&
+           hipMemsetAsync(d_max, 0, 8, sb) == hipSuccess;
+      if (ok) {
+        launch_stretch_scan(ix->st[0], ix->wide, n_stretch, (u64*)info, d_max, sb);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&maxlen, d_max, 4, hipMemcpyDeviceToHost, sb) == hipSuccess &&
+             hipStreamSynchronize(sb) == hipSuccess;
+      }
+      RowTabGeom g = row_tab_geom(ix, maxlen, 0);
+      ok = ok && g.sa_bits <= 57;
+      size_t mfree = 0, mtotal = 0;
+      (void)hipMemGetInfo(&mfree, &mtotal);
+      ok = ok && g.sa_bytes + g.text_bytes + n_stretch * 4 < (u64)mfree / 2;
+      ok = ok && hipMalloc(&ix->d_csa, g.sa_bytes) == hipSuccess && hipMalloc(&ix->d_ctext, g.text_bytes) == hipSuccess &&
+           hipMalloc((void**)&ix->d_cslen, std::max<u64>(n_stretch, 1) * 4) == hipSuccess &&
+           hipMemsetAsync(ix->d_csa, 0, g.sa_bytes, sb) == hipSuccess && hipMemsetAsync(ix->d_ctext, 0, g.text_bytes, sb) == hipSuccess;
+      if (ok) {
+        launch_rows_fill(ix->st[0], ix->wide, n_stretch, (const u64*)info, (unsigned char*)ix->d_csa, g.sa_bits, g.ld_bits, g.t_bits,
+                         (unsigned char*)ix->d_ctext, g.text_stride, ix->d_cslen, sb);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(sb) == hipSuccess;
+      }
+      if (info) hipFree(info);
+      if (d_max) hipFree(d_max);
+      if (ok) {
+        ix->csa_bits = g.sa_bits;
+        ix->cld_bits = g.ld_bits;
+        ix->ct_bits = g.t_bits;
+        ix->ctext_stride = g.text_stride;
+        ix->device_bytes += g.sa_bytes + g.text_bytes + n_stretch * 4;
+      } else {
+        (void)hipGetLastError();
+        if (ix->d_csa) hipFree(ix->d_csa);
+        if (ix->d_ctext) hipFree(ix->d_ctext);
+        if (ix->d_cslen) hipFree(ix->d_cslen);
+        ix->d_csa = ix->d_ctext = nullptr;
+        ix->d_cslen = nullptr;
+      }
+    }
+    if (ok && ix->d_csa) {
+      f.sa = (const unsigned char*)ix->d_csa;
+      f.text = (const unsigned char*)ix->d_ctext;
+      f.xmap = nullptr;
+      f.sa_bits = ix->csa_bits;
+      f.ld_bits = ix->cld_bits;
+      f.t_bits = ix->ct_bits;
+      f.text_stride = ix->ctext_stride;
+      slen = ix->d_cslen;
+    } else {
+      ok = false;
+    }
+  }
+  u64* d_cnt = nullptr;
+  u64* list = nullptr;
+  void* tab = nullptr;
+  u64 h[2] = {0, 0}, distinct = 0, slots = 0;
+  ok = ok && hipMalloc((void**)&d_cnt, 16) == hipSuccess && hipMemsetAsync(d_cnt, 0, 16, sb) == hipSuccess;
+  if (ok) {
+    launch_deep_scan(f, slen, n_stretch, k, d_cnt, nullptr, 0, sb);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, sb) == hipSuccess && hipStreamSynchronize(sb) == hipSuccess;
+    distinct = h[0];
+  }
+  if (ok) {
+    size_t mfree = 0, mtotal = 0;
+    (void)hipMemGetInfo(&mfree, &mtotal);
+    slots = std::max<u64>(64, distinct * 2 + 16);
+    ok = distinct < (1ull << 32) - 256 && slots * deep_entry_bytes() + distinct * 8 < (u64)mfree / 100 * 45;
+  }
+  ok = ok && hipMalloc((void**)&list, std::max<u64>(distinct, 1) * 8) == hipSuccess && hipMalloc(&tab, slots * deep_entry_bytes()) == hipSuccess &&
+       hipMemsetAsync(tab, 0, slots * deep_entry_bytes(), sb) == hipSuccess && hipMemsetAsync(d_cnt, 0, 16, sb) == hipSuccess;
+  if (ok) {
+    launch_deep_scan(f, slen, n_stretch, k, d_cnt, list, distinct, sb);
+    launch_deep_fill(f, f, ix->wide, slen, n_stretch, k, list, distinct, tab, slots, d_cnt + 1, sb);
+    ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, sb) == hipSuccess && hipStreamSynchronize(sb) == hipSuccess &&
+         h[0] == distinct && h[1] == 0;
+  }
+  if (list) hipFree(list);
+  if (d_cnt) hipFree(d_cnt);
+  (void)hipStreamDestroy(sb);
+  if (!ok) {
+    (void)hipGetLastError();
+    if (tab) hipFree(tab);
+    if (verbose) fprintf(stderr, "[sigax] k-mer table for k = %u not built: the corrector walks\n", k);
+    return;
+  }
+  ix->d_ktab = tab;
+  ix->ktab_slots = slots;
+  ix->ktab_k = k;
+  ix->ktab_bytes = slots * deep_entry_bytes();
+  ix->device_bytes += ix->ktab_bytes;
+  if (verbose)
+    fprintf(stderr, "[sigax] k-mer table: k = %u, %llu distinct k-mers, %.2f GB, %.3f s\n", k, distinct, ix->ktab_bytes / 1e9,
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+}
+
 static CorrectArgs correct_args(sigax_index* ix, const unsigned char* d_seqs, const unsigned char* d_quals, const u64* d_offs, u64 n_reads,
                                 uint32_t kmer_size, int32_t kmer_threshold, uint32_t kmer_rounds, uint32_t count_offset,
                                 unsigned char* d_out, unsigned char* d_valid, u64* d_stat, hipStream_t st) {
@@ -1407,6 +1573,9 @@ static CorrectArgs correct_args(sigax_index* ix, const unsigned char* d_seqs, co
   ca.out = d_out;
   ca.valid = d_valid;
   ca.dstat = d_stat;
+  ensure_kmer_table(ix, kmer_size);
+  ca.ktab = ix->ktab_k == kmer_size ? ix->d_ktab : nullptr;
+  ca.ktab_slots = ix->ktab_slots;
   ensure_prefix_table(ix, st);
   ca.ptab = ix->d_ptab;
   ca.pk = ix->ptab_k;
@@ -1675,6 +1844,7 @@ extern "C" int sigax_batch_set_device_reads(sigax_batch* b, const void* d_seqs, 
 
 static int enqueue(sigax_batch* b, hipStream_t st) {
   sigax_index* ix = b->ix;
+  if (ix->fwd_only) return fail(SIGAX_E_STATE, "the index was opened without its reverse strand: overlap runs need <prefix>.rbwt too");
   std::lock_guard<std::mutex> lock(*ix->enqueue_mu);  // one batch's launch sequence at a time on the shared streams
   publish_tables(ix);
   publish_deep(ix);

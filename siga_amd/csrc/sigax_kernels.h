@@ -155,6 +155,8 @@ struct CorrectArgs {
   unsigned char* out;    // corrected sequences, same layout as seqs
   unsigned char* valid;  // CorrectResult::validQC; 2 = read longer than the kernel supports
   unsigned long long* dstat;  // [0] reads too long, [1] rank-table sectors asked for, [2] k-mer lookups (4 x u64)
+  const void* ktab;           // hash of the reads' distinct k-mers with their counts (fm_layout.h: deep start table, K = k), or NULL
+  unsigned long long ktab_slots;
   const void* ptab;           // intervals of all pk-mers (launch_prefix_build), or NULL
   uint32_t pk;
   uint32_t max_len;           // upper bound of the batch's read lengths, 0 = unknown (launch_correct picks the kernel form)

@@ -2269,6 +2269,7 @@ struct GFx {
   // are used up, and from the row table its stretch = Occ('$') at the path's end and the rounds until then
   u64 tw;
   u32 tk, tld, ttt;
+  u32 ccor;  // OR of the item's four chain_cnt words (body())
 #ifdef SIGAX_FX_PROFILE
   u32 dbg_round;
 #endif
@@ -2830,6 +2831,34 @@ struct GFx {
     // stride-2 ring walk of :728-802 visits it over and over, so this is a plain loop with the group in registers.
     {
       u64 alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+      if (TEXT) {
+        // All the rounds up to the one that ends the top-level block, AT ONCE: the top-level block (the first lane) ends after
+        // R = its remaining symbols; until then a round only asks whether every block's next symbol (complemented for
+        // QUERYCOMP blocks: rank - 1 -> 3 - (rank - 1), the bitwise NOT of its two bits) is the same non-'$' one -- i.e.
+        // whether the next R symbols of every lane's window equal the first lane's.  One XOR and a shift instead of R rounds of
+        // shuffles and ballots (BASELINE configs[1]: R is 5 on average; the rounds were a quarter of this kernel's
+        // instructions).  Counted as the R rounds it replaces.  Anything else -- a lane whose read ends first, a disagreement
+        // (a branch), top-level blocks ending at different rounds, a window that runs out first -- is left to the rounds below.
+        const bool mine = (alive >> gl) & 1ull;
+        const u32 first = ffs0(alive);
+        const u32 R = gshfl(ttt, first);
+        if (R > 0u && R <= (u32)SIGAX_TEXT_WINDOW) {
+          const bool qc = (af_of(e.src) & 4u) != 0;
+          const u64 X = qc ? ~tw : tw;
+          const u64 Xf = gshfl(X, first);
+          const u32 topLen = gshfl(e.len, first);
+          const bool isTop = mine && e.len == topLen;
+          const bool okl = !mine || (ttt >= R && (u32)SIGAX_TEXT_WINDOW - tk >= R && ((X ^ Xf) >> (64u - 2u * R)) == 0ull && (!isTop || ttt == R));
+          if (gballot(!okl) == 0) {
+            if (mine) {
+              tw <<= 2u * R;
+              tk += R;
+              ttt -= R;
+            }
+            nocc += 2u * pop(alive) * R;
+          }
+        }
+      }
       u32 guard = 0;
       while (alive) {
         u64 na = 0;
@@ -2936,6 +2965,7 @@ struct GFx {
     {
       uint4 c4 = reinterpret_cast<const uint4*>(A.chain_cnt)[r];
       cc[0] = c4.x; cc[1] = c4.y; cc[2] = c4.z; cc[3] = c4.w;
+      ccor = c4.x | c4.y | c4.z | c4.w;  // account() reads the finds' substring flags off it
     }
     if (sd == 0) {  // containfwd, containrev first (:1161-1162)
       u32 ccl = gl == 0 ? cc[0] : gl == 1 ? cc[1] : gl == 2 ? cc[2] : cc[3];
@@ -3275,8 +3305,7 @@ struct GFx {
     nocc_total += nocc;
     if (xerror) { word |= OCC_SIDE_ERR; ++nerr; }
     if (sd == 0) {
-      uint4 c4 = reinterpret_cast<const uint4*>(A.chain_cnt)[r];
-      u32 sub = (c4.x | c4.y | c4.z | c4.w) & SIGAX_CC_SUBSTRING;
+      u32 sub = ccor & SIGAX_CC_SUBSTRING;
       A.substring[r] = sub ? 1 : 0;
       if (sub) { word |= OCC_SIDE_SUB; ++nsub; }
     }
@@ -3484,8 +3513,30 @@ __global__ __launch_bounds__(256) void k_prefix_build(FmStrand s, void* tab, u32
 template <bool WIDE>
 __device__ __forceinline__ u32 kmer_occ(const FmRef& f, const FmTables& tb, const Find2TablesT<WIDE>* t2, const uint32_t* gran2,
                                         const u64* super2, const void* ptab, u32 pk, const unsigned char* seq, u32 s, u32 k, u32 ovpos,
-                                        u32 ovrank, u32& nsec) {
+                                        u32 ovrank, u32& nsec, const void* ktab = nullptr, u64 ktab_slots = 0) {
   typedef typename PosOf<WIDE>::type P;
+  if (ktab != nullptr) {
+    // the table holds every distinct k-mer of the indexed reads with its number of occurrences (fm_layout.h: the deep start
+    // table with K = k): one lookup, and a k-mer that is not there does not occur.  Key = the k-mer in the order the
+    // backward search consumes it (last base first).  k-mers with a non-ACGT base walk as before.
+    u64 k0 = 0, k1 = 0;
+    bool acgt = true;
+    for (u32 i = 0; i < k; ++i) {
+      const u32 p = s + k - 1u - i;
+      const u32 r = p == ovpos ? ovrank : base_rank(seq[p]);
+      acgt = acgt && r != 0u;
+      const u64 c = (u64)((r - 1u) & 3u);
+      if (i < 32u) k0 |= c << (2u * i);
+      else k1 |= c << (2u * (i - 32u));
+    }
+    if (acgt) {
+      k1 |= (u64)(0x8000u | k) << 48;
+      P a0 = 0, a1 = 0, az = 0;
+      nsec += 1u;
+      if (!deep_lookup<WIDE>(ktab, ktab_slots, k0, k1, a0, a1, az)) return 0u;
+      return (u64)az > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)az;
+    }
+  }
   u32 j = k;
   P lo, hi;
   bool started = false;
@@ -3631,7 +3682,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMAX <= 512
           bool good = false;
           if (s < nw) {
             if (sh.redo[s]) {
-              sh.cnt[s] = kmer_occ<WIDE>(F, tb, t2, A.fwd.gran2, A.fwd.super2, A.ptab, A.pk, sh.seq, s, k, 0xFFFFFFFFu, 0u, nsec);
+              sh.cnt[s] = kmer_occ<WIDE>(F, tb, t2, A.fwd.gran2, A.fwd.super2, A.ptab, A.pk, sh.seq, s, k, 0xFFFFFFFFu, 0u, nsec, A.ktab, A.ktab_slots);
               ++nlook;
               sh.redo[s] = 0;
             }
@@ -3683,7 +3734,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMAX <= 512
                 const u32 kidx = side ? (pos < n - k ? pos : n - k) : (pos + 1 >= k ? pos + 1 - k : 0u);
                 const u32 thr = sh.score[pos] >= A.cutoff ? A.high : A.low;
                 const u32 minCount = A.offset > thr ? A.offset : thr;  // max(countVector[..] (always 0) + offset, threshold)
-                cand = kmer_occ<WIDE>(F, tb, t2, A.fwd.gran2, A.fwd.super2, A.ptab, A.pk, sh.seq, kidx, k, pos, brank, nsec) >= minCount;
+                cand = kmer_occ<WIDE>(F, tb, t2, A.fwd.gran2, A.fwd.super2, A.ptab, A.pk, sh.seq, kidx, k, pos, brank, nsec, A.ktab, A.ktab_slots) >= minCount;
                 ++nlook;
               }
             }

@@ -993,6 +993,14 @@ bool FMIndex::load(const std::string& prefix, FMIndex& fmi, int device) {
                             (prefix + ".rsai").c_str(), device, &fmi._h);
   return rc == SIGAX_OK;
 }
+// the forward index alone: FMIndex::load(prefix + ".bwt") of src/correct.cpp:41-47 (`siga index --no-reverse` writes no more)
+bool FMIndex::loadForward(const std::string& prefix, FMIndex& fmi, int device) {
+  if (fmi._h) {
+    sigax_index_close(fmi._h);
+    fmi._h = nullptr;
+  }
+  return sigax_index_open((prefix + ".bwt").c_str(), nullptr, nullptr, nullptr, device, &fmi._h) == SIGAX_OK;
+}
 
 uint64_t FMIndex::length() const {
   sigax_index_info inf;
@@ -2019,7 +2027,7 @@ int sigah_index_file(const char* reads_path, const char* prefix, int threads, ch
 int sigah_overlap_file_gpus(const char* reads_path, const char* prefix, uint64_t min_overlap, const char* output, int irreducible,
                             int rc, uint64_t threads, uint64_t batch, int device, int gpus, char* err, uint64_t errcap) {
   sigah::FMIndex fmi;
-  if (!sigah::FMIndex::load(prefix, fmi, device)) {
+  if (!sigah::FMIndex::loadForward(prefix, fmi, device)) {
     if (err && errcap) snprintf(err, errcap, "Failed to load FMIndex from %s: %s", prefix, sigax_last_error());
     return -1;
   }
@@ -2036,7 +2044,7 @@ int sigah_overlap_file_gpus(const char* reads_path, const char* prefix, uint64_t
 int sigah_overlap_file(const char* reads_path, const char* prefix, uint64_t min_overlap, const char* output, int irreducible,
                        int rc, uint64_t threads, uint64_t batch, int device, char* err, uint64_t errcap) {
   sigah::FMIndex fmi;
-  if (!sigah::FMIndex::load(prefix, fmi, device)) {
+  if (!sigah::FMIndex::loadForward(prefix, fmi, device)) {
     if (err && errcap) snprintf(err, errcap, "Failed to load FMIndex from %s: %s", prefix, sigax_last_error());
     return -1;
   }
@@ -2052,7 +2060,7 @@ int sigah_overlap_file(const char* reads_path, const char* prefix, uint64_t min_
 int sigah_rmdup_file(const char* reads_path, const char* prefix, const char* output, const char* duplicates, int device,
                      char* err, uint64_t errcap) {
   sigah::FMIndex fmi;
-  if (!sigah::FMIndex::load(prefix, fmi, device)) {
+  if (!sigah::FMIndex::loadForward(prefix, fmi, device)) {
     if (err && errcap) snprintf(err, errcap, "Failed to load FMIndex from %s: %s", prefix, sigax_last_error());
     return -1;
   }
@@ -2068,7 +2076,7 @@ int sigah_rmdup_file(const char* reads_path, const char* prefix, const char* out
 int sigah_correct_file(const char* reads_path, const char* prefix, const char* output, uint64_t k, uint64_t threshold,
                        uint64_t rounds, uint64_t offset, int device, char* err, uint64_t errcap) {
   sigah::FMIndex fmi;
-  if (!sigah::FMIndex::load(prefix, fmi, device)) {
+  if (!sigah::FMIndex::loadForward(prefix, fmi, device)) {
     if (err && errcap) snprintf(err, errcap, "Failed to load FMIndex from %s: %s", prefix, sigax_last_error());
     return -1;
   }

@@ -73,6 +73,7 @@ class FMIndex {
   FMIndex() : _h(nullptr) {}
   ~FMIndex();
   static bool load(const std::string& prefix, FMIndex& fmi, int device = 0);
+  static bool loadForward(const std::string& prefix, FMIndex& fmi, int device = 0);  // <prefix>.bwt alone (`siga correct`)
   sigax_index* handle() const { return _h; }
   uint64_t length() const;
 

@@ -357,7 +357,7 @@ static int run_correct(int argc, char** argv) {
     return -1;
   }
   sigah::FMIndex fmi;
-  if (!sigah::FMIndex::load(prefix, fmi, device)) {
+  if (!sigah::FMIndex::loadForward(prefix, fmi, device)) {
     fprintf(stderr, "Failed to load FMIndex from %s: %s\n", prefix.c_str(), sigax_last_error());
     return -1;
   }

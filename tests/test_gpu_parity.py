@@ -1,5 +1,7 @@
 """GPU parity tests proper: the HIP path (through the C-ABI, include/sigax.h) against the oracle on the same inputs.
 Bit-exact: Occ values, per-read block lists IN ORDER (hits text), substring flags, ASQG text."""
+import os
+
 import numpy as np
 import pytest
 
@@ -441,3 +443,44 @@ def test_deep_start_table_comes_with_reuse(sa):
             break
         time.sleep(0.1)
     assert seen == 45
+
+
+def test_forward_only_index_serves_the_corrector_and_refuses_overlaps(sa, tmp_path):
+    """`siga index --no-reverse` writes <prefix>.bwt/.sai alone and `siga correct` loads just that (src/correct.cpp:41-47,
+    examples/siga-ecoli-miseq.sh:64-70): sigax_index_open with rbwt_path = NULL.  Occ, k-mer counts and corrections equal the
+    two-strand index's; an overlap run and Occ on the missing strand come back as SIGAX_E_STATE, not as a crash."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    from siga_amd import _lib, host
+    fx = fixture("toy")
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.sigax_index_open((fx.prefix + ".bwt").encode(), None, None, None, 0, C.byref(h)) == 0, _lib.last_error()
+    fwd = sa.FMIndexPair(h.value)
+    both = _pair(sa, fx)
+    pos = np.arange(0, len(fx.fwd), 53, dtype=np.uint64)
+    assert np.array_equal(fwd.occ(pos, 0), both.occ(pos, 0))
+    kmers = [s[i:i + 25] for s in fx.seqs[:200] for i in (0, 17, 60)]
+    assert np.array_equal(fwd.kmer_counts(kmers), both.kmer_counts(kmers))
+    out = np.zeros((3, 5), dtype=np.uint64)
+    p3 = np.arange(3, dtype=np.uint64)
+    assert L.sigax_occ_batch(fwd.handle, 1, p3.ctypes.data, 3, out.ctypes.data) == -6
+    with pytest.raises(sa.overlap.SigaxError) as e:
+        sa.OverlapBuilder(fwd).overlap(fx.seqs[:10], 45)
+    assert e.value.code == -6 and "reverse strand" in str(e.value)
+    # the CLI on a forward-only index in the CWD
+    import shutil
+    import subprocess
+    cwd = str(tmp_path)
+    with open(cwd + "/reads.fa", "w") as f:
+        for n, s in _noisy(fx.reads, 0.2, 3):
+            f.write(">%s\n%s\n" % (n, s))
+    assert subprocess.run([host.CLI_PATH, "index", "--no-reverse", "reads.fa"], cwd=cwd).returncode == 0
+    assert not os.path.exists(cwd + "/reads.rbwt")
+    assert subprocess.run([host.CLI_PATH, "correct", "-k", "41", "reads.fa"], cwd=cwd).returncode == 0
+    po.correct(po.Index.load(cwd + "/reads.bwt"), cwd + "/reads.fa", cwd + "/o.ec", k=41)
+    assert open(cwd + "/reads.ec.fa").read() == open(cwd + "/o.ec").read()
+    r = subprocess.run([host.CLI_PATH, "overlap", "-m", "45", "reads.fa"], cwd=cwd, capture_output=True, text=True)
+    assert r.returncode != 0 and "rbwt" in r.stderr
+    fwd.close()
+    both.close()

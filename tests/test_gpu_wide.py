@@ -110,8 +110,12 @@ def test_sixteen_lane_groups_bit_exact():
 def test_correct_without_the_kmer_prefix_table():
     """`siga correct`'s k-mer lookups start from the interval of their last twelve bases (a table of all 12-mers, built on
     first use); SIGAX_KMER_PREFIX=0 walks every step as the reference does.  Same files either way, 32- and 64-bit positions."""
-    _run_parity({"SIGAX_KMER_PREFIX": "0"}, "correct")
+    _run_parity({"SIGAX_KMER_PREFIX": "0", "SIGAX_KMER_TABLE": "0"}, "correct")
     _run_parity({"SIGAX_FORCE_WIDE": "1"}, "correct")
+    # ... and without the table of the reads' distinct k-mers (one lookup per k-mer: what every other correction test runs),
+    # the prefix table + walk of round 3
+    _run_parity({"SIGAX_KMER_TABLE": "0"}, "correct")
+    _run_parity({"SIGAX_KMER_TABLE": "0", "SIGAX_FORCE_WIDE": "1"}, "correct_matches")
 
 
 def test_locality_order_of_the_batch_bit_exact():

@@ -2,7 +2,8 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/sq; mkdir -p $O
-P="python3 bench.py --cpu-sample 0 --steps 3 --warmup 1"
+P="python3 bench.py --cpu-sample 0 --no-e2e --upload-steps 0 --steps 3 --warmup 1 ${SQ_ARGS:-}"
+export SIGAX_TABLES_SYNC=1
 SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc $SQ -d $O/sq --output-format csv -- $P > $O/sq.json 2> $O/sq.err; echo "sq rc=$?"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc $SQ -d $O/sq1 --output-format csv -- $P --subbatches 1 --depth 1 > $O/sq1.json 2> $O/sq1.err; echo "sq1 rc=$?"
