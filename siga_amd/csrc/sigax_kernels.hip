@@ -2884,6 +2884,60 @@ struct GFx {
       ni = 0;
       u32 p = 0;
       while (p != ng) {
+        if (TEXT && p == 0u && ni == 0u && ng >= 3u) {
+          // Many turns of the ring AT ONCE.  While nothing is erased and nothing branches, the stride-2 walk visits the groups at
+          // the EVEN places of the list, in order, again and again (with an even number of groups a pass ends at the list's end
+          // and the next starts at place 0; with an odd number it wraps to place 0 inside the pass), and the groups at the odd
+          // places are not touched at all.  A visit to a countdown group with t rounds to go takes one off; a visit to a group
+          // of blocks whose next symbols agree is a plain round.  So until the first group at an even place has something to
+          // decide -- a countdown at 0, a top-level block at its read's end, a block whose next symbol differs from its
+          // group's first, a text window used up -- every turn is the same, and d turns cost what one costs: d = the smallest
+          // number of such uneventful visits any even-place group has left.  Reads with sequencing errors spend their time
+          // here (a substitution in an overlapping read leaves a countdown group of ~100 rounds behind: at 1 % substitutions
+          // the ring took 27 of filter/extract's 31 ms per million reads).  Counted as the visits it replaces.
+          bool ing = false, even = false, hole = false;
+          u32 myfirst = 0;
+          for (u32 q = 0; q < ng; ++q) {
+            const u32 sl = gshfl(gD, q);
+            const u64 al = gshfl(gAlive, sl);
+            if (al == 0ull && (q & 1u) == 0u) hole = true;  // an empty group is erased when it is visited: an event
+            if ((al >> gl) & 1ull) {
+              ing = true;
+              even = (q & 1u) == 0u;
+              myfirst = ffs0(al);
+            }
+          }
+          const bool cd = (e.len & FX_COUNTDOWN) != 0u;
+          const u64 X = (af_of(e.src) & 4u) ? ~tw : tw;
+          const u64 Xf = gshfl(X, myfirst);
+          const u32 tf = gshfl(ttt, myfirst);
+          u32 d = 0xFFFFFFFFu;
+          if (ing && even) {
+            if (cd) {
+              d = (u32)e.c1hi;
+            } else {
+              const u64 x = X ^ Xf;
+              const u32 a = x ? (u32)__clzll((long long)x) >> 1 : 32u;
+              const u32 avail = (u32)SIGAX_TEXT_WINDOW - (tk < (u32)SIGAX_TEXT_WINDOW ? tk : (u32)SIGAX_TEXT_WINDOW);
+              d = min(min(a, ttt), min(avail, tf));
+            }
+          }
+#pragma unroll
+          for (u32 off = (u32)W / 2u; off > 0u; off >>= 1) d = min(d, gshfl(d, gl ^ off));
+          if (!hole && d != 0xFFFFFFFFu && d >= 1u) {
+            const bool adv = ing && even;
+            if (adv) {
+              if (cd) {
+                e.c1hi -= (P)d;
+              } else {
+                tw <<= 2u * d;
+                tk += d;
+                ttt -= d;
+              }
+            }
+            nocc += 2u * d * pop(gballot(adv));
+          }
+        }
         const u32 slot = gshfl(gD, p);
         const u64 alive = gshfl(gAlive, slot);
         if (slot != cur && !inreg) {

@@ -2027,7 +2027,7 @@ int sigah_index_file(const char* reads_path, const char* prefix, int threads, ch
 int sigah_overlap_file_gpus(const char* reads_path, const char* prefix, uint64_t min_overlap, const char* output, int irreducible,
                             int rc, uint64_t threads, uint64_t batch, int device, int gpus, char* err, uint64_t errcap) {
   sigah::FMIndex fmi;
-  if (!sigah::FMIndex::loadForward(prefix, fmi, device)) {
+  if (!sigah::FMIndex::load(prefix, fmi, device)) {
     if (err && errcap) snprintf(err, errcap, "Failed to load FMIndex from %s: %s", prefix, sigax_last_error());
     return -1;
   }
@@ -2044,7 +2044,7 @@ int sigah_overlap_file_gpus(const char* reads_path, const char* prefix, uint64_t
 int sigah_overlap_file(const char* reads_path, const char* prefix, uint64_t min_overlap, const char* output, int irreducible,
                        int rc, uint64_t threads, uint64_t batch, int device, char* err, uint64_t errcap) {
   sigah::FMIndex fmi;
-  if (!sigah::FMIndex::loadForward(prefix, fmi, device)) {
+  if (!sigah::FMIndex::load(prefix, fmi, device)) {
     if (err && errcap) snprintf(err, errcap, "Failed to load FMIndex from %s: %s", prefix, sigax_last_error());
     return -1;
   }
@@ -2060,7 +2060,7 @@ int sigah_overlap_file(const char* reads_path, const char* prefix, uint64_t min_
 int sigah_rmdup_file(const char* reads_path, const char* prefix, const char* output, const char* duplicates, int device,
                      char* err, uint64_t errcap) {
   sigah::FMIndex fmi;
-  if (!sigah::FMIndex::loadForward(prefix, fmi, device)) {
+  if (!sigah::FMIndex::load(prefix, fmi, device)) {
     if (err && errcap) snprintf(err, errcap, "Failed to load FMIndex from %s: %s", prefix, sigax_last_error());
     return -1;
   }

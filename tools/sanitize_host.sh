@@ -42,4 +42,30 @@ one() { # name, -fsanitize flags, runtime to preload, options env
 }
 rm -f build/san_*/asan.* build/san_*/ubsan.* build/san_*/tsan.* 2>/dev/null
 if [ "$what" = asan ] || [ "$what" = all ]; then one asan "-fsanitize=address,undefined" "$GCCDIR/libasan.so:$GCCDIR/libubsan.so"; fi
-if [ "$what" = tsan ] || [ "$what" = all ]; then one tsan "-fsanitize=thread" "$GCCDIR/libtsan.so"; fi
+# TSan: a preloaded libtsan under CPython hangs (it wants to be first in the process), so the threaded paths are driven by a
+# small C++ program instead (tools/tsan_driver.cpp: loader, name ranks, VT/ED formatters, gz writer, index builders, each on
+# several thread counts with the outputs compared) plus the CLI itself
+tsan() {
+  O=$ROOT/build/san_tsan; mkdir -p $O; rm -f $O/tsan.*
+  cp -f $LIBDIR/libsigax.so $O/
+  COMMON="g++ -O1 -g -fno-omit-frame-pointer -std=c++17 -fPIC -Wall -Wno-sign-compare -pthread -fsanitize=thread"
+  $COMMON -shared -o $O/libsiga_host.so siga_amd/host/siga_host.cpp -L$O -lsigax -lz -ldl -Wl,-rpath,'$ORIGIN' || return 1
+  $COMMON -o $O/siga siga_amd/host/siga_main.cpp -L$O -lsiga_host -lsigax -lz -ldl -Wl,-rpath,'$ORIGIN' || return 1
+  $COMMON -o $O/tsan_driver tools/tsan_driver.cpp -L$O -lsiga_host -lsigax -lz -ldl -Wl,-rpath,'$ORIGIN' || return 1
+  log=$ROOT/profiles/r04_sanitize_tsan.log
+  D=$(mktemp -d)
+  {
+    echo "== tsan: $COMMON"
+    echo "== $(g++ --version | head -1); $(date -u +%F)"
+    export TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 strict_memcmp=0 log_path=$O/tsan second_deadlock_stack=1"
+    timeout -k 10 1200 $O/tsan_driver $D; echo "tsan_driver rc=$?"
+    cp $D/tsan_reads.fa $D/cli.fa
+    (cd $D && timeout -k 10 600 $O/siga index --cpu -t 4 cli.fa; echo "siga index --cpu -t 4 rc=$?"; timeout -k 10 600 $O/siga index --cpu -a sais -t 4 -p cli_sais cli.fa; echo "siga index -a sais rc=$?")
+    echo "== reports:"
+    ls $O | grep -E "^tsan\." || echo "(none)"
+    for f in $O/tsan.*; do [ -f "$f" ] && { echo "---- $f"; head -120 "$f"; }; done
+  } > $log 2>&1
+  rm -rf $D
+  tail -25 $log
+}
+if [ "$what" = tsan ] || [ "$what" = all ]; then tsan; fi
