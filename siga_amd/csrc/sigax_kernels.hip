@@ -2884,8 +2884,10 @@ struct GFx {
       ni = 0;
       u32 p = 0;
       while (p != ng) {
-        if (TEXT && p == 0u && ni == 0u && ng >= 3u) {
-          // Many turns of the ring AT ONCE.  While nothing is erased and nothing branches, the stride-2 walk visits the groups at
+        if (TEXT && p == 0u && ni == 0u) {
+          // Many turns of the ring AT ONCE (one group, or the head of two, is the same walk: place 0 again and again; a countdown
+          // group that is alone there is emitted without counting down, and the count comes out the same: 2 t here + 2 there).
+          // While nothing is erased and nothing branches, the stride-2 walk visits the groups at
           // the EVEN places of the list, in order, again and again (with an even number of groups a pass ends at the list's end
           // and the next starts at place 0; with an odd number it wraps to place 0 inside the pass), and the groups at the odd
           // places are not touched at all.  A visit to a countdown group with t rounds to go takes one off; a visit to a group
