@@ -520,7 +520,7 @@ def bench_overlap(args):
                                        n_total, L, G, args.seed, args.min_overlap, job_world,
                                        " (this process: rank 0's shard only)" if job_world != world else "",
                                        ", the locality ordering included," if ri["read_order"] else ""),
-                       "reads_per_gpu": n_local, "edges": total_edges, "blocks_per_read": st["n_blocks"] / max(n_local, 1),
+                       "reads_per_gpu": n_local, "genome_bp": G, "read_len": L, "kernels_sha": kernels_sha(), "edges": total_edges, "blocks_per_read": st["n_blocks"] / max(n_local, 1),
                        "n_occ_min_per_read": (st["n_occ_find"] + st["n_occ_extract"]) / max(n_local, 1),
                        "sectors_per_read": {"find": sec_f / max(n_local, 1), "extract": sec_x / max(n_local, 1)},
                        "algorithmic_bytes_per_read": bytes_step / max(n_local, 1),
@@ -738,8 +738,10 @@ def bench_correct(args):
         "metric": "reads/sec corrected (siga correct k-mer path, output bit-exact)", "value": N * steps / elapsed, "unit": "reads/s",
         "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "siga correct -k %d -x 3 -i 10 -O 1 on synthetic %dx%d bp reads from %d bp genome with %.2g "
+        "config": {"workload": "BASELINE configs[3] (`siga correct` k-mer path; configs[1]-shaped reads with substitutions stand in for the E. coli "
+                               "MiSeq set): siga correct -k %d -x 3 -i 10 -O 1 on synthetic %dx%d bp reads from %d bp genome with %.2g "
                                "substitutions per base; FM-index of those reads resident in HBM" % (k, N, L, G, err_rate),
+                   "kernels_sha": kernels_sha(),
                    "reads_written": n_valid, "reads_equal_to_truth": restored, "kmer_lookups_per_read": int(stat[2]) / N,
                    "sectors_per_read": int(stat[1]) / N, "algorithmic_bytes_per_read": bytes_step / N},
         "roofline": None,

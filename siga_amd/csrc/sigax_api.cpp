@@ -1874,7 +1874,11 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   // Three workgroups per CU: all of them are resident beside the finder's two (register file: 2 x 64 + 3 x 128 per
   // SIMD), so no filter/extract workgroup is left waiting to take the slot a finished finder workgroup frees.
   static const char* env_fxg = getenv("SIGAX_FX_GRID");
-  unsigned fast_grid = (unsigned)std::min<u64>(env_fxg ? (u64)atoi(env_fxg) : 3u * (unsigned)ix->n_cu, ((u64)n + 3) / 4);  // two items per wave
+  // (round 4: 2.5 per CU beside the per-lane finder's three workgroups -- two fit a CU's LDS beside them, the rest queue --;
+  // 3 per CU beside the cooperative finder as before)
+  static const char* env_cmin_g = getenv("SIGAX_COOP_MIN_SYMBOLS");
+  const bool coop_idx = ix->wide || ix->n_symbols >= (env_cmin_g ? strtoull(env_cmin_g, nullptr, 10) : (1ull << 30));
+  unsigned fast_grid = (unsigned)std::min<u64>(env_fxg ? (u64)atoi(env_fxg) : (coop_idx ? 3u * (unsigned)ix->n_cu : 5u * (unsigned)ix->n_cu / 2u), ((u64)n + 3) / 4);  // two items per wave
   if (fast_grid == 0) fast_grid = 1;
   if ((rc = ensure(&b->wpool, (size_t)fast_grid * 4 * fast_pool_entries_per_wave() * SIGAX_ENT_BYTES)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->work, ((size_t)n + 1) * 4)) != SIGAX_OK) return rc;
@@ -1943,7 +1947,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     const u64 coop_min0 = env_cmin0 ? strtoull(env_cmin0, nullptr, 10) : (1ull << 30);
     const bool coop_would = (ix->st[0].gran2 && ix->st[1].gran2) && (env_coop0 ? env_coop0[0] != '0' : (ix->wide || ix->n_symbols >= coop_min0)) &&
                             32ull * perm_stride + 32 <= 32768;
-    if (order_on && n >= 2 && (coop_would || 128ull * perm_stride + 8 <= find_stage_capacity())) {
+    if (order_on && n >= 2 && (coop_would || 128ull * perm_stride + 8 <= find_stage_capacity(b->cur_max_len))) {
       if (!b->perm_valid || b->perm_nsub != nsub) {
         HIP_TRY(hipEventRecord(b->ev[EV_ORD0], st));  // behind the upload of the reads
         HIP_TRY(hipStreamWaitEvent(ix->s_ord, b->ev[EV_ORD0], 0));
@@ -1979,6 +1983,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.offs = b->d_offs;
     fa.n_reads = n;
     fa.minov = b->minov;
+    fa.max_len = b->cur_max_len;
     fa.chain_mask = (b->flags & SIGAX_DUPLICATE) ? 0x9u : (b->flags & SIGAX_RC) ? 0xFu : 0x5u;
     fa.cap = b->cap;
     fa.max_seen = ix->cap_seen->load();
@@ -2017,7 +2022,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     fa.arena = b->arena.p;
     fa.chain_cnt = (uint32_t*)b->chain_cnt.p;
     fa.dstat = dstat;
-    fa.perm = (fa.coop || 128ull * perm_stride + 8 <= find_stage_capacity()) ? d_perm : nullptr;
+    fa.perm = (fa.coop || 128ull * perm_stride + 8 <= find_stage_capacity(b->cur_max_len)) ? d_perm : nullptr;
     fa.stage_stride = perm_stride;
     b->last_two_step = fa.two_step != 0;
     b->last_coop = fa.coop != 0;
@@ -2031,7 +2036,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     // strand's granule table once the two tables together pass the translation reach (profiles/r01_gather_probe.txt).
     const bool big_one_step = !fa.two_step && ix->n_symbols >= (1ull << 30);
     const bool split = fa.coop || ((env_split ? env_split[0] != '0' : ((fa.two_step && ix->split_strands) || big_one_step)) &&
-                                   128ull * b->cur_max_len + 8 <= find_stage_capacity());
+                                   128ull * b->cur_max_len + 8 <= find_stage_capacity(b->cur_max_len));
     b->find_per_sub = split ? 2u : 1u;
     if (split) {
       // one launch per strand's two-step table (chains 0,1 gather from the forward index, 2,3 from the reverse one)

@@ -47,6 +47,7 @@ struct FindArgs {
   uint32_t max_seen;                 // chains no longer than this need not report their length (DS_MAX_CHAIN)
   uint32_t start_ok;                 // both strands carry the start table and min-overlap >= 12: chains may start twelve symbols in
   uint32_t deep_k;                   // both strands carry the deep start table with this K <= min-overlap (fm_layout.h), or 0
+  uint32_t max_len;                  // the batch's longest read (sizes the per-lane finder's LDS budget)
   uint32_t read_begin, read_end;     // this launch's sub-batch
   uint32_t stage_bytes;              // dynamic LDS per workgroup that may hold the workgroup's reads (set by launch_find)
   uint32_t two_step;                 // both strands carry the two-step table (u32 positions only)
@@ -189,7 +190,7 @@ void launch_deep_scan(const FmStrand& s, const uint32_t* slen, unsigned long lon
 void launch_deep_fill(const FmStrand& prim, const FmStrand& other, bool wide, const uint32_t* slen, unsigned long long n_stretch, uint32_t K,
                       const unsigned long long* list, unsigned long long n_list, void* tab, unsigned long long nslots, unsigned long long* err,
                       hipStream_t st);
-unsigned long long find_stage_capacity();  // bytes of reads a finder workgroup can stage in LDS
+unsigned long long find_stage_capacity(unsigned max_len);  // bytes of reads a finder workgroup can stage in LDS (batch's longest read given)
 void launch_filter_extract(const FxArgs& a, bool wide, unsigned grid, hipStream_t st);
 // qhint: items the four queues held last time (per sub-batch; ~0 = unknown), or NULL
 void launch_filter_extract_fast(const FxArgs& a, bool wide, unsigned grid32, unsigned grid64, const unsigned long long* qhint, hipStream_t st);

@@ -4048,13 +4048,22 @@ void launch_correct(const CorrectArgs& a0, bool wide, hipStream_t st) {
   else hipLaunchKernelGGL((k_correct<false, CORRECT_LMAX>), dim3(g), dim3(256), 0, st, a);
 }
 
-static unsigned find_lds_budget() {
+// LDS budget of a per-lane finder workgroup (its residency cap and its read-staging buffer; SIGAX_FIND_LDS overrides).
+// Round 4: 45000 = THREE workgroups (twelve waves) per CU and two filter/extract workgroups beside them, where rounds 1-3 ran
+// two and three: since the deep start table and the extractor's fast-forward took a quarter of each kernel's work, the
+// finder is what the step waits for, and it follows its residency (tools/sweep_env.sh, BASELINE configs[1], same box: 60000
+// 145.7 M reads/s, 50000 143.6, 47000 149.6, 45000 153.4-153.8 -- with a filter/extract grid of 2.5 per CU 155.9 --, 43000
+// and below slower again: the finder's workgroups then leave filter/extract no LDS at all).  Reads too long for 128 of them
+// to fit the smaller staging buffer get the budget they need, up to the old 60000.
+static unsigned find_lds_budget(unsigned max_len) {
   static const char* env = getenv("SIGAX_FIND_LDS");
-  return env ? (unsigned)atoi(env) : 60000u;
+  if (env) return (unsigned)atoi(env);
+  const unsigned need = (unsigned)sizeof(FindStage) + 128u * max_len + 64u;
+  return need <= 45000u ? 45000u : (need <= 60000u ? need : 60000u);
 }
-// bytes of a workgroup's reads that can be staged in LDS (see launch_find)
-unsigned long long find_stage_capacity() {
-  const unsigned lds = find_lds_budget();
+// bytes of a workgroup's reads that can be staged in LDS when the batch's longest read has max_len bases (see launch_find)
+unsigned long long find_stage_capacity(unsigned max_len) {
+  const unsigned lds = find_lds_budget(max_len);
   return lds > (unsigned)sizeof(FindStage) ? lds - (unsigned)sizeof(FindStage) : 0u;
 }
 
@@ -4066,7 +4075,7 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
   // wave slots and registers for the filter/extract kernel that runs beside it on the other stream.
   // Measured on MI355X at C2: 28 resident waves/CU 15.7 ms, 12 waves 14.5 ms, 8 waves 13.4 ms, 4 waves 14.9 ms.
   // 60 KB per workgroup = two workgroups (8 waves) per CU and 40 KB of LDS left for filter/extract workgroups.
-  unsigned lds = (unsigned)find_stage_capacity();  // the record staging rows are part of the budget
+  unsigned lds = (unsigned)find_stage_capacity(a.max_len);  // the record staging rows are part of the budget
   FindArgs b = a;
   b.stage_bytes = lds;  // the residency cap doubles as the staging buffer for the workgroup's reads
   if (a.coop && a.two_step && a.fwd.gran2 && a.rev.gran2 && a.chains_per_wg == 2) {

@@ -8,7 +8,7 @@ HBM-side bytes per launch come from the L2's memory-side request counters by siz
 because FETCH_SIZE = 64 B x TCC_EA0_RDREQ whatever the request size (tools/fetch_calib.hip: it reads exactly half of a
 coalesced stream's bytes, and 64 B per line for random 16-byte pieces of 128-byte lines)."""
 import collections, csv, glob, json, os, shutil, sys
-R = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+R = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 O = 'gpurun_out/prof'
 def latest(pat):
     fs = sorted(glob.glob(pat), key=os.path.getmtime)
@@ -52,20 +52,22 @@ for tag, suffix in (('default', ''), ('subbatches_1', '1')):
                 merged[k].update(v)
     res[tag] = merged
     try:
-        launches = last_json('%s/q_rd%s.json' % (O, suffix))['launches_per_step']
+        bj = last_json('%s/q_rd%s.json' % (O, suffix))
+        launches = bj['launches_per_step']
+        sha = bj['config'].get('kernels_sha')
     except Exception:
         continue
     fx_rd = fx_wr = 0.0
     for k, c in merged.items():
         if k.startswith('k_find'):
             tr['k_find/1000000/5000000/150/%d' % launches] = {
-                'hbm_bytes_per_launch': rd_bytes(c) + wr_bytes(c), 'read': rd_bytes(c), 'write': wr_bytes(c), 'kernel': k,
+                'hbm_bytes_per_launch': rd_bytes(c) + wr_bytes(c), 'read': rd_bytes(c), 'write': wr_bytes(c), 'kernel': k, 'kernels_sha': sha,
                 'source': 'profiles/%s_pmc_per_launch.json %s: TCC_EA0_RDREQ/_WRREQ by size class (tools/collect_profiles.py)' % (R, tag)}
         if k.startswith('k_filter_extract_fast') or k.startswith('k_fx_route'):
             fx_rd += rd_bytes(c); fx_wr += wr_bytes(c)
     if fx_rd:
         tr['k_filter_extract_fast/1000000/5000000/150/%d' % launches] = {
-            'hbm_bytes_per_launch': fx_rd + fx_wr, 'read': fx_rd, 'write': fx_wr,
+            'hbm_bytes_per_launch': fx_rd + fx_wr, 'read': fx_rd, 'write': fx_wr, 'kernels_sha': sha,
             'source': 'profiles/%s_pmc_per_launch.json %s: 32-lane + 64-lane launch of one sub-batch' % (R, tag)}
 kc = collections.defaultdict(dict)
 for name in ('k_rd', 'k_hm'):
@@ -76,7 +78,11 @@ if kc:
     res['correct'] = kc
     # one correction call = the launch of the small form + the launch of the 1024 form behind it: both counted
     tot = sum(rd_bytes(c) for c in kc.values())
-    tr['k_correct/1000000/5000000/150/31'] = {'hbm_bytes_per_launch': tot, 'read': tot, 'kernel': ' + '.join(sorted(kc)),
+    try:
+        csha = last_json('%s/k_rd.json' % O)['config'].get('kernels_sha')
+    except Exception:
+        csha = None
+    tr['k_correct/1000000/5000000/150/31'] = {'hbm_bytes_per_launch': tot, 'read': tot, 'kernel': ' + '.join(sorted(kc)), 'kernels_sha': csha,
                                               'source': 'profiles/%s_pmc_per_launch.json correct (reads only)' % R}
 json.dump(res, open('profiles/%s_pmc_per_launch.json' % R, 'w'), indent=1)
 if tr:

@@ -5,8 +5,8 @@ same run), <R>_bench_<shape>.json (the plain run with --isolated), <R>_pmc_<shap
 and launch) and the shape's keys of traffic.json (what bench.py prints as roofline.traffic).  Memory-side bytes per launch as
 in tools/collect_profiles.py: 128 x RDREQ_128B + 64 x RDREQ_64B + 32 x RDREQ_32B (+ writes likewise)."""
 import collections, csv, glob, json, os, shutil, sys
-R = sys.argv[1] if len(sys.argv) > 1 else 'r03'
-O = 'gpurun_out/shapes'
+R = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+O = os.environ.get('SHAPES_OUT', 'gpurun_out/shapes')
 def latest(pat):
     fs = sorted(glob.glob(pat), key=os.path.getmtime)
     return fs[-1] if fs else None
@@ -55,17 +55,17 @@ for shape in ('c3', 'c5'):
         b = last_json('%s/%s_rd.json' % (O, shape))
     except Exception:
         continue
-    key = '%d/%d/%d/%d' % (b['config']['reads_per_gpu'], int(b['config']['workload'].split(' bp reads from ')[1].split(' ')[0]),
-                           int(b['config']['workload'].split('x')[1].split(' ')[0]), b['launches_per_step'])
+    key = '%d/%d/%d/%d' % (b['config']['reads_per_gpu'], b['config']['genome_bp'], b['config']['read_len'], b['launches_per_step'])
+    sha = b['config'].get('kernels_sha')
     fx_rd = fx_wr = 0.0
     for k, c in merged.items():
         if k.startswith('k_find'):
-            tr['k_find/' + key] = {'hbm_bytes_per_launch': rd_bytes(c) + wr_bytes(c), 'read': rd_bytes(c), 'write': wr_bytes(c), 'kernel': k,
+            tr['k_find/' + key] = {'hbm_bytes_per_launch': rd_bytes(c) + wr_bytes(c), 'read': rd_bytes(c), 'write': wr_bytes(c), 'kernel': k, 'kernels_sha': sha,
                                    'source': 'profiles/%s_pmc_%s.json: TCC_EA0_RDREQ/_WRREQ by size class (tools/collect_shapes.py)' % (R, shape)}
         if k.startswith('k_filter_extract_fast') or k.startswith('k_fx_route'):
             fx_rd += rd_bytes(c); fx_wr += wr_bytes(c)
     if fx_rd:
-        tr['k_filter_extract_fast/' + key] = {'hbm_bytes_per_launch': fx_rd + fx_wr, 'read': fx_rd, 'write': fx_wr,
+        tr['k_filter_extract_fast/' + key] = {'hbm_bytes_per_launch': fx_rd + fx_wr, 'read': fx_rd, 'write': fx_wr, 'kernels_sha': sha,
                                               'source': 'profiles/%s_pmc_%s.json: the launch chain of one sub-batch' % (R, shape)}
     print(shape, key, {k: v['hbm_bytes_per_launch'] for k, v in tr.items() if key in k})
 json.dump(tr, open(tpath, 'w'), indent=1)

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/xlat; mkdir -p $O
 export SIGAX_TABLES_SYNC=1
-C2="--cpu-sample 0 --steps 3 --warmup 1 --subbatches 1 --depth 1"
+C2="--cpu-sample 0 --no-e2e --upload-steps 0 --steps 3 --warmup 1 --subbatches 1 --depth 1"
 C3="$C2 --reads-per-gpu 2500000 --genome-per-gpu 12500000 --emulate-world 8 --seed 2"
 # at most a few counters of one block per pass ("Request exceeds the capabilities of the hardware to collect" otherwise)
 P1="TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum"

@@ -8,8 +8,8 @@ cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof; mkdir -p $O
 # the row tables at open rather than beside the second run: every profiled launch is then a steady-state one
 export SIGAX_TABLES_SYNC=1
-B="python3 bench.py --cpu-sample 0 --steps 20 --warmup 3"
-P="python3 bench.py --cpu-sample 0 --steps 3 --warmup 1"
+B="python3 bench.py --cpu-sample 0 --no-e2e --upload-steps 0 --steps 20 --warmup 3"
+P="python3 bench.py --cpu-sample 0 --no-e2e --upload-steps 0 --steps 3 --warmup 1"
 ISO="--subbatches 1 --depth 1"
 RD="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum"
 WR="TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"
@@ -47,8 +47,8 @@ if [ "$what" = correct ] || [ "$what" = all ]; then
   run k_hm --kernel-trace --pmc $HM -d $O/k_hm --output-format csv -- $C || exit 1
 fi
 if [ "$what" = full ] || [ "$what" = all ]; then
-  # the plain default run (300 timed steps, CPU baseline leg) as the driver runs it, plus --isolated
-  timeout -k 10 400 python3 bench.py --isolated > $O/bench_full.json 2> $O/bench_full.err; echo "bench_full rc=$?" >> $O/profiles.log
+  # the plain default run (300 timed steps, CPU baseline leg, end_to_end and upload_inclusive legs) as the driver runs it, plus --isolated
+  timeout -k 10 600 python3 bench.py --isolated > $O/bench_full.json 2> $O/bench_full.err; echo "bench_full rc=$?" >> $O/profiles.log
 fi
 find $O -name "*kernel_trace.csv" -size +4M -delete
 cat $O/profiles.log

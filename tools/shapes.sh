@@ -10,10 +10,10 @@ cd "$GRAFT_REPO_ROOT"
 O=${SHAPES_OUT:-gpurun_out/shapes}; mkdir -p $O
 export SIGAX_TABLES_SYNC=1   # row tables at open: every profiled launch is a steady-state one
 if [ "$shape" = c3 ]; then
-  A="--emulate-world 8 --cpu-sample 0"    # defaults = configs[2]: 2.5 M reads per rank from 20 M x 150 bp, 100 Mb, seed 2
+  A="--emulate-world 8 --cpu-sample 0 --upload-steps 0"    # defaults = configs[2]: 2.5 M reads per rank from 20 M x 150 bp, 100 Mb, seed 2
   STEPS="--steps 20 --warmup 2"; PSTEPS="--steps 3 --warmup 1"
 else
-  A="--emulate-world 8 --reads-per-gpu 6250000 --genome-per-gpu 28750000 --read-len 250 --seed 3 --max-local-reads 1000000 --cpu-sample 0"
+  A="--emulate-world 8 --reads-per-gpu 6250000 --genome-per-gpu 28750000 --read-len 250 --seed 3 --max-local-reads 1000000 --cpu-sample 0 --upload-steps 0"
   STEPS="--steps 10 --warmup 2"; PSTEPS="--steps 2 --warmup 1"
 fi
 RD="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_32B_sum"
