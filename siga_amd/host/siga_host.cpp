@@ -1692,6 +1692,12 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
     out.write_parts(parts);
     if (pt.on) fprintf(stderr, "[siga]   batch %zu: VT text %.3f s, deflate + write %.3f s\n", b, std::chrono::duration<double>(tv1 - tv0).count(),
                        std::chrono::duration<double>(std::chrono::steady_clock::now() - tv1).count());
+    // the reference's progress line (OverlapPostProcess, src/overlap_builder.cpp:319-321: every threads x batch reads)
+    if (pt.on) {
+      const size_t stepn = std::max<size_t>(threads, 1) * std::max<size_t>(batch, 1);
+      for (size_t at = (lo / stepn + 1) * stepn; at <= lo + cnt; at += stepn)
+        if (at % (stepn * 64) == 0 || at + stepn > n) fprintf(stderr, "processed %zu sequences\n", at);  // (every 64th: a device batch is a million reads)
+    }
     edges.emplace_back(r.edges, r.n_edges);
     ed_text.emplace_back();
     if (ed_held < ed_hold_max) {

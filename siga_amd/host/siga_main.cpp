@@ -78,7 +78,12 @@ static int apply_ini(int argc, char** argv, const option* longopts, std::vector<
 static int usage() {
   printf("siga [index|correct|overlap|rmdup] [OPTION] ... READSFILE\n"
          "  index     build the FM-index (.sai/.bwt/.rsai/.rbwt) of READSFILE\n"
-         "  overlap   compute pairwise overlaps between all the sequences in READSFILE (GPU)\n");
+         "  overlap   compute pairwise overlaps between all the sequences in READSFILE (GPU)\n"
+         "  rmdup     remove duplicated reads (GPU)\n"
+         "  correct   k-mer based error correction (GPU)\n"
+         "common options: -s, --ini=FILE (options from FILE, the command line goes over them);\n"
+         "                -c, --log4cxx=FILE is accepted and ignored (this build logs to stderr; SIGA_TIMING=1 prints phase\n"
+         "                times and the reference's \"processed N sequences\" progress lines)\n");
   return 256;
 }
 

@@ -89,7 +89,8 @@ def test_fullsize_every_read_against_oracle(c2):
 def test_row_tables_come_with_reuse_not_with_the_first_pass(c2):
     """An index opened through the plain C-ABI call builds the extractor's row tables only once it has been asked for as
     many reads as it holds -- one pass of `siga overlap` (src/overlap.cpp:41-47) never pays for them -- or when the caller
-    says it is here to stay (sigax_index_prepare).  Same blocks and edges with the extractor walking (first pass) and
+    says it is here to stay (sigax_index_prepare / sigax_index_prepare_overlap); the finder's deep start table follows the
+    same rule.  Same blocks and edges with the extractor walking and every chain starting twelve symbols in (first pass) and
     with the tables (after prepare); the tables show in the index's device bytes."""
     sa = c2["sa"]
     pair = sa.FMIndexPair.load(c2["prefix"], resident=False)
@@ -105,8 +106,8 @@ def test_row_tables_come_with_reuse_not_with_the_first_pass(c2):
         for k in ("block_offs", "blocks", "substring", "edges"):
             assert first[k].tobytes() == full[k].tobytes(), k
         assert first["stats"]["n_occ_find"] + first["stats"]["n_occ_extract"] == full["stats"]["n_occ_find"] + full["stats"]["n_occ_extract"]
-        second = b.overlap(reads, M, edges=True)  # the index is being reused: the build starts beside this run
-        pair.prepare()                             # ... and is waited for here
+        second = b.overlap(reads, M, edges=True)  # the index is being reused: the builds start beside this run
+        pair.prepare_overlap(M)                    # ... and are waited for here
         assert pair.info()["device_bytes"] == c2["pair"].info()["device_bytes"]
         third = b.overlap(reads, M, edges=True)
         for k in ("block_offs", "blocks", "substring", "edges"):

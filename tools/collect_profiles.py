@@ -106,3 +106,13 @@ if os.path.exists('%s/bench_full.json' % O):
     b = last_json('%s/bench_full.json' % O)
     json.dump(b, open('profiles/%s_bench_default.json' % R, 'w'))
     print('bench_full', b['value'], b['ms_per_step'], b['roofline']['frac'], b['roofline'].get('isolated', {}).get('frac'))
+
+for k in (31, 41):
+    f = '%s/bench_correct_k%d.json' % (O, k)
+    if os.path.exists(f):
+        try:
+            b = last_json(f)
+            json.dump(b, open('profiles/%s_bench_correct_k%d.json' % (R, k), 'w'))
+            print('correct k', k, b['value'], b['ms_per_step'])
+        except Exception as e:
+            print('correct k', k, 'no bench line', e)

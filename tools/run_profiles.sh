@@ -49,6 +49,10 @@ fi
 if [ "$what" = full ] || [ "$what" = all ]; then
   # the plain default run (300 timed steps, CPU baseline leg, end_to_end and upload_inclusive legs) as the driver runs it, plus --isolated
   timeout -k 10 600 python3 bench.py --isolated > $O/bench_full.json 2> $O/bench_full.err; echo "bench_full rc=$?" >> $O/profiles.log
+  # BASELINE configs[3]: the corrector at k = 31 (code default) and k = 41 (the example script's), CPU baseline leg included
+  for k in 31 41; do
+    timeout -k 10 400 python3 bench.py --workload correct --kmer $k --steps 20 --warmup 3 > $O/bench_correct_k$k.json 2> $O/bench_correct_k$k.err; echo "bench_correct_k$k rc=$?" >> $O/profiles.log
+  done
 fi
 find $O -name "*kernel_trace.csv" -size +4M -delete
 cat $O/profiles.log
