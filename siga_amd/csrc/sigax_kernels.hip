@@ -3532,6 +3532,10 @@ struct CorrectShT {
   unsigned char redo[LMAX];   // window must be recounted
   unsigned short pref[LMAX + 1];  // solid windows before this one
   u32 cnt[LMAX];              // occurrences of the window's k-mer (saturated)
+  // the read's bases as 2-bit codes (rank - 1), LAST base first: symbol j at bits 2 (j & 31) of word j / 32, so the k-mer
+  // starting at s, in the order the backward search consumes it (= the k-mer table's key), is the 2 k bits from bit
+  // 2 (n - s - k) on; two words of zeros behind for the unaligned reads
+  u64 rv[LMAX / 32 + 3];
 };
 
 // Interval::occurrences of the k-mer starting at `s` in sh.seq, with base `ovpos` replaced by rank `ovrank`.
@@ -3569,8 +3573,34 @@ __global__ __launch_bounds__(256) void k_prefix_build(FmStrand s, void* tab, u32
 template <bool WIDE>
 __device__ __forceinline__ u32 kmer_occ(const FmRef& f, const FmTables& tb, const Find2TablesT<WIDE>* t2, const uint32_t* gran2,
                                         const u64* super2, const void* ptab, u32 pk, const unsigned char* seq, u32 s, u32 k, u32 ovpos,
-                                        u32 ovrank, u32& nsec, const void* ktab = nullptr, u64 ktab_slots = 0) {
+                                        u32 ovrank, u32& nsec, const void* ktab = nullptr, u64 ktab_slots = 0, const u64* rv = nullptr,
+                                        u32 n = 0) {
   typedef typename PosOf<WIDE>::type P;
+  if (ktab != nullptr && rv != nullptr) {
+    // ACGT-only read with its reverse-packed codes in LDS (CorrectShT::rv): the key is two shifted words, the candidate
+    // substitution two bits of it -- a dozen instructions instead of k byte reads and rank conversions
+    const u32 o = 2u * (n - s - k), w = o >> 6, sh = o & 63u;
+    const u64 a = rv[w], b = rv[w + 1], c = rv[w + 2];
+    u64 k0 = sh ? (a >> sh) | (b << (64u - sh)) : a;
+    u64 k1 = sh ? (b >> sh) | (c << (64u - sh)) : b;
+    if (k <= 32u) {
+      if (k < 32u) k0 &= (1ull << (2u * k)) - 1ull;
+      k1 = 0;
+    } else {
+      k1 &= (1ull << (2u * (k - 32u))) - 1ull;
+    }
+    if (ovpos >= s && ovpos < s + k) {
+      const u32 i = s + k - 1u - ovpos;
+      const u64 cc = (u64)((ovrank - 1u) & 3u);
+      if (i < 32u) k0 = (k0 & ~(3ull << (2u * i))) | (cc << (2u * i));
+      else k1 = (k1 & ~(3ull << (2u * (i - 32u)))) | (cc << (2u * (i - 32u)));
+    }
+    k1 |= (u64)(0x8000u | k) << 48;
+    P a0 = 0, a1 = 0, az = 0;
+    nsec += 1u;
+    if (!deep_lookup<WIDE>(ktab, ktab_slots, k0, k1, a0, a1, az)) return 0u;
+    return (u64)az > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)az;
+  }
   if (ktab != nullptr) {
     // the table holds every distinct k-mer of the indexed reads with its number of occurrences (fm_layout.h: the deep start
     // table with K = k): one lookup, and a k-mer that is not there does not occur.  Key = the k-mer in the order the
@@ -3722,9 +3752,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMAX <= 512
     wave_lds_sync();
     if (n >= k) {  // src/correct_processor.cpp:85-89
       const u32 nw = n - k + 1;
+      // the reverse-packed codes for the k-mer table's keys (only reads of A, C, G, T: the others keep the byte-wise keys)
+      bool clean = false;
+      if (A.ktab != nullptr) {
+        bool bad = false;
+        for (u32 w = lane; w < n / 32u + 3u; w += 64) {
+          u64 v = 0;
+          for (u32 j = 0; j < 32u; ++j) {
+            const u32 t = 32u * w + j;
+            if (t < n) {
+              const u32 r = base_rank(sh.seq[n - 1u - t]);
+              bad = bad || r == 0u;
+              v |= (u64)((r - 1u) & 3u) << (2u * j);
+            }
+          }
+          sh.rv[w] = v;
+        }
+        clean = __ballot(bad) == 0ull;
+      }
+      const u64* rv = clean ? sh.rv : nullptr;
       for (u32 s = lane; s < nw; s += 64) {
-        u32 m = 255;
-        for (u32 j = 0; j < k; ++j) m = min(m, (u32)sh.score[s + j]);
+        u32 m = 15;  // no qualities (FASTA): every base scores 15
+        if (A.quals != nullptr) {
+          m = 255;
+          for (u32 j = 0; j < k; ++j) m = min(m, (u32)sh.score[s + j]);
+        }
         sh.minph[s] = (unsigned char)m;
         sh.redo[s] = 1;
       }
@@ -3738,7 +3790,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMAX <= 512
           bool good = false;
           if (s < nw) {
             if (sh.redo[s]) {
-              sh.cnt[s] = kmer_occ<WIDE>(F, tb, t2, A.fwd.gran2, A.fwd.super2, A.ptab, A.pk, sh.seq, s, k, 0xFFFFFFFFu, 0u, nsec, A.ktab, A.ktab_slots);
+              sh.cnt[s] = kmer_occ<WIDE>(F, tb, t2, A.fwd.gran2, A.fwd.super2, A.ptab, A.pk, sh.seq, s, k, 0xFFFFFFFFu, 0u, nsec, A.ktab, A.ktab_slots, rv, n);
               ++nlook;
               sh.redo[s] = 0;
             }
@@ -3790,7 +3842,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMAX <= 512
                 const u32 kidx = side ? (pos < n - k ? pos : n - k) : (pos + 1 >= k ? pos + 1 - k : 0u);
                 const u32 thr = sh.score[pos] >= A.cutoff ? A.high : A.low;
                 const u32 minCount = A.offset > thr ? A.offset : thr;  // max(countVector[..] (always 0) + offset, threshold)
-                cand = kmer_occ<WIDE>(F, tb, t2, A.fwd.gran2, A.fwd.super2, A.ptab, A.pk, sh.seq, kidx, k, pos, brank, nsec, A.ktab, A.ktab_slots) >= minCount;
+                cand = kmer_occ<WIDE>(F, tb, t2, A.fwd.gran2, A.fwd.super2, A.ptab, A.pk, sh.seq, kidx, k, pos, brank, nsec, A.ktab, A.ktab_slots, rv, n) >= minCount;
                 ++nlook;
               }
             }
@@ -3803,7 +3855,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMAX <= 512
               const u32 wl = (u32)__ffsll((long long)wm) - 1u;  // lowest lane = smallest position, left before right
               const u32 wpos = __builtin_amdgcn_readlane(pos, wl);
               const u32 wr = 1u + (wl & 3u);
-              if (lane == 0) sh.seq[wpos] = wr == 1 ? 'A' : wr == 2 ? 'C' : wr == 3 ? 'G' : 'T';
+              if (lane == 0) {
+                sh.seq[wpos] = wr == 1 ? 'A' : wr == 2 ? 'C' : wr == 3 ? 'G' : 'T';
+                if (rv != nullptr) {  // ... and in the packed copy
+                  const u32 t = n - 1u - wpos;
+                  sh.rv[t >> 5] = (sh.rv[t >> 5] & ~(3ull << (2u * (t & 31u)))) | ((u64)(wr - 1u) << (2u * (t & 31u)));
+                }
+              }
               const u32 wlo = wpos + 1 >= k ? wpos + 1 - k : 0, whi = wpos < nw - 1 ? wpos : nw - 1;
               for (u32 s = wlo + lane; s <= whi; s += 64) sh.redo[s] = 1;
               corrected = true;
