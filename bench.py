@@ -245,11 +245,11 @@ def bench_overlap(args):
         dist.barrier()
     shard = reads[lo:hi] if whole else draw((lo, hi))
     pair = FMIndexPair.load(prefix, device=dev_index)
-    info = pair.info()
     # ReadInfo{name,length}: names r<i>; rank of a name under std::string operator<
     pair.set_reads(np.full(n_total, L, dtype=np.uint32), rank_of_r_names(n_total))
     # the index stays open for every step: row tables (set_reads did that) and the finder's deep start table for this -m
     pair.prepare_overlap(args.min_overlap)
+    info = pair.info()  # (device bytes with every table in place)
     log("index on GPU: %.1f MB, wide=%d (%.1f s since start)" % (info["device_bytes"] / 1e6, info["wide"], time.time() - t0))
 
     # N > 1 over RCCL: the edge gather goes through the library's own exchange step (sigax_gather_counts + sigax_gather_edges:

@@ -4,7 +4,7 @@
 mkdir -p gpurun_out/err
 : > gpurun_out/err/rates.txt
 for e in 0 0.0003 0.001 0.003 0.01; do
-  timeout -k 10 300 python bench.py --cpu-sample 0 --steps 40 --warmup 40 --error-rate $e --isolated > gpurun_out/err/e$e.json 2> gpurun_out/err/e$e.err || exit 1
+  timeout -k 10 300 python bench.py --cpu-sample 0 --no-e2e --upload-steps 0 --steps 40 --warmup 40 --error-rate $e --isolated > gpurun_out/err/e$e.json 2> gpurun_out/err/e$e.err || exit 1
   python - $e >> gpurun_out/err/rates.txt <<EOT
 import json, sys
 e = sys.argv[1]
