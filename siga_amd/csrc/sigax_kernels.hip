@@ -1490,15 +1490,8 @@ __global__ __launch_bounds__(256) void k_find_n2(FindArgs A) {
 #ifdef SIGAX_FIND_PRIO
   __builtin_amdgcn_s_setprio(SIGAX_FIND_PRIO);  // A/B: issue priority over the filter/extract waves on the same SIMD
 #endif
-#ifdef SIGAX_N2_DIRECT  // A/B build: records stored as they are made (no parking in LDS, no quad flush); launch_find pads the dynamic LDS
-  (void)sg;
-  FindStageNone sgn;
-  if (staged) find_body<false, true, true, false, 256, FindStageNone>(A, tb, sgn, t2, find_dyn_lds, rd_base);
-  else find_body<false, false, false, false, 256, FindStageNone>(A, tb, sgn, t2, find_dyn_lds, rd_base);
-#else
   if (staged) find_body<false, true, true>(A, tb, sg, t2, find_dyn_lds, rd_base);
   else find_body<false, false, false>(A, tb, sg, t2, find_dyn_lds, rd_base);
-#endif
 }
 // u32 positions, two-step table of any size below 2^32 symbols, lines fetched cooperatively through LDS: a workgroup =
 // 2 waves = the two chains of one strand for 64 reads (launched once per strand)
@@ -4158,9 +4151,6 @@ void launch_find(const FindArgs& a, bool wide, hipStream_t st) {
     return;
   }
   if (wide) hipLaunchKernelGGL(k_find_w, dim3(g), dim3(bs), lds, st, b);
-#ifdef SIGAX_N2_DIRECT
-  else if (a.two_step && a.fwd.gran2 && a.rev.gran2) hipLaunchKernelGGL(k_find_n2, dim3(g), dim3(bs), lds + (unsigned)sizeof(FindStage), st, b);  // same residency as the parking build
-#endif
   else if (a.two_step && a.fwd.gran2 && a.rev.gran2) hipLaunchKernelGGL(k_find_n2, dim3(g), dim3(bs), lds, st, b);
   else hipLaunchKernelGGL(k_find_n, dim3(g), dim3(bs), lds, st, b);
 }
