@@ -189,9 +189,14 @@ def bench_overlap(args):
     dev_index = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # SIGA_BENCH_REHEARSE_RANKS=1 (tests, one-GPU boxes): a world of ONE rank takes the N > 1 path -- process group, the library's
+    # RCCL communicator, counts + gather of every step's edge records, timing reduced over ranks -- so that the code the
+    # driver's multi-GPU runs execute has run before it gets there
+    multi_path = world > 1 or os.environ.get("SIGA_BENCH_REHEARSE_RANKS") == "1"
+    if multi_path:
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=60),
                                     device_id=dev)
@@ -241,7 +246,7 @@ def bench_overlap(args):
             offs_all = np.arange(0, (n_total + 1) * L, L, dtype=np.uint64)
             host.index_build_gpu(reads.reshape(-1), offs_all, prefix, device=dev_index)
         log("reads + index ready in %.1f s (%d reads, %d symbols per strand)" % (time.time() - t0, n_total, n_total * (L + 1)))
-    if world > 1:
+    if multi_path:
         dist.barrier()
     shard = reads[lo:hi] if whole else draw((lo, hi))
     pair = FMIndexPair.load(prefix, device=dev_index)
@@ -256,7 +261,7 @@ def bench_overlap(args):
     # ncclAllGather of counts, grouped ncclSend/ncclRecv of records); torch.distributed's gather stays as the fallback
     # (gloo rehearsals, SIGA_BENCH_TORCH_GATHER=1, or a rank without its communicator)
     comm = None
-    if world > 1 and args.backend == "nccl" and os.environ.get("SIGA_BENCH_TORCH_GATHER") != "1":
+    if multi_path and args.backend == "nccl" and os.environ.get("SIGA_BENCH_TORCH_GATHER") != "1":
         comm = make_sigax_comm(_lib.lib(), rank, world, dev_index, dev)
         log("rank %d: edge gather through %s" % (rank, "sigax_gather_edges (RCCL, C-ABI)" if comm else "torch.distributed"))
     n_local = hi - lo
@@ -339,7 +344,7 @@ def bench_overlap(args):
         lib.sigax_batch_device_outputs(batches[i], None, None, None, C.byref(d_edges))
         ne = int(stats.n_edges)
         with torch.cuda.stream(streams[i]):
-            if world == 1:
+            if not multi_path:
                 # the records leave the device here, inside the timed region; the copy runs beside the next step's kernels
                 # and is waited for when this batch object is finished the next time (or by the final synchronize)
                 if ne:
@@ -406,21 +411,21 @@ def bench_overlap(args):
     drain()
     ksum[:] = 0
     order_ms[0] = 0.0
-    if world > 1:
+    if multi_path:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t_start = time.perf_counter()
     run_steps(args.steps, depth + args.warmup)
     total_edges = last_edges[0]
-    if world > 1 and comm is not None:
+    if multi_path and comm is not None:
         total_edges = gathered_total[0]  # (the copies to pinned host memory are waited for by the synchronize below)
-    elif world > 1:
+    elif multi_path:
         total_edges = drain()  # every step's edge records have reached rank 0 before the clock stops
     torch.cuda.synchronize(dev)  # ... and its pinned host buffer
-    if world > 1:
+    if multi_path:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if multi_path:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -435,7 +440,7 @@ def bench_overlap(args):
     # upload_inclusive: the same steps with every step's reads going up from pinned host memory through sigax_batch_upload
     # (the PCIe-inclusive rate of the device path; the headline keeps the reads resident, as the metric's contract says)
     upl = None
-    if world == 1 and args.upload_steps > 0:
+    if world == 1 and not multi_path and args.upload_steps > 0:
         h_seqs = torch.from_numpy(np.ascontiguousarray(shard).reshape(-1)).pin_memory()
         h_offs = np.arange(0, (n_local + 1) * L, L, dtype=np.uint64)
         k0 = depth + args.warmup + args.steps
@@ -566,13 +571,13 @@ def bench_overlap(args):
                 "kernel_ms_per_step": {k: float(v) for k, v in zip(KERNELS, iso)}}
         if upl is not None:
             out["upload_inclusive"] = upl
-        if world > 1:
+        if multi_path:
             # what RCCL saw (the driver's SCALE record can be checked against it)
             out["config"]["ranks"] = {"backend": args.backend, "world_size": dist.get_world_size(), "devices_visible": torch.cuda.device_count(),
                                       "device_of_rank0": dev_index,
                                       "edge_gather": "sigax_gather_counts + sigax_gather_edges (C-ABI; ncclAllGather + grouped ncclSend/ncclRecv)"
                                                      if comm is not None else "torch.distributed all_gather + gather (%s)" % args.backend}
-        if world == 1 and args.cpu_sample > 0:
+        if world == 1 and not multi_path and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(prefix, reads, min(args.cpu_sample, n_total), args.min_overlap, st, lib, batch)
 
     for bt in batches:
@@ -581,12 +586,12 @@ def bench_overlap(args):
         torch.cuda.synchronize(dev)
         lib.sigax_comm_destroy(comm)
     pair.close()
-    if rank == 0 and world == 1 and job_world == 1 and not args.no_e2e and not args.error_rate and not by_pos and n_total <= 2000000:
+    if rank == 0 and world == 1 and not multi_path and job_world == 1 and not args.no_e2e and not args.error_rate and not by_pos and n_total <= 2000000:
         if reads is None:
             reads = draw(None)
         out["end_to_end"] = end_to_end_cli(workdir, reads, args.min_overlap, out.get("cpu_baseline"),
                                            named.startswith("BASELINE configs[1]") and args.min_overlap == 45)
-    if world > 1:
+    if multi_path:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

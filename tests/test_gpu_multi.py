@@ -65,6 +65,35 @@ def test_rccl_exchange_step_with_one_rank():
     assert L.sigax_comm_create(0, 3, 2, idb, C.byref(comm)) == -1  # rank outside the world
 
 
+def test_bench_takes_the_multi_rank_path_with_a_world_of_one(tmp_path):
+    """bench.py's N > 1 code -- RCCL process group, the library's communicator made from an id broadcast over it, every step's
+    edge records through sigax_gather_counts / sigax_gather_edges into rank 0's device buffer and on to pinned host memory,
+    timing reduced over ranks, `config.ranks` -- rehearsed with a world of ONE rank on the one GPU of this box
+    (SIGA_BENCH_REHEARSE_RANKS=1), so that the driver's 2/4/8-GPU runs are not its first execution.  Same edge count as the
+    plain one-GPU run."""
+    bench = os.path.join(ROOT, "bench.py")
+    common = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--seed", "2", "--read-len", "100", "--min-overlap", "40",
+              "--workdir", str(tmp_path / "job"), "--no-e2e", "--upload-steps", "0", "--reads-per-gpu", "40000", "--genome-per-gpu", "200000"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+
+    def run(extra_env):
+        r = subprocess.run([sys.executable, bench] + common, cwd=ROOT, env=dict(env, **extra_env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    plain = run({})
+    multi = run({"SIGA_BENCH_REHEARSE_RANKS": "1"})
+    assert "ranks" not in plain["config"]
+    assert multi["config"]["ranks"]["world_size"] == 1 and "sigax_gather_edges" in multi["config"]["ranks"]["edge_gather"]
+    assert multi["config"]["edges"] == plain["config"]["edges"] > 20000
+    fallback = run({"SIGA_BENCH_REHEARSE_RANKS": "1", "SIGA_BENCH_TORCH_GATHER": "1"})
+    assert "torch.distributed" in fallback["config"]["ranks"]["edge_gather"] and fallback["config"]["edges"] == plain["config"]["edges"]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
