@@ -1877,7 +1877,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   // (round 4: 2.5 per CU beside the per-lane finder's three workgroups -- two fit a CU's LDS beside them, the rest queue --;
   // 3 per CU beside the cooperative finder as before)
   static const char* env_cmin_g = getenv("SIGAX_COOP_MIN_SYMBOLS");
-  const bool coop_idx = ix->wide || ix->n_symbols >= (env_cmin_g ? strtoull(env_cmin_g, nullptr, 10) : (1ull << 30));
+  const bool coop_idx = ix->wide || ix->n_symbols >= (env_cmin_g ? strtoull(env_cmin_g, nullptr, 10) : (1ull << 31));
   unsigned fast_grid = (unsigned)std::min<u64>(env_fxg ? (u64)atoi(env_fxg) : (coop_idx ? 3u * (unsigned)ix->n_cu : 5u * (unsigned)ix->n_cu / 2u), ((u64)n + 3) / 4);  // two items per wave
   if (fast_grid == 0) fast_grid = 1;
   if ((rc = ensure(&b->wpool, (size_t)fast_grid * 4 * fast_pool_entries_per_wave() * SIGAX_ENT_BYTES)) != SIGAX_OK) return rc;
@@ -1944,7 +1944,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     const bool order_on = env_ord != nullptr && env_ord[0] != '0';
     static const char* env_coop0 = getenv("SIGAX_FIND_COOP");
     static const char* env_cmin0 = getenv("SIGAX_COOP_MIN_SYMBOLS");
-    const u64 coop_min0 = env_cmin0 ? strtoull(env_cmin0, nullptr, 10) : (1ull << 30);
+    const u64 coop_min0 = env_cmin0 ? strtoull(env_cmin0, nullptr, 10) : (1ull << 31);
     const bool coop_would = (ix->st[0].gran2 && ix->st[1].gran2) && (env_coop0 ? env_coop0[0] != '0' : (ix->wide || ix->n_symbols >= coop_min0)) &&
                             32ull * perm_stride + 32 <= 32768;
     if (order_on && n >= 2 && (coop_would || 128ull * perm_stride + 8 <= find_stage_capacity(b->cur_max_len))) {
@@ -2004,7 +2004,10 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
       // bench.py: 7.6e8 symbols 93.6 M reads/s per lane vs 92.3 M cooperative; 1.5e9 symbols 76.7 vs 90.4 M; round 2, before
       // the cooperative finder's LDS diet, had 80 vs 66 M at 1.2e9); from 2^31 the per-lane finder's 32-bit byte offsets
       // no longer reach the table at all.
-      const u64 coop_min = env_cmin ? strtoull(env_cmin, nullptr, 10) : (1ull << 30);
+      // Round 4: with the deep start table and three workgroups per CU the per-lane finder leads again wherever it can reach
+      // (same box, one rank's view of the 4-GPU job, 1.51e9 symbols: 117.6 M reads/s per lane vs 111.0 M cooperative; 2-GPU
+      // job, 7.6e8: 128.6 vs 120.0 M), so the switch sits at its reach: 2^31 symbols.
+      const u64 coop_min = env_cmin ? strtoull(env_cmin, nullptr, 10) : (1ull << 31);
       // the workgroup's 64 reads, staged as 4-bit ranks: one byte range, or by slot under the locality order
       const u64 need = d_perm ? 32ull * perm_stride + 32 : (64ull * b->cur_max_len + 16) / 2 + 16;
       const bool can = fa.two_step && need <= 32768;
