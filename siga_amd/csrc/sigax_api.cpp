@@ -1714,6 +1714,7 @@ struct sigax_batch {
   u64 qhint[4];       // items per sub-batch in the four filter/extract queues in the previous run (~0: none yet)
   bool qhint_lean_off;  // ... measured with lean_off in this state
   bool lean_off;      // see sigax_batch_finish
+  bool fx_heavy;      // the last run's filter/extract launches took longer than its finder launches (sigax_batch_finish)
   unsigned lean_off_runs;
   unsigned nsub_req;  // 0 = automatic
   unsigned find_per_sub;  // finder launches per sub-batch (2 = one per strand's two-step table)
@@ -1772,6 +1773,7 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
   b->nsub = 1;
   b->lean_off = false;
   b->lean_off_runs = 0;
+  b->fx_heavy = false;
   b->qhint[0] = b->qhint[1] = b->qhint[2] = b->qhint[3] = ~0ull;
   b->qhint_lean_off = false;
   b->perm_valid = false;
@@ -1878,9 +1880,15 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   // 3 per CU beside the cooperative finder as before)
   static const char* env_cmin_g = getenv("SIGAX_COOP_MIN_SYMBOLS");
   const bool coop_idx = ix->wide || ix->n_symbols >= (env_cmin_g ? strtoull(env_cmin_g, nullptr, 10) : (1ull << 31));
-  unsigned fast_grid = (unsigned)std::min<u64>(env_fxg ? (u64)atoi(env_fxg) : (coop_idx ? 3u * (unsigned)ix->n_cu : 5u * (unsigned)ix->n_cu / 2u), ((u64)n + 3) / 4);  // two items per wave
+  // ... and 3 per CU again for a batch object whose last run waited for filter/extract rather than for the finder (reads
+  // with sequencing errors: fx_heavy, see sigax_batch_finish).  tools/sweep_env.sh, BASELINE configs[1] shape, 2.5 against 3
+  // per CU: no errors 155.9 / 153.6 M reads/s, 0.03 % substitutions 138.7 / 144.7, 0.1 % 121.7 / 121.9, 0.3 % 93.7 / 98.0,
+  // 1 % 66.7 / 76.7 (profiles/r04_error_rates.txt).
+  const unsigned grid_max = 3u * (unsigned)ix->n_cu;
+  unsigned fast_grid = (unsigned)std::min<u64>(env_fxg ? (u64)atoi(env_fxg) : ((coop_idx || b->fx_heavy) ? grid_max : 5u * (unsigned)ix->n_cu / 2u), ((u64)n + 3) / 4);  // two items per wave
   if (fast_grid == 0) fast_grid = 1;
-  if ((rc = ensure(&b->wpool, (size_t)fast_grid * 4 * fast_pool_entries_per_wave() * SIGAX_ENT_BYTES)) != SIGAX_OK) return rc;
+  // (the pools are sized for the larger grid: a change of mind costs no allocation)
+  if ((rc = ensure(&b->wpool, (size_t)std::max(fast_grid, std::min<unsigned>(grid_max, (unsigned)(((u64)n + 3) / 4))) * 4 * fast_pool_entries_per_wave() * SIGAX_ENT_BYTES)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->work, ((size_t)n + 1) * 4)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->work64, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
   if ((rc = ensure(&b->work64b, (2 * (size_t)n + 2) * 4)) != SIGAX_OK) return rc;
@@ -2272,6 +2280,26 @@ extern "C" int sigax_batch_finish(sigax_batch* b, void* stream, sigax_stats* sta
         }
       } else if (--b->lean_off_runs == 0) {
         b->lean_off = false;
+      }
+    }
+    {
+      // Which kernel did the step wait for?  The launches' own durations (beside each other, as they ran) decide the
+      // residency split of this batch object's next run: the finder's three workgroups per CU leave two and a half
+      // filter/extract workgroups room, which is the better split while the two kernels take about the same time; reads with
+      // sequencing errors make filter/extract the longer one by up to 2x, and it then gets three per CU (enqueue).  With
+      // hysteresis: the ratio itself moves by 0.1 with the split.
+      float tf = 0.f, tx = 0.f, t = 0.f;
+      bool ok = true;
+      for (unsigned i = 0; i < b->nsub && ok; ++i) {
+        ok = hipEventElapsedTime(&t, b->sev[i][SV_F0], b->sev[i][SV_F1]) == hipSuccess;
+        tf += t;
+        ok = ok && hipEventElapsedTime(&t, b->sev[i][SV_X0], b->sev[i][SV_X1]) == hipSuccess;
+        tx += t;
+      }
+      if (!ok) (void)hipGetLastError();
+      else if (tf > 0.f) {
+        if (!b->fx_heavy && tx > 1.12f * tf) b->fx_heavy = true;
+        else if (b->fx_heavy && tx < 0.95f * tf) b->fx_heavy = false;
       }
     }
     b->last.n_extract_errors = ds[DS_EXTRACT_ERRORS];

@@ -8,7 +8,7 @@ export SIGAX_TABLES_SYNC=1
 for spec in "$@"; do
   name=${spec%%:*}; vars=${spec#*:}
   envs=$(echo "$vars" | tr ',' ' ')
-  env $envs timeout -k 10 400 python3 bench.py --cpu-sample 0 --no-e2e --upload-steps 0 $A > $O/$name.json 2> $O/$name.err || { echo "$name FAILED"; tail -3 $O/$name.err; continue; }
+  env $envs timeout -k 10 ${SWEEP_TIMEOUT:-400} python3 bench.py --cpu-sample 0 --no-e2e --upload-steps 0 $A > $O/$name.json 2> $O/$name.err || { echo "$name FAILED"; tail -3 $O/$name.err; continue; }
   python3 - $O/$name.json "$name" "$vars" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
