@@ -106,6 +106,16 @@ def test_sixteen_lane_groups_bit_exact():
     _run_parity({"SIGAX_FX_16": "1", "SIGAX_FORCE_WIDE": "1"}, "hits_and_asqg or deep")
 
 
+def test_filter_extract_grid_does_not_change_results():
+    """A batch object sizes the filter/extract grid by its last run (sigax_batch_finish: three workgroups per CU once
+    filter/extract outlasts the finder, two and a half otherwise): persistent waves draw items from one
+    counter, so any grid gives the same bytes.  One workgroup, and far more workgroups than items' waves, on read sets
+    with substitutions, duplicates and repeats, and on batch objects that run several times."""
+    _run_parity({"SIGAX_FX_GRID": "1"}, None, seeds=(1, 3, 8, 21))
+    _run_parity({"SIGAX_FX_GRID": "4096", "SIGAX_FX_GRID64": "4096"}, None, seeds=(2, 5, 13, 22))
+    _run_parity({"SIGAX_FX_GRID": "3"}, "in_flight or deep_coverage or duplicate")
+
+
 def test_correct_without_the_kmer_prefix_table():
     """`siga correct`'s k-mer lookups start from the interval of their last twelve bases (a table of all 12-mers, built on
     first use); SIGAX_KMER_PREFIX=0 walks every step as the reference does.  Same files either way, 32- and 64-bit positions."""
