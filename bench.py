@@ -91,6 +91,11 @@ def parse_args():
     ap.add_argument("--max-local-reads", type=int, default=0,
                     help="with --emulate-world: run only the first so many reads of rank 0's shard per step (a shard of BASELINE "
                          "configs[4] is 6.25 M reads of 250 bp: more than three batch objects in flight hold beside its index)")
+    ap.add_argument("--shard", default="key", choices=["key", "contiguous"],
+                    help="N > 1: which reads a rank gets.  key (default): a contiguous range of the reads' locality-key order "
+                         "(siga_amd.sharding.locality_keys: minimizer hash, from the sequences alone; computed once per read set, "
+                         "outside the step; the reads keep their ids: sigax_batch_set_device_read_ids); contiguous: a contiguous "
+                         "range of the file, as rounds 1-3 did")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow on fewer GPUs than ranks (edge records gathered via host)")
     ap.add_argument("--reuse-order", action="store_true",
@@ -229,7 +234,12 @@ def bench_overlap(args):
     if args.max_local_reads:
         hi = min(hi, lo + args.max_local_reads)
     have_index = all(os.path.exists(prefix + e) for e in (".bwt", ".rbwt", ".sai", ".rsai"))
-    whole = (rank == 0 and not have_index) or bool(args.error_rate) or (args.cpu_sample > 0 and world == 1)
+    # key-range sharding (N > 1): rank r runs reads order[lo:hi] of the locality-key order instead of reads lo..hi-1 of the
+    # file; rank 0 computes the order once per read set (from the sequences alone; kept beside the index files)
+    by_key = job_world > 1 and args.shard == "key" and not by_pos
+    order_path = prefix + ".keyorder.npy"
+    whole = (rank == 0 and not have_index) or bool(args.error_rate) or (args.cpu_sample > 0 and world == 1) or \
+            (by_key and rank == 0 and not os.path.exists(order_path))
 
     def draw(subset):
         r, _ = fast_reads(G, L, n_total, args.seed, by_position=by_pos, subset=subset)  # uint8 [., L]
@@ -246,9 +256,27 @@ def bench_overlap(args):
             offs_all = np.arange(0, (n_total + 1) * L, L, dtype=np.uint64)
             host.index_build_gpu(reads.reshape(-1), offs_all, prefix, device=dev_index)
         log("reads + index ready in %.1f s (%d reads, %d symbols per strand)" % (time.time() - t0, n_total, n_total * (L + 1)))
+    shard_keys_s = None
+    if by_key and rank == 0 and not os.path.exists(order_path):
+        from siga_amd.sharding import locality_keys, key_order
+        tk = time.time()
+        order = key_order(locality_keys(reads, device=dev)).astype(np.uint32)
+        shard_keys_s = time.time() - tk
+        np.save(order_path + ".tmp.npy", order)
+        os.replace(order_path + ".tmp.npy", order_path)
+        with open(order_path + ".seconds", "w") as f:
+            f.write("%.3f\n" % shard_keys_s)
+        log("locality keys + order of %d reads in %.1f s (once per read set)" % (n_total, shard_keys_s))
     if multi_path:
         dist.barrier()
-    shard = reads[lo:hi] if whole else draw((lo, hi))
+    ids = None
+    if by_key:
+        ids = np.ascontiguousarray(np.load(order_path, mmap_mode="r")[lo:hi]).astype(np.uint32)
+        if shard_keys_s is None and os.path.exists(order_path + ".seconds"):
+            shard_keys_s = float(open(order_path + ".seconds").read())
+        shard = reads[ids] if whole else draw(ids)
+    else:
+        shard = reads[lo:hi] if whole else draw((lo, hi))
     pair = FMIndexPair.load(prefix, device=dev_index)
     # ReadInfo{name,length}: names r<i>; rank of a name under std::string operator<
     pair.set_reads(np.full(n_total, L, dtype=np.uint32), rank_of_r_names(n_total))
@@ -267,6 +295,7 @@ def bench_overlap(args):
     n_local = hi - lo
     d_seqs = torch.from_numpy(np.ascontiguousarray(shard).reshape(-1)).to(dev)
     d_offs = torch.arange(0, (n_local + 1) * L, L, dtype=torch.int64, device=dev)
+    d_ids = torch.from_numpy(ids.view(np.int32)).to(dev) if ids is not None else None
     lib = _lib.lib()
     flags = _lib.SIGAX_IRREDUCIBLE | _lib.SIGAX_RC | _lib.SIGAX_EDGES
     # --depth batches in flight on one index: the library queues every batch's finder launches on one stream and its
@@ -282,6 +311,8 @@ def bench_overlap(args):
         rc = lib.sigax_batch_set_device_reads(bt, d_seqs.data_ptr(), d_offs.data_ptr(), n_local, n_local * L, L)
         assert rc == 0, _lib.last_error()
         assert lib.sigax_batch_set_subbatches(bt, args.subbatches) == 0, _lib.last_error()
+        if d_ids is not None:  # the reads' places in the index's read table stay with the batch object
+            assert lib.sigax_batch_set_device_read_ids(bt, d_ids.data_ptr(), n_local) == 0, _lib.last_error()
         batches.append(bt)
         streams.append(torch.cuda.Stream(device=dev) if depth > 1 else torch.cuda.current_stream(dev))
     batch = batches[0]
@@ -490,7 +521,7 @@ def bench_overlap(args):
         ach_fx = bytes_fx / nsub_step / (fx_ms * 1e-3) / 1e9 if fx_ms > 0 else 0.0
         lines_find = sec_f / 2 if two_step else sec_f  # memory requests: 128-byte lines / 64-byte granules
         glines = lines_find / launches / (find_ms * 1e-3) / 1e9 if find_ms > 0 else 0.0
-        key = "%d/%d/%d/%d" % (n_local, G, L, launches)
+        key = "%d/%d/%d/%d" % (n_local, G, L, launches) + ("/key" if by_key else "")  # (a key-range shard misses the caches less)
         traffic = traffic_entry("k_find/" + key)
         fx_traffic = traffic_entry("k_filter_extract_fast/" + key)
         # What bounds the finder's gathers: the table one launch gathers from (one strand's two-step lines, or both strands'
@@ -523,8 +554,12 @@ def bench_overlap(args):
                                    "the batch its reads anew (what a product batch pays per upload%s is inside the timed region) and "
                                    "ends with the edge records in pinned host memory on rank 0" % (
                                        n_total, L, G, args.seed, args.min_overlap, job_world,
-                                       " (this process: rank 0's shard only)" if job_world != world else "",
+                                       (" by locality-key range (each rank a contiguous slice of the reads' minimizer-key order, ids kept)" if by_key else " by file position" if job_world > 1 else "") +
+                                       (" (this process: rank 0's shard only)" if job_world != world else ""),
                                        ", the locality ordering included," if ri["read_order"] else ""),
+                       "sharding": ({"by": "locality key (siga_amd.sharding.locality_keys)", "keys_and_order_seconds": shard_keys_s,
+                                     "note": "computed from the sequences alone, once per read set, outside the step"} if by_key
+                                    else {"by": "file position"} if job_world > 1 else None),
                        "reads_per_gpu": n_local, "genome_bp": G, "read_len": L, "kernels_sha": kernels_sha(), "edges": total_edges, "blocks_per_read": st["n_blocks"] / max(n_local, 1),
                        "n_occ_min_per_read": (st["n_occ_find"] + st["n_occ_extract"]) / max(n_local, 1),
                        "sectors_per_read": {"find": sec_f / max(n_local, 1), "extract": sec_x / max(n_local, 1)},

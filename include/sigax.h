@@ -201,6 +201,17 @@ int  sigax_batch_upload(sigax_batch*, const char* seqs, const uint64_t* offs, ui
 /* Use reads that already sit in device memory (d_seqs bytes, d_offs u64[n_reads+1]); max_len = longest read. */
 int  sigax_batch_set_device_reads(sigax_batch*, const void* d_seqs, const void* d_offs, uint32_t n_reads,
                                   uint64_t n_bases, uint32_t max_len);
+/* The batch's reads need not be consecutive reads of the indexed set: ids[r] = read r's place in the index's read table
+ * (what an ED record's query field then says; blocks and substring flags do not depend on it).  This is what lets a caller
+ * shard its reads by anything but position in the file -- e.g. by a locality key, so that one GPU's reads cover one part
+ * of the genome deeply instead of all of it thinly (bench.py --gpus N, siga_amd/sharding.py).  The ids stay with the batch
+ * object for every later run until set again; NULL = read_base + r as before.  A run whose reads are not as many as the ids
+ * fails with SIGAX_E_STATE; an id beyond the indexed reads fails the upload (host form) or the run's
+ * sigax_batch_finish (device form) with SIGAX_E_ARG, without touching memory outside the tables.
+ * No counterpart in the reference (one process, reads in file order: src/overlap_builder.cpp:1113-1182 takes the id from
+ * the read's position in the file). */
+int  sigax_batch_upload_read_ids(sigax_batch*, const uint32_t* ids, uint32_t n_reads, void* stream);
+int  sigax_batch_set_device_read_ids(sigax_batch*, const void* d_ids, uint32_t n_reads);
 /* How many sub-batches a run is cut into (0 = automatic).  With more than one, sub-batch i's filter/extract kernels run on
  * an internal stream beside sub-batch i+1's block finder (the first is VALU-bound, the second memory-request-bound). */
 int  sigax_batch_set_subbatches(sigax_batch*, uint32_t n);

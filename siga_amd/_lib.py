@@ -11,6 +11,8 @@ SIGAX_IRREDUCIBLE = 1
 SIGAX_RC = 2
 SIGAX_EDGES = 4
 SIGAX_DUPLICATE = 8
+SIGAX_E_ARG = -1
+SIGAX_E_STATE = -6
 
 BLOCK_DTYPE = np.dtype([
     ("capped0_lo", "<u8"), ("capped0_hi", "<u8"), ("capped1_lo", "<u8"), ("capped1_hi", "<u8"),
@@ -53,7 +55,7 @@ SYMBOLS = [
     "sigax_last_error", "sigax_device_count", "sigax_stream_create", "sigax_stream_destroy", "sigax_index_open", "sigax_index_open_mem", "sigax_index_prepare", "sigax_index_prepare_overlap", "sigax_index_clone", "sigax_index_close",
     "sigax_index_info_get", "sigax_index_set_reads", "sigax_index_check_order", "sigax_occ_batch", "sigax_kmer_count_batch",
     "sigax_correct_batch", "sigax_correct_device", "sigax_overlap_batch", "sigax_result_free", "sigax_batch_create", "sigax_batch_destroy", "sigax_batch_upload",
-    "sigax_batch_set_device_reads", "sigax_batch_set_subbatches", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
+    "sigax_batch_set_device_reads", "sigax_batch_upload_read_ids", "sigax_batch_set_device_read_ids", "sigax_batch_set_subbatches", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
     "sigax_batch_download", "sigax_batch_download_edges", "sigax_batch_size_hint", "sigax_batch_kernel_ms", "sigax_batch_run_info", "sigax_build_strand", "sigax_build_session", "sigax_free",
     "sigax_comm_unique_id", "sigax_comm_create", "sigax_comm_destroy", "sigax_gather_counts", "sigax_gather_edges",
 ]
@@ -100,6 +102,8 @@ def lib():
     L.sigax_batch_destroy.restype = None
     L.sigax_batch_upload.argtypes = [vp, cp, vp, u32, vp]
     L.sigax_batch_set_device_reads.argtypes = [vp, vp, vp, u32, u64, u32]
+    L.sigax_batch_upload_read_ids.argtypes = [vp, vp, u32, vp]
+    L.sigax_batch_set_device_read_ids.argtypes = [vp, vp, u32]
     L.sigax_batch_run.argtypes = [vp, u32, u32, u32, vp]
     L.sigax_batch_finish.argtypes = [vp, vp, C.POINTER(Stats)]
     L.sigax_batch_device_outputs.argtypes = [vp, pvp, pvp, pvp, pvp]

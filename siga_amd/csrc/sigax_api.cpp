@@ -1694,8 +1694,11 @@ struct sigax_batch {
   uint32_t cur_max_len;
   // parameters of the last run (for the regrow-and-rerun loop)
   uint32_t read_base, minov, flags;
+  const uint32_t* d_ids;  // the reads' ids in the index's read table, or NULL: read_base + r (sigax_batch_set_device_read_ids)
+  uint32_t ids_n;         // ... for this many reads
   bool ran;
   // arenas
+  DevBuf ids_own;  // sigax_batch_upload_read_ids
   DevBuf arena, chain_cnt, pool, wpool, work, work64, work64b, work64c, work64d, perm, ord_keys, ord_tmp, occ_side, slow_flag, offs2, item_base, fin, fin_cnt, substring, block_offs, outb, edge_cnt,
       edge_offs, edges, partial, dstat;
   uint32_t cap;
@@ -1728,7 +1731,7 @@ struct sigax_batch {
 extern "C" void sigax_batch_destroy(sigax_batch* b) {
   if (!b) return;
   hipSetDevice(b->ix->device);
-  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->work64c, &b->work64d, &b->perm, &b->ord_keys, &b->ord_tmp, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin,
+  DevBuf* all[] = {&b->ids_own, &b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->work64c, &b->work64d, &b->perm, &b->ord_keys, &b->ord_tmp, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin,
                    &b->fin_cnt, &b->substring, &b->block_offs, &b->outb, &b->edge_cnt, &b->edge_offs, &b->edges,
                    &b->partial, &b->dstat};
   for (DevBuf* d : all)
@@ -1757,6 +1760,8 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
   b->n_bases = 0;
   b->cur_max_len = 0;
   b->read_base = b->minov = b->flags = 0;
+  b->d_ids = nullptr;
+  b->ids_n = 0;
   b->ran = b->finished = false;
   b->cap = 0;
   b->cap_floor = 0;
@@ -1844,6 +1849,25 @@ extern "C" int sigax_batch_set_device_reads(sigax_batch* b, const void* d_seqs, 
   return SIGAX_OK;
 }
 
+extern "C" int sigax_batch_set_device_read_ids(sigax_batch* b, const void* d_ids, uint32_t n_reads) {
+  if (!b) return fail(SIGAX_E_ARG, "NULL batch");
+  b->d_ids = (const uint32_t*)d_ids;
+  b->ids_n = d_ids ? n_reads : 0;
+  b->ran = b->finished = false;
+  return SIGAX_OK;
+}
+
+extern "C" int sigax_batch_upload_read_ids(sigax_batch* b, const uint32_t* ids, uint32_t n_reads, void* stream) {
+  if (!b || (n_reads && !ids)) return fail(SIGAX_E_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(b->ix->device));
+  for (uint32_t i = 0; i < n_reads; ++i)
+    if (ids[i] >= b->ix->n_strings) return fail(SIGAX_E_ARG, "read id %u (entry %u) is beyond the %llu indexed reads", ids[i], i, (unsigned long long)b->ix->n_strings);
+  int rc = ensure(&b->ids_own, ((size_t)n_reads + 1) * 4);
+  if (rc != SIGAX_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(b->ids_own.p, ids, (size_t)n_reads * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return sigax_batch_set_device_read_ids(b, n_reads ? b->ids_own.p : nullptr, n_reads);
+}
+
 static int enqueue(sigax_batch* b, hipStream_t st) {
   sigax_index* ix = b->ix;
   if (ix->fwd_only) return fail(SIGAX_E_STATE, "the index was opened without its reverse strand: overlap runs need <prefix>.rbwt too");
@@ -1860,7 +1884,9 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   const bool edges = (b->flags & SIGAX_EDGES) != 0;
   if (edges && (!ix->d_sai[0] || !ix->d_read_len))
     return fail(SIGAX_E_STATE, "SIGAX_EDGES needs the .sai tables and sigax_index_set_reads()");
-  if (edges && (u64)b->read_base + n > ix->n_strings)
+  if (b->d_ids != nullptr && b->ids_n != n)
+    return fail(SIGAX_E_STATE, "the batch holds read ids for %u reads and %u reads (sigax_batch_set_device_read_ids(NULL) forgets them)", b->ids_n, n);
+  if (edges && b->d_ids == nullptr && (u64)b->read_base + n > ix->n_strings)
     return fail(SIGAX_E_ARG, "read_base + n_reads exceeds the indexed read set");
   b->cap = chain_cap(ix, b->cur_max_len, b->minov, b->cap_floor);
   int rc;
@@ -2155,6 +2181,9 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   oa.wide = ix->wide ? 1u : 0u;
   oa.item_edges = edges ? (uint32_t*)b->edge_cnt.p : nullptr;
   oa.read_base = b->read_base;
+  oa.read_ids = b->d_ids;
+  oa.n_index_reads = (uint32_t)std::min<u64>(ix->n_strings, 0xFFFFFFFFull);
+  oa.bad_ids = dstat + DS_BAD_IDS;
   oa.sai = ix->d_sai[0];
   oa.rsai = ix->d_sai[1];
   oa.n_sai = ix->n_sai;
@@ -2171,6 +2200,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     ea.fin_cnt = (const uint32_t*)b->fin_cnt.p;
     ea.n_items = 2 * (u64)n;
     ea.read_base = b->read_base;
+    ea.read_ids = b->d_ids;
     ea.sai = ix->d_sai[0];
     ea.rsai = ix->d_sai[1];
     ea.n_sai = ix->n_sai;
@@ -2221,6 +2251,9 @@ extern "C" int sigax_batch_finish(sigax_batch* b, void* stream, sigax_stats* sta
       const uint32_t got = (uint32_t)std::min<u64>(ds[DS_MAX_CHAIN], 0x0FFFFFFFull);
       while (got > seen && !b->ix->cap_seen->compare_exchange_weak(seen, got)) {}
     }
+    if (ds[DS_BAD_IDS])
+      return fail(SIGAX_E_ARG, "%llu (read, side) items carry a read id beyond the %llu indexed reads (sigax_batch_set_device_read_ids)",
+                  (unsigned long long)ds[DS_BAD_IDS], (unsigned long long)b->ix->n_strings);
     if (ds[DS_FIND_OVERFLOW]) {
       if (b->cap >= worst_cap(b->cur_max_len, b->minov))
         return fail(SIGAX_E_CAPACITY, "candidate arena overflow (max read length given too small?)");
@@ -2461,7 +2494,7 @@ extern "C" int sigax_batch_run_info(sigax_batch* b, sigax_run_info* out) {
   out->row_direct = f.xmap ? 1u : 0u;
   out->deep_k = b->last_deep_k;
   out->arena_bytes = b->arena.bytes;
-  DevBuf* all[] = {&b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->work64c, &b->work64d, &b->perm,
+  DevBuf* all[] = {&b->ids_own, &b->seqs_own, &b->offs_own, &b->arena, &b->chain_cnt, &b->pool, &b->wpool, &b->work, &b->work64, &b->work64b, &b->work64c, &b->work64d, &b->perm,
                    &b->ord_keys, &b->ord_tmp, &b->occ_side, &b->slow_flag, &b->offs2, &b->item_base, &b->fin, &b->fin_cnt, &b->substring, &b->block_offs,
                    &b->outb, &b->edge_cnt, &b->edge_offs, &b->edges, &b->partial, &b->dstat};
   for (DevBuf* d : all) out->workspace_bytes += d->bytes;

@@ -28,6 +28,7 @@ enum {
   DS_SEC_FIND = DS_W64_BASE + 8,   // distinct 64-byte sectors of the rank tables the finder asked for, step by step
   DS_SEC_EXTRACT,                  // ... filter/extract, round by round
   DS_MAX_CHAIN,                    // most candidate blocks any chain of the run pushed (also when its slots ran out)
+  DS_BAD_IDS,                      // (read, side) items whose read id (sigax_batch_set_read_ids) is beyond the indexed read set
   DS_PROF_BASE = 32,               // 32 diagnostic counters (builds with -DSIGAX_FX_PROFILE only)
   DS_W64B_BASE = 64,               // [DS_W64B_BASE + i], [DS_W64C_BASE + i]: items in the second and third queue between
   DS_W64C_BASE = 72,               // sub-batch i's filter/extract launches
@@ -122,6 +123,11 @@ struct OrderArgs {
   // edge records are counted on the way (per item), unless item_edges is NULL
   uint32_t* item_edges;  // [n_items]
   uint32_t read_base;
+  // the batch's reads in the index's read table: read_base + i, or read_ids[i] (a rank's share of a key-range sharding:
+  // any subset in any order); an id >= n_index_reads makes no edge and is counted in *bad_ids
+  const uint32_t* read_ids;
+  uint32_t n_index_reads;
+  unsigned long long* bad_ids;
   const uint32_t* sai;
   const uint32_t* rsai;
   unsigned long long n_sai;
@@ -136,6 +142,7 @@ struct EdgeArgs {
   const uint32_t* fin_cnt;               // [n_items] its blocks
   unsigned long long n_items;
   uint32_t read_base;
+  const uint32_t* read_ids;  // as in OrderArgs (items of out-of-range ids have no records: k_order_scatter counted none)
   const uint32_t* sai;
   const uint32_t* rsai;
   unsigned long long n_sai;

@@ -3980,9 +3980,15 @@ __global__ __launch_bounds__(256) void k_order_scatter(OrderArgs A) {
   if (w >= A.n_items) return;
   u32 cnt = A.fin_cnt[w];
   u32 kept = 0;
+  u32 q = A.read_base + (u32)(w >> 1);
+  bool known = true;  // the read is one of the index's
+  if (A.read_ids != nullptr) {
+    q = A.read_ids[w >> 1];
+    known = q < A.n_index_reads;
+    if (!known) atomicAdd(A.bad_ids, 1ull);
+  }
   if (cnt) {
     u64 srcb = A.item_base[w], dstb = A.offs2[w];
-    const u32 q = A.read_base + (u32)(w >> 1);
     for (u32 i = 0; i < cnt; ++i) {
       if (srcb + i >= A.fin_cap || dstb + i >= A.out_cap) break;  // only after an overflow, whose results the host discards
       const ulonglong2* s = reinterpret_cast<const ulonglong2*>(A.fin + srcb + i);
@@ -3996,7 +4002,7 @@ __global__ __launch_bounds__(256) void k_order_scatter(OrderArgs A) {
         v2 = s[2]; v3 = s[3];
       }
       d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3; d[4] = v4;
-      if (A.item_edges != nullptr) {
+      if (A.item_edges != nullptr && known) {
         const u32 len = (u32)v4.x, af = (u32)(v4.x >> 32);
         const u32* sa = (af & 2u) ? A.rsai : A.sai;
         for (u64 j = v0.x; j <= v0.y && j < A.n_sai; ++j)
@@ -4019,7 +4025,7 @@ __global__ __launch_bounds__(256) void k_edges_fill(EdgeArgs A) {
   u64 e = A.edge_offs[w];
   if (A.edge_offs[w + 1] == e) return;  // no record from this item (most items: the self-containment blocks)
   const u64 first = A.offs2[w];
-  const u32 q = A.read_base + (u32)(w >> 1);
+  const u32 q = A.read_ids != nullptr ? A.read_ids[w >> 1] : A.read_base + (u32)(w >> 1);
   for (u32 i = 0; i < cnt; ++i) {
     if (first + i >= A.blocks_cap) return;  // only after an overflow, whose results the host discards
     const ulonglong2* s = reinterpret_cast<const ulonglong2*>(A.blocks + first + i);

@@ -80,3 +80,60 @@ def gather_edges(local_edges, group=None, dst=0):
         return torch.cat([bufs[r][: counts[r]] for r in range(world)], dim=0), counts
     dist.gather(padded, gather_list=None, dst=dst, group=group)
     return None, counts
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Key-range sharding: which reads go to which rank
+# ------------------------------------------------------------------------------------------------------------------
+LOCALITY_K = 16  # bases of the minimizer
+
+
+def locality_keys(reads, device=None, chunk=1 << 20):
+    """reads: uint8 array [n, L] of ASCII bases -> int64 array [n] of locality keys, computed from the sequences alone.
+
+    key = (hash of the read's minimizer) << 16 | where the minimizer sits in the read, turned so that it grows with the
+    read's start on the minimizer's strand.  The minimizer is the canonical 16-mer (the smaller of a 16-mer and its reverse
+    complement) with the smallest hash, so a read and the reverse complement of its neighbour on the genome share it.
+    Reads that share a minimizer cover the same 2L-wide stretch of the genome: sorted by key they are neighbours, and a
+    contiguous slice of that order (one rank's share: `key_order` / `shard_range`) covers its part of the genome as deep as
+    the whole read set covers the whole genome -- the backward searches of a rank then walk a fraction of the index's rows
+    (a non-ACGT base counts as 'A' here; the key only decides placement, never a result).  Runs on `device` (a torch
+    device; the reads go through it in chunks)."""
+    import numpy as np
+    n, L = reads.shape
+    k = LOCALITY_K
+    out = np.empty(n, dtype=np.int64)
+    if L < k:
+        out[:] = 0
+        return out
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    lut = torch.zeros(256, dtype=torch.int64, device=dev)
+    for ch, v in ((b"C", 1), (b"G", 2), (b"T", 3), (b"c", 1), (b"g", 2), (b"t", 3)):
+        lut[ch[0]] = v
+    for lo in range(0, n, chunk):
+        r = torch.from_numpy(np.ascontiguousarray(reads[lo:lo + chunk])).to(dev)
+        f = lut[r.long()]          # [m, L] codes, most significant base first in a k-mer
+        g = 3 - f                  # complement; the reverse complement reads it the other way round
+        w = 1
+        while w < k:               # k-mers by doubling: f[i] = f[i] << 2w | f[i + w]; g[i] = g[i] | g[i + w] << 2w
+            f = (f[:, :-w] << (2 * w)) | f[:, w:]
+            g = g[:, :-w] | (g[:, w:] << (2 * w))
+            w *= 2
+        fw = f <= g
+        c = torch.where(fw, f, g)  # canonical 16-mer (32 bits)
+        h = (c * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF   # wraps like uint64 arithmetic, sign bit dropped
+        h = (h >> 31) & 0xFFFFFFFF                             # upper bits of the product: 32-bit hash
+        hm, at = h.min(dim=1)
+        on_fw = fw.gather(1, at[:, None])[:, 0]
+        # the read starts `at` bases before the minimizer on its own strand; seen from the canonical strand a read whose
+        # minimizer was taken from the reverse complement starts L - k - at before it
+        off = torch.where(on_fw, at, (L - k) - at)
+        key = (hm << 16) | ((L - k) - off)   # earlier start on the canonical strand = minimizer further in = smaller key
+        out[lo:lo + r.shape[0]] = key.cpu().numpy()
+    return out
+
+
+def key_order(keys):
+    """stable order of the reads by locality key -> int64 permutation (read ids in key order)"""
+    import numpy as np
+    return np.argsort(keys, kind="stable")

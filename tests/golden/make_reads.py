@@ -84,7 +84,8 @@ def dup_reads():
 def fast_reads(G, L, N, seed, by_position=False, subset=None):
     """numpy generator for BASELINE-sized sets -> (uint8 array [N, L] of ASCII, genome array).  by_position: the same reads
     in genome order instead of random order (a measurement aid: what locality between neighbouring reads would be worth).
-    subset=(lo, hi): only reads lo..hi-1 of the same set (one rank's shard, without materialising the other ranks')."""
+    subset=(lo, hi): only reads lo..hi-1 of the same set (one rank's shard, without materialising the other ranks'); or an
+    index array: those reads, in that order."""
     rng = np.random.default_rng(seed)
     genome = rng.integers(0, 4, size=G, dtype=np.uint8)
     npos = G - L + 1
@@ -99,7 +100,7 @@ def fast_reads(G, L, N, seed, by_position=False, subset=None):
     if by_position:
         keys = np.sort(keys)
     if subset is not None:
-        keys = keys[subset[0]:subset[1]]
+        keys = keys[subset] if isinstance(subset, np.ndarray) else keys[subset[0]:subset[1]]
     pos = (keys >> 1).astype(np.int64)
     strand = (keys & 1).astype(bool)
     codes = np.lib.stride_tricks.sliding_window_view(genome, L)[pos]  # [N, L] copy

@@ -506,3 +506,75 @@ def test_forward_only_index_serves_the_corrector_and_refuses_overlaps(sa, tmp_pa
     assert r.returncode != 0 and "rbwt" in r.stderr
     fwd.close()
     both.close()
+
+
+@pytest.mark.parametrize("name", ["toy", "ragged"])
+def test_reads_in_any_order_under_their_ids(sa, name):
+    """sigax_batch_upload_read_ids / _set_device_read_ids: a batch's reads may be any subset of the indexed reads in any
+    order (one rank's share under key-range sharding, siga_amd/sharding.py).  A shuffled half of the read set, given with its
+    ids: every read's blocks and substring flag are those of the plain run over the whole set, and its edge records are the
+    plain run's records of that query, in the same order.  Ids for another number of reads, and ids beyond the indexed reads,
+    are refused."""
+    import ctypes as C
+    import torch
+    from siga_amd import _lib
+    from siga_amd.overlap import pack_reads, name_ranks
+    fx = fixture(name)
+    pair = _pair(sa, fx)
+    reads = sa.overlap.read_sequences(fx.fa)
+    seqs = [r[2] for r in reads]
+    n = len(seqs)
+    pair.set_reads(np.array([len(s) for s in seqs], dtype=np.uint32), name_ranks([r[0] for r in reads]))
+    L = _lib.lib()
+    flags = _lib.SIGAX_IRREDUCIBLE | _lib.SIGAX_RC | _lib.SIGAX_EDGES
+    offs0, blocks0, sub0, eds0, st0, _ = _run_batch(sa, L, pair, seqs, 45, flags)
+    by_query = {}
+    for e in eds0:
+        by_query.setdefault(int(e["query"]), []).append(e.tobytes())
+    ids = np.random.default_rng(5).permutation(n)[: max(n // 2, 1)].astype(np.uint32)
+    part = [seqs[i] for i in ids]
+    buf, offs = pack_reads(part)
+    bt = C.c_void_p()
+    assert L.sigax_batch_create(pair.handle, len(part), len(buf), max(map(len, part)), C.byref(bt)) == 0, _lib.last_error()
+    try:
+        assert L.sigax_batch_upload(bt, buf, offs.ctypes.data, len(part), None) == 0, _lib.last_error()
+        d_ids = torch.from_numpy(ids.astype(np.int32)).cuda()
+        for form in ("host", "device"):
+            if form == "host":
+                assert L.sigax_batch_upload_read_ids(bt, ids.ctypes.data, len(ids), None) == 0, _lib.last_error()
+            else:
+                assert L.sigax_batch_set_device_read_ids(bt, d_ids.data_ptr(), len(ids)) == 0, _lib.last_error()
+            for rep in range(2):
+                assert L.sigax_batch_run(bt, 12345, 45, flags, None) == 0, _lib.last_error()  # read_base is not looked at
+                stats = _lib.Stats()
+                assert L.sigax_batch_finish(bt, None, C.byref(stats)) == 0, _lib.last_error()
+                o, b, s, e = _batch_download(sa, L, bt)
+                want_e = []
+                for r, q in enumerate(ids):
+                    q = int(q)
+                    assert b[o[r]:o[r + 1]].tobytes() == blocks0[offs0[q]:offs0[q + 1]].tobytes(), (form, r, q)
+                    assert s[r] == sub0[q]
+                    want_e += by_query.get(q, [])
+                assert e.tobytes() == b"".join(want_e), form
+        # ids for another number of reads
+        assert L.sigax_batch_set_device_read_ids(bt, d_ids.data_ptr(), len(ids) + 1) == 0
+        assert L.sigax_batch_run(bt, 0, 45, flags, None) == _lib.SIGAX_E_STATE
+        # an id beyond the indexed reads: the host form refuses it at once, the device form when the run is finished
+        bad = ids.copy()
+        bad[len(bad) // 2] = n
+        assert L.sigax_batch_upload_read_ids(bt, bad.ctypes.data, len(bad), None) == _lib.SIGAX_E_ARG
+        d_bad = torch.from_numpy(bad.astype(np.int32)).cuda()
+        assert L.sigax_batch_set_device_read_ids(bt, d_bad.data_ptr(), len(bad)) == 0
+        assert L.sigax_batch_run(bt, 0, 45, flags, None) == 0, _lib.last_error()
+        assert L.sigax_batch_finish(bt, None, C.byref(_lib.Stats())) == _lib.SIGAX_E_ARG
+        assert "beyond" in _lib.last_error()
+        # forgotten again: consecutive reads from read_base
+        assert L.sigax_batch_set_device_read_ids(bt, None, 0) == 0
+        buf2, offs2 = pack_reads(seqs[: len(part)])
+        assert L.sigax_batch_upload(bt, buf2, offs2.ctypes.data, len(part), None) == 0, _lib.last_error()
+        assert L.sigax_batch_run(bt, 0, 45, flags, None) == 0, _lib.last_error()
+        assert L.sigax_batch_finish(bt, None, C.byref(_lib.Stats())) == 0, _lib.last_error()
+        o, b, s, e = _batch_download(sa, L, bt)
+        assert e.tobytes() == b"".join(x for q in range(len(part)) for x in by_query.get(q, []))
+    finally:
+        L.sigax_batch_destroy(bt)

@@ -1,5 +1,6 @@
 """Two ranks of the REAL path (torch.distributed, gloo; both ranks on the one GPU of the test box): each rank runs its
-contiguous shard of the reads through the HIP kernels with read_base = shard start, the 16-byte edge records are gathered
+contiguous shard of the reads through the HIP kernels with read_base = shard start (the bench rehearsal below: its slice of
+the locality-key order, every read under its own id), the 16-byte edge records are gathered
 to rank 0, and rank 0's ASQG text built from the gathered records is byte for byte the one-GPU ASQG and the oracle's."""
 import os
 import socket
@@ -94,4 +95,10 @@ def test_bench_self_launch_two_ranks_gloo_counts_the_one_rank_edges(tmp_path):
     one = run(["--gpus", "1", "--reads-per-gpu", "40000", "--genome-per-gpu", "200000"])
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == "weak"
     assert two["config"]["edges"] == one["config"]["edges"] > 20000
+    # the ranks' reads were slices of the locality-key order (the default for N > 1; each read under its own id); slices of
+    # the file give the same records
+    assert two["config"]["sharding"]["by"].startswith("locality key") and one["config"]["sharding"] is None
+    assert os.path.exists(str(tmp_path / "job" / "reads.keyorder.npy"))
+    by_file = run(["--gpus", "2", "--backend", "gloo", "--shard", "contiguous", "--reads-per-gpu", "20000", "--genome-per-gpu", "100000"])
+    assert by_file["config"]["sharding"] == {"by": "file position"} and by_file["config"]["edges"] == one["config"]["edges"]
     assert two["config"]["reads_per_gpu"] == 20000 and two["value"] > 0

@@ -68,3 +68,61 @@ def test_gather_edges_gloo_world2():
     assert ok and counts == [5, 12]
     ok2, c2 = q.get(timeout=10)
     assert ok2 and c2 == [0, 0]
+
+
+def _locus_reads(G, L, N, seed):
+    """reads of both strands at known places of a random genome -> (ASCII array [N, L], start of each on the forward strand)"""
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, size=G, dtype=np.uint8)
+    pos = rng.integers(0, G - L + 1, size=N)
+    rc = rng.random(N) < 0.5
+    codes = np.lib.stride_tricks.sliding_window_view(genome, L)[pos]
+    codes[rc] = (3 - codes[rc])[:, ::-1]
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[codes], pos
+
+
+def test_locality_keys_put_neighbours_on_one_rank():
+    """Key-range sharding (bench.py --shard key): the key comes from a read's sequence alone, a read and its reverse
+    complement get the same minimizer, reads next to each other in key order lie next to each other on the genome, and a
+    rank's slice of the order covers a fraction of the genome deeply where a slice of the file covers all of it thinly.
+    Every read is on exactly one rank."""
+    from siga_amd.sharding import key_order, locality_keys
+    G, L, N, W = 100000, 100, 30000, 8
+    reads, pos = _locus_reads(G, L, N, 11)
+    keys = locality_keys(reads, chunk=7000)  # several chunks
+    assert keys.shape == (N,) and keys.dtype == np.int64 and (keys >= 0).all()
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[np.frombuffer(b"ACGT", dtype=np.uint8)] = np.frombuffer(b"TGCA", dtype=np.uint8)
+    krc = locality_keys(comp[reads[:, ::-1]])
+    assert np.array_equal(keys >> 16, krc >> 16)
+    order = key_order(keys)
+    assert np.array_equal(np.sort(order), np.arange(N))
+    near = np.abs(np.diff(pos[order])) < L
+    assert near.mean() > 0.85
+    def covered(ids):
+        c = np.zeros(G + 1, dtype=np.int64)
+        np.add.at(c, pos[ids], 1)
+        np.add.at(c, pos[ids] + L, -1)
+        d = np.cumsum(c)[:G]
+        return (d > 0).mean(), d[d > 0].mean()
+    seen = np.zeros(N, dtype=np.int64)
+    for r in range(W):
+        lo, hi = shard_range(N, r, W)
+        seen[order[lo:hi]] += 1
+        frac_key, depth_key = covered(order[lo:hi])
+        frac_file, depth_file = covered(np.arange(lo, hi))
+        assert frac_key < 0.45 and frac_file > 0.9          # (1/8 of the genome would be perfect)
+        assert depth_key > 2.5 * depth_file
+    assert (seen == 1).all()
+    # shorter than a minimizer: no key, still a valid order
+    assert (locality_keys(reads[:5, :10]) == 0).all()
+
+
+def test_fast_reads_subset_by_ids():
+    from tests.golden.make_reads import fast_reads
+    whole, _ = fast_reads(20000, 100, 3000, 3)
+    ids = np.random.default_rng(1).permutation(3000)[:500].astype(np.uint32)
+    part, _ = fast_reads(20000, 100, 3000, 3, subset=ids)
+    assert np.array_equal(part, whole[ids])
+    part, _ = fast_reads(20000, 100, 3000, 3, subset=(100, 200))
+    assert np.array_equal(part, whole[100:200])

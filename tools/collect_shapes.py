@@ -56,6 +56,8 @@ for shape in ('c3', 'c5'):
     except Exception:
         continue
     key = '%d/%d/%d/%d' % (b['config']['reads_per_gpu'], b['config']['genome_bp'], b['config']['read_len'], b['launches_per_step'])
+    if (b['config'].get('sharding') or {}).get('by', '').startswith('locality'):
+        key += '/key'  # as bench.py names the entry of a key-range shard
     sha = b['config'].get('kernels_sha')
     fx_rd = fx_wr = 0.0
     for k, c in merged.items():
