@@ -508,6 +508,26 @@ def test_forward_only_index_serves_the_corrector_and_refuses_overlaps(sa, tmp_pa
     both.close()
 
 
+class _DeviceWords:
+    """a u32 array in device memory, through the HIP runtime libsigax.so is bound to (dlsym on the library's handle looks
+    through its dependencies: the process may hold a second runtime, PyTorch's own)"""
+
+    def __init__(self, values):
+        import ctypes as C
+        from siga_amd import _lib
+        self.hip = _lib.lib()
+        self.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipFree.argtypes = [C.c_void_p]
+        v = np.ascontiguousarray(values, dtype=np.uint32)
+        self.ptr = C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(self.ptr), max(v.nbytes, 4)) == 0
+        assert self.hip.hipMemcpy(self.ptr, v.ctypes.data, v.nbytes, 1) == 0  # hipMemcpyHostToDevice
+
+    def free(self):
+        self.hip.hipFree(self.ptr)
+
+
 @pytest.mark.parametrize("name", ["toy", "ragged"])
 def test_reads_in_any_order_under_their_ids(sa, name):
     """sigax_batch_upload_read_ids / _set_device_read_ids: a batch's reads may be any subset of the indexed reads in any
@@ -516,7 +536,6 @@ def test_reads_in_any_order_under_their_ids(sa, name):
     plain run's records of that query, in the same order.  Ids for another number of reads, and ids beyond the indexed reads,
     are refused."""
     import ctypes as C
-    import torch
     from siga_amd import _lib
     from siga_amd.overlap import pack_reads, name_ranks
     fx = fixture(name)
@@ -536,14 +555,15 @@ def test_reads_in_any_order_under_their_ids(sa, name):
     buf, offs = pack_reads(part)
     bt = C.c_void_p()
     assert L.sigax_batch_create(pair.handle, len(part), len(buf), max(map(len, part)), C.byref(bt)) == 0, _lib.last_error()
+    d_ids = d_bad = None
     try:
         assert L.sigax_batch_upload(bt, buf, offs.ctypes.data, len(part), None) == 0, _lib.last_error()
-        d_ids = torch.from_numpy(ids.astype(np.int32)).cuda()
+        d_ids = _DeviceWords(ids)
         for form in ("host", "device"):
             if form == "host":
                 assert L.sigax_batch_upload_read_ids(bt, ids.ctypes.data, len(ids), None) == 0, _lib.last_error()
             else:
-                assert L.sigax_batch_set_device_read_ids(bt, d_ids.data_ptr(), len(ids)) == 0, _lib.last_error()
+                assert L.sigax_batch_set_device_read_ids(bt, d_ids.ptr, len(ids)) == 0, _lib.last_error()
             for rep in range(2):
                 assert L.sigax_batch_run(bt, 12345, 45, flags, None) == 0, _lib.last_error()  # read_base is not looked at
                 stats = _lib.Stats()
@@ -557,14 +577,14 @@ def test_reads_in_any_order_under_their_ids(sa, name):
                     want_e += by_query.get(q, [])
                 assert e.tobytes() == b"".join(want_e), form
         # ids for another number of reads
-        assert L.sigax_batch_set_device_read_ids(bt, d_ids.data_ptr(), len(ids) + 1) == 0
+        assert L.sigax_batch_set_device_read_ids(bt, d_ids.ptr, len(ids) + 1) == 0
         assert L.sigax_batch_run(bt, 0, 45, flags, None) == _lib.SIGAX_E_STATE
         # an id beyond the indexed reads: the host form refuses it at once, the device form when the run is finished
         bad = ids.copy()
         bad[len(bad) // 2] = n
         assert L.sigax_batch_upload_read_ids(bt, bad.ctypes.data, len(bad), None) == _lib.SIGAX_E_ARG
-        d_bad = torch.from_numpy(bad.astype(np.int32)).cuda()
-        assert L.sigax_batch_set_device_read_ids(bt, d_bad.data_ptr(), len(bad)) == 0
+        d_bad = _DeviceWords(bad)
+        assert L.sigax_batch_set_device_read_ids(bt, d_bad.ptr, len(bad)) == 0
         assert L.sigax_batch_run(bt, 0, 45, flags, None) == 0, _lib.last_error()
         assert L.sigax_batch_finish(bt, None, C.byref(_lib.Stats())) == _lib.SIGAX_E_ARG
         assert "beyond" in _lib.last_error()
@@ -578,3 +598,6 @@ def test_reads_in_any_order_under_their_ids(sa, name):
         assert e.tobytes() == b"".join(x for q in range(len(part)) for x in by_query.get(q, []))
     finally:
         L.sigax_batch_destroy(bt)
+        for d in (d_ids, d_bad):
+            if d is not None:
+                d.free()
