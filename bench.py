@@ -96,6 +96,9 @@ def parse_args():
                          "(siga_amd.sharding.locality_keys: minimizer hash, from the sequences alone; computed once per read set, "
                          "outside the step; the reads keep their ids: sigax_batch_set_device_read_ids); contiguous: a contiguous "
                          "range of the file, as rounds 1-3 did")
+    ap.add_argument("--key-order", action="store_true",
+                    help="N = 1: hand the batch its reads in locality-key order (the one rank's slice of --shard key is the whole order; "
+                         "ids kept).  Off by default: the headline keeps the file's order")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow on fewer GPUs than ranks (edge records gathered via host)")
     ap.add_argument("--reuse-order", action="store_true",
@@ -236,7 +239,7 @@ def bench_overlap(args):
     have_index = all(os.path.exists(prefix + e) for e in (".bwt", ".rbwt", ".sai", ".rsai"))
     # key-range sharding (N > 1): rank r runs reads order[lo:hi] of the locality-key order instead of reads lo..hi-1 of the
     # file; rank 0 computes the order once per read set (from the sequences alone; kept beside the index files)
-    by_key = job_world > 1 and args.shard == "key" and not by_pos
+    by_key = ((job_world > 1 and args.shard == "key") or args.key_order) and not by_pos
     order_path = prefix + ".keyorder.npy"
     whole = (rank == 0 and not have_index) or bool(args.error_rate) or (args.cpu_sample > 0 and world == 1) or \
             (by_key and rank == 0 and not os.path.exists(order_path))
@@ -554,7 +557,7 @@ def bench_overlap(args):
                                    "the batch its reads anew (what a product batch pays per upload%s is inside the timed region) and "
                                    "ends with the edge records in pinned host memory on rank 0" % (
                                        n_total, L, G, args.seed, args.min_overlap, job_world,
-                                       (" by locality-key range (each rank a contiguous slice of the reads' minimizer-key order, ids kept)" if by_key else " by file position" if job_world > 1 else "") +
+                                       (" -- handed over in locality-key order, ids kept (--key-order)" if by_key and job_world == 1 else " by locality-key range (each rank a contiguous slice of the reads' minimizer-key order, ids kept)" if by_key else " by file position" if job_world > 1 else "") +
                                        (" (this process: rank 0's shard only)" if job_world != world else ""),
                                        ", the locality ordering included," if ri["read_order"] else ""),
                        "sharding": ({"by": "locality key (siga_amd.sharding.locality_keys)", "keys_and_order_seconds": shard_keys_s,
