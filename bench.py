@@ -261,18 +261,31 @@ def bench_overlap(args):
         log("reads + index ready in %.1f s (%d reads, %d symbols per strand)" % (time.time() - t0, n_total, n_total * (L + 1)))
     shard_keys_s = None
     if by_key and rank == 0 and not os.path.exists(order_path):
-        from siga_amd.sharding import locality_keys, key_order
-        tk = time.time()
-        order = key_order(locality_keys(reads, device=dev)).astype(np.uint32)
-        shard_keys_s = time.time() - tk
-        np.save(order_path + ".tmp.npy", order)
-        os.replace(order_path + ".tmp.npy", order_path)
-        with open(order_path + ".seconds", "w") as f:
-            f.write("%.3f\n" % shard_keys_s)
-        log("locality keys + order of %d reads in %.1f s (once per read set)" % (n_total, shard_keys_s))
+        try:
+            from siga_amd.sharding import locality_keys, key_order
+            tk = time.time()
+            order = key_order(locality_keys(reads, device=dev)).astype(np.uint32)
+            shard_keys_s = time.time() - tk
+            np.save(order_path + ".tmp.npy", order)
+            os.replace(order_path + ".tmp.npy", order_path)
+            with open(order_path + ".seconds", "w") as f:
+                f.write("%.3f\n" % shard_keys_s)
+            log("locality keys + order of %d reads in %.1f s (once per read set)" % (n_total, shard_keys_s))
+            del order
+            torch.cuda.empty_cache()
+        except Exception as e:  # the sharding policy must not cost the run: every rank then takes its file range (below)
+            log("locality keys failed (%s: %s); ranks take file ranges" % (type(e).__name__, e))
     if multi_path:
         dist.barrier()
     ids = None
+    if by_key:
+        # every rank looks at the same file: no order (or not this read set's) = file ranges for all of them
+        try:
+            by_key = np.load(order_path, mmap_mode="r").shape == (n_total,)
+        except Exception:
+            by_key = False
+        if not by_key:
+            log("rank %d: no locality-key order for this read set, taking the file range" % rank)
     if by_key:
         ids = np.ascontiguousarray(np.load(order_path, mmap_mode="r")[lo:hi]).astype(np.uint32)
         if shard_keys_s is None and os.path.exists(order_path + ".seconds"):
