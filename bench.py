@@ -93,7 +93,7 @@ def parse_args():
                          "configs[4] is 6.25 M reads of 250 bp: more than three batch objects in flight hold beside its index)")
     ap.add_argument("--shard", default="key", choices=["key", "contiguous"],
                     help="N > 1: which reads a rank gets.  key (default): a contiguous range of the reads' locality-key order "
-                         "(siga_amd.sharding.locality_keys: minimizer hash, from the sequences alone; computed once per read set, "
+                         "(siga_amd.sharding.locality_keys -> sigax_locality_keys: minimizer hash, from the sequences alone; computed once per read set, "
                          "outside the step; the reads keep their ids: sigax_batch_set_device_read_ids); contiguous: a contiguous "
                          "range of the file, as rounds 1-3 did")
     ap.add_argument("--key-order", action="store_true",
@@ -264,7 +264,7 @@ def bench_overlap(args):
         try:
             from siga_amd.sharding import locality_keys, key_order
             tk = time.time()
-            order = key_order(locality_keys(reads, device=dev)).astype(np.uint32)
+            order = key_order(locality_keys(reads, device=dev), device=dev).astype(np.uint32)
             shard_keys_s = time.time() - tk
             np.save(order_path + ".tmp.npy", order)
             os.replace(order_path + ".tmp.npy", order_path)

@@ -212,6 +212,12 @@ int  sigax_batch_set_device_reads(sigax_batch*, const void* d_seqs, const void* 
  * the read's position in the file). */
 int  sigax_batch_upload_read_ids(sigax_batch*, const uint32_t* ids, uint32_t n_reads, void* stream);
 int  sigax_batch_set_device_read_ids(sigax_batch*, const void* d_ids, uint32_t n_reads);
+/* Locality keys of reads in device memory (d_seqs bytes, d_offs u64[n_reads+1]) into d_keys u64[n_reads], queued on `stream`
+ * (a hipStream_t or NULL): key = min over the read's 16-mers of hash(canonical 16-mer) << 16 | start offset (csrc/sigax_keys.hip).
+ * Reads of one stretch of the genome, either strand, get neighbouring keys: a caller that sorts its reads by key and gives each
+ * GPU a contiguous range of that order (with sigax_batch_*_read_ids above) has every GPU walk a part of the index instead of
+ * all of it.  Needs no index.  No counterpart in the reference. */
+int  sigax_locality_keys(int device, const void* d_seqs, const void* d_offs, uint32_t n_reads, void* d_keys, void* stream);
 /* How many sub-batches a run is cut into (0 = automatic).  With more than one, sub-batch i's filter/extract kernels run on
  * an internal stream beside sub-batch i+1's block finder (the first is VALU-bound, the second memory-request-bound). */
 int  sigax_batch_set_subbatches(sigax_batch*, uint32_t n);

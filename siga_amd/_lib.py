@@ -58,6 +58,7 @@ SYMBOLS = [
     "sigax_batch_set_device_reads", "sigax_batch_upload_read_ids", "sigax_batch_set_device_read_ids", "sigax_batch_set_subbatches", "sigax_batch_run", "sigax_batch_finish", "sigax_batch_device_outputs",
     "sigax_batch_download", "sigax_batch_download_edges", "sigax_batch_size_hint", "sigax_batch_kernel_ms", "sigax_batch_run_info", "sigax_build_strand", "sigax_build_session", "sigax_free",
     "sigax_comm_unique_id", "sigax_comm_create", "sigax_comm_destroy", "sigax_gather_counts", "sigax_gather_edges",
+    "sigax_locality_keys",
 ]
 
 _lib = None
@@ -103,6 +104,7 @@ def lib():
     L.sigax_batch_upload.argtypes = [vp, cp, vp, u32, vp]
     L.sigax_batch_set_device_reads.argtypes = [vp, vp, vp, u32, u64, u32]
     L.sigax_batch_upload_read_ids.argtypes = [vp, vp, u32, vp]
+    L.sigax_locality_keys.argtypes = [C.c_int, vp, vp, u32, vp, vp]
     L.sigax_batch_set_device_read_ids.argtypes = [vp, vp, u32]
     L.sigax_batch_run.argtypes = [vp, u32, u32, u32, vp]
     L.sigax_batch_finish.argtypes = [vp, vp, C.POINTER(Stats)]

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libsigax.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["sigax_kernels.hip", "sigax_api.cpp", "sigax_index_build.hip", "sigax_comm.cpp"]
+SOURCES = ["sigax_kernels.hip", "sigax_api.cpp", "sigax_index_build.hip", "sigax_comm.cpp", "sigax_keys.hip"]
 HEADERS = ["sigax_kernels.h", "fm_layout.h", os.path.join(ROOT, "include", "sigax.h")]
 
 

@@ -91,25 +91,51 @@ LOCALITY_K = 16  # bases of the minimizer
 def locality_keys(reads, device=None, chunk=1 << 20):
     """reads: uint8 array [n, L] of ASCII bases -> int64 array [n] of locality keys, computed from the sequences alone.
 
-    key = (hash of the read's minimizer) << 16 | where the minimizer sits in the read, turned so that it grows with the
-    read's start on the minimizer's strand.  The minimizer is the canonical 16-mer (the smaller of a 16-mer and its reverse
-    complement) with the smallest hash, so a read and the reverse complement of its neighbour on the genome share it.
-    Reads that share a minimizer cover the same 2L-wide stretch of the genome: sorted by key they are neighbours, and a
-    contiguous slice of that order (one rank's share: `key_order` / `shard_range`) covers its part of the genome as deep as
-    the whole read set covers the whole genome -- the backward searches of a rank then walk a fraction of the index's rows
-    (a non-ACGT base counts as 'A' here; the key only decides placement, never a result).  Runs on `device` (a torch
-    device; the reads go through it in chunks)."""
+    key = min over the read's 16-mers of  hash(canonical 16-mer) << 16 | (L - 16 - off): the read's minimizer -- the canonical
+    16-mer (the smaller of a 16-mer and its reverse complement) with the smallest hash, so a read and the reverse complement of
+    its neighbour on the genome share it -- above, and below it where the read starts before the minimizer on the canonical
+    strand (off), turned so that an earlier start sorts first.  Reads that share a minimizer cover the same 2L-wide stretch of
+    the genome: sorted by key they are neighbours, and a contiguous slice of that order (one rank's share: `key_order` /
+    `shard_range`) covers its part of the genome as deep as the whole read set covers the whole genome -- the backward searches
+    of a rank then walk a fraction of the index's rows (a non-ACGT base counts as 'A' here; the key only decides placement,
+    never a result).
+
+    On a GPU (`device` a cuda device) the keys come from the library's kernel (sigax_locality_keys, csrc/sigax_keys.hip); on
+    the CPU from the torch restatement below, which the tests hold the kernel against."""
+    import numpy as np
+    n, L = reads.shape
+    out = np.empty(n, dtype=np.int64)
+    if L < LOCALITY_K:
+        out[:] = 0
+        return out
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    if dev.type == "cuda":
+        from . import _lib
+        lib = _lib.lib()
+        d_offs = torch.arange(0, (min(chunk, n) + 1) * L, L, dtype=torch.int64, device=dev)
+        for lo in range(0, n, chunk):
+            m = min(chunk, n - lo)
+            r = torch.from_numpy(np.ascontiguousarray(reads[lo:lo + m]).reshape(-1)).to(dev)
+            k = torch.empty(m, dtype=torch.int64, device=dev)
+            torch.cuda.current_stream(dev).synchronize()  # (the library launches on the default stream)
+            rc = lib.sigax_locality_keys(dev.index or 0, r.data_ptr(), d_offs.data_ptr(), m, k.data_ptr(), None)
+            if rc != 0:
+                raise RuntimeError("sigax_locality_keys: " + _lib.last_error())
+            out[lo:lo + m] = k.cpu().numpy()
+        return out
+    return _locality_keys_torch(reads, dev, chunk)
+
+
+def _locality_keys_torch(reads, dev, chunk=1 << 20):
+    """the restatement of csrc/sigax_keys.hip in torch ops (any device)"""
     import numpy as np
     n, L = reads.shape
     k = LOCALITY_K
     out = np.empty(n, dtype=np.int64)
-    if L < k:
-        out[:] = 0
-        return out
-    dev = torch.device(device) if device is not None else torch.device("cpu")
     lut = torch.zeros(256, dtype=torch.int64, device=dev)
     for ch, v in ((b"C", 1), (b"G", 2), (b"T", 3), (b"c", 1), (b"g", 2), (b"t", 3)):
         lut[ch[0]] = v
+    at = torch.arange(L - k + 1, dtype=torch.int64, device=dev)[None, :]
     for lo in range(0, n, chunk):
         r = torch.from_numpy(np.ascontiguousarray(reads[lo:lo + chunk])).to(dev)
         f = lut[r.long()]          # [m, L] codes, most significant base first in a k-mer
@@ -122,18 +148,18 @@ def locality_keys(reads, device=None, chunk=1 << 20):
         fw = f <= g
         c = torch.where(fw, f, g)  # canonical 16-mer (32 bits)
         h = (c * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF   # wraps like uint64 arithmetic, sign bit dropped
-        h = (h >> 31) & 0xFFFFFFFF                             # upper bits of the product: 32-bit hash
-        hm, at = h.min(dim=1)
-        on_fw = fw.gather(1, at[:, None])[:, 0]
-        # the read starts `at` bases before the minimizer on its own strand; seen from the canonical strand a read whose
-        # minimizer was taken from the reverse complement starts L - k - at before it
-        off = torch.where(on_fw, at, (L - k) - at)
-        key = (hm << 16) | ((L - k) - off)   # earlier start on the canonical strand = minimizer further in = smaller key
+        h = (h >> 31) & 0xFFFFFFFF                             # bits 31..62 of the product: 32-bit hash
+        # the read starts `at` bases before the 16-mer on its own strand; seen from the canonical strand a read whose 16-mer
+        # is the larger one of the pair starts L - k - at before it
+        off = torch.where(fw, at, (L - k) - at)
+        key = ((h << 16) | ((L - k) - off)).min(dim=1).values  # earlier start on the canonical strand = smaller key
         out[lo:lo + r.shape[0]] = key.cpu().numpy()
     return out
 
 
-def key_order(keys):
-    """stable order of the reads by locality key -> int64 permutation (read ids in key order)"""
+def key_order(keys, device=None):
+    """stable order of the reads by locality key -> int64 permutation (read ids in key order); sorted on `device` if given"""
     import numpy as np
+    if device is not None and torch.device(device).type == "cuda":
+        return torch.sort(torch.from_numpy(np.ascontiguousarray(keys)).to(device), stable=True).indices.cpu().numpy()
     return np.argsort(keys, kind="stable")

@@ -126,3 +126,41 @@ def test_fast_reads_subset_by_ids():
     assert np.array_equal(part, whole[ids])
     part, _ = fast_reads(20000, 100, 3000, 3, subset=(100, 200))
     assert np.array_equal(part, whole[100:200])
+
+
+def _key_by_definition(seq):
+    """csrc/sigax_keys.hip's definition, base by base"""
+    k = 16
+    L = len(seq)
+    if L < k:
+        return 0
+    code = {"A": 0, "C": 1, "G": 2, "T": 3, "a": 0, "c": 1, "g": 2, "t": 3}
+    c = [code.get(ch, 0) for ch in seq]
+    best = None
+    for i in range(L - k + 1):
+        f = 0
+        for j in range(k):
+            f = (f << 2) | c[i + j]
+        g = 0
+        for j in range(k):
+            g |= (3 - c[i + j]) << (2 * j)
+        fw = f <= g
+        canon = f if fw else g
+        h = ((canon * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF) >> 31 & 0xFFFFFFFF
+        off = i if fw else (L - k) - i
+        key = (h << 16) | ((L - k) - off)
+        best = key if best is None or key < best else best
+    return best
+
+
+def test_locality_keys_follow_their_definition():
+    """the torch restatement (what the GPU kernel is held against in tests/test_gpu_keys.py) against the definition, base by
+    base: mixed case, non-ACGT bytes, palindromic 16-mers (f == g), reads of exactly 16 bases"""
+    from siga_amd.sharding import locality_keys
+    rng = np.random.default_rng(4)
+    for L in (16, 17, 40, 151):
+        reads = np.frombuffer(b"ACGTacgtNn.", dtype=np.uint8)[rng.choice([0, 1, 2, 3, 0, 1, 2, 3, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10], size=(60, L))]
+        reads[0, :16] = np.frombuffer(b"ACGTACGTACGTACGT", dtype=np.uint8)  # its own reverse complement
+        got = locality_keys(reads, chunk=25)
+        want = [_key_by_definition(bytes(r).decode("latin1")) for r in reads]
+        assert got.tolist() == want, L
