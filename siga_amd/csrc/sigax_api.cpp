@@ -1718,6 +1718,11 @@ struct sigax_batch {
   bool qhint_lean_off;  // ... measured with lean_off in this state
   bool lean_off;      // see sigax_batch_finish
   bool fx_heavy;      // the last run's filter/extract launches took longer than its finder launches (sigax_batch_finish)
+  // which finder between 2^30 and 2^31 symbols (want_coop): 0, 1 = per-lane runs (the second one timed), 2, 3 = cooperative runs
+  // (the second one timed), 4 = decided
+  int coop_tune;
+  float coop_t_lane;
+  bool coop_pick;
   unsigned lean_off_runs;
   unsigned nsub_req;  // 0 = automatic
   unsigned find_per_sub;  // finder launches per sub-batch (2 = one per strand's two-step table)
@@ -1779,6 +1784,9 @@ extern "C" int sigax_batch_create(sigax_index* ix, uint32_t max_reads, uint64_t 
   b->lean_off = false;
   b->lean_off_runs = 0;
   b->fx_heavy = false;
+  b->coop_tune = 0;
+  b->coop_t_lane = 0.f;
+  b->coop_pick = false;
   b->qhint[0] = b->qhint[1] = b->qhint[2] = b->qhint[3] = ~0ull;
   b->qhint_lean_off = false;
   b->perm_valid = false;
@@ -1849,8 +1857,34 @@ extern "C" int sigax_batch_set_device_reads(sigax_batch* b, const void* d_seqs, 
   return SIGAX_OK;
 }
 
+// Cooperative or per-lane finder for this run?  The cooperative one (lines through LDS, eight lanes per line: one address
+// translation) wherever the per-lane finder's 32-bit byte offsets do not reach (2^31 symbols; 64-bit positions); the per-lane
+// one below 2^30 symbols.  In between it depends on what the library cannot see -- how local the batch's reads are: one
+// rank's view of the 4-GPU job of bench.py, 1.51e9 symbols: file-range shard 117.6 M reads/s per lane against 111.0 M
+// cooperative, key-range shard 132-134 M against 138-139 M (profiles/r04_key_sharding.txt) -- so a batch object measures:
+// two runs per lane, two cooperative, the second of each timed (its finder launches' own durations, as they ran), then it
+// keeps the faster.  SIGAX_FIND_COOP / SIGAX_COOP_MIN_SYMBOLS decide statically as before; SIGAX_COOP_TUNE_MIN moves the
+// lower end of the measured range (tests: 0 = every index).
+static bool coop_tunable(const sigax_index* ix) {
+  static const char* env_coop = getenv("SIGAX_FIND_COOP");
+  static const char* env_cmin = getenv("SIGAX_COOP_MIN_SYMBOLS");
+  static const char* env_tmin = getenv("SIGAX_COOP_TUNE_MIN");
+  if (env_coop || env_cmin || ix->wide) return false;
+  const u64 lo = env_tmin ? strtoull(env_tmin, nullptr, 10) : (1ull << 30);
+  return ix->n_symbols >= lo && ix->n_symbols < (1ull << 31);
+}
+static bool want_coop(const sigax_index* ix, const sigax_batch* b) {
+  static const char* env_coop = getenv("SIGAX_FIND_COOP");
+  static const char* env_cmin = getenv("SIGAX_COOP_MIN_SYMBOLS");
+  if (env_coop) return env_coop[0] != '0';
+  if (ix->wide || ix->n_symbols >= (env_cmin ? strtoull(env_cmin, nullptr, 10) : (1ull << 31))) return true;
+  if (!coop_tunable(ix)) return false;
+  return b->coop_tune >= 4 ? b->coop_pick : b->coop_tune >= 2;
+}
+
 extern "C" int sigax_batch_set_device_read_ids(sigax_batch* b, const void* d_ids, uint32_t n_reads) {
   if (!b) return fail(SIGAX_E_ARG, "NULL batch");
+  if ((d_ids != nullptr) != (b->d_ids != nullptr)) b->coop_tune = 0;  // another kind of shard: measure the finders again (want_coop)
   b->d_ids = (const uint32_t*)d_ids;
   b->ids_n = d_ids ? n_reads : 0;
   b->ran = b->finished = false;
@@ -1904,8 +1938,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
   static const char* env_fxg = getenv("SIGAX_FX_GRID");
   // (round 4: 2.5 per CU beside the per-lane finder's three workgroups -- two fit a CU's LDS beside them, the rest queue --;
   // 3 per CU beside the cooperative finder as before)
-  static const char* env_cmin_g = getenv("SIGAX_COOP_MIN_SYMBOLS");
-  const bool coop_idx = ix->wide || ix->n_symbols >= (env_cmin_g ? strtoull(env_cmin_g, nullptr, 10) : (1ull << 31));
+  const bool coop_idx = want_coop(ix, b);
   // ... and 3 per CU again for a batch object whose last run waited for filter/extract rather than for the finder (reads
   // with sequencing errors: fx_heavy, see sigax_batch_finish).  tools/sweep_env.sh, BASELINE configs[1] shape, 2.5 against 3
   // per CU: no errors 155.9 / 153.6 M reads/s, 0.03 % substitutions 138.7 / 144.7, 0.1 % 121.7 / 121.9, 0.3 % 93.7 / 98.0,
@@ -1976,11 +2009,7 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     // keep full: 17 to 40 ms on the batch's chain.  Kept as an option for callers whose batches are deep.
     static const char* env_ord = getenv("SIGAX_READ_ORDER");
     const bool order_on = env_ord != nullptr && env_ord[0] != '0';
-    static const char* env_coop0 = getenv("SIGAX_FIND_COOP");
-    static const char* env_cmin0 = getenv("SIGAX_COOP_MIN_SYMBOLS");
-    const u64 coop_min0 = env_cmin0 ? strtoull(env_cmin0, nullptr, 10) : (1ull << 31);
-    const bool coop_would = (ix->st[0].gran2 && ix->st[1].gran2) && (env_coop0 ? env_coop0[0] != '0' : (ix->wide || ix->n_symbols >= coop_min0)) &&
-                            32ull * perm_stride + 32 <= 32768;
+    const bool coop_would = (ix->st[0].gran2 && ix->st[1].gran2) && want_coop(ix, b) && 32ull * perm_stride + 32 <= 32768;
     if (order_on && n >= 2 && (coop_would || 128ull * perm_stride + 8 <= find_stage_capacity(b->cur_max_len))) {
       if (!b->perm_valid || b->perm_nsub != nsub) {
         HIP_TRY(hipEventRecord(b->ev[EV_ORD0], st));  // behind the upload of the reads
@@ -2032,8 +2061,6 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
     static const char* env_mu = getenv("SIGAX_FIND_MASK_UPPER");  // A/B aid: 0 = ten loads for every lane
     fa.mask_upper = (env_mu && env_mu[0] == '0') ? 0u : 1u;
     {
-      static const char* env_coop = getenv("SIGAX_FIND_COOP");
-      static const char* env_cmin = getenv("SIGAX_COOP_MIN_SYMBOLS");
       // From 2^30 symbols the cooperative finder is the faster one (round 3, one rank's view of the 2- / 4- / 8-GPU jobs of
       // bench.py: 7.6e8 symbols 93.6 M reads/s per lane vs 92.3 M cooperative; 1.5e9 symbols 76.7 vs 90.4 M; round 2, before
       // the cooperative finder's LDS diet, had 80 vs 66 M at 1.2e9); from 2^31 the per-lane finder's 32-bit byte offsets
@@ -2041,11 +2068,10 @@ static int enqueue(sigax_batch* b, hipStream_t st) {
       // Round 4: with the deep start table and three workgroups per CU the per-lane finder leads again wherever it can reach
       // (same box, one rank's view of the 4-GPU job, 1.51e9 symbols: 117.6 M reads/s per lane vs 111.0 M cooperative; 2-GPU
       // job, 7.6e8: 128.6 vs 120.0 M), so the switch sits at its reach: 2^31 symbols.
-      const u64 coop_min = env_cmin ? strtoull(env_cmin, nullptr, 10) : (1ull << 31);
       // the workgroup's 64 reads, staged as 4-bit ranks: one byte range, or by slot under the locality order
       const u64 need = d_perm ? 32ull * perm_stride + 32 : (64ull * b->cur_max_len + 16) / 2 + 16;
       const bool can = fa.two_step && need <= 32768;
-      const bool want = env_coop ? env_coop[0] != '0' : (ix->wide || ix->n_symbols >= coop_min);
+      const bool want = want_coop(ix, b);
       fa.coop = (can && want) ? 1u : 0u;
       fa.coop_stage_bytes = (uint32_t)((need + 15) & ~15ull);
       // measurement aid: cap the grid at this many workgroups per CU (they then walk the tiles).  Not a way to set the
@@ -2333,6 +2359,16 @@ extern "C" int sigax_batch_finish(sigax_batch* b, void* stream, sigax_stats* sta
       else if (tf > 0.f) {
         if (!b->fx_heavy && tx > 1.12f * tf) b->fx_heavy = true;
         else if (b->fx_heavy && tx < 0.95f * tf) b->fx_heavy = false;
+      }
+      if (b->coop_tune < 4 && coop_tunable(b->ix)) {  // want_coop: this run was per lane (0, 1) or cooperative (2, 3)
+        if (!ok || tf <= 0.f) {
+          b->coop_tune = 4;  // no times, no tuning: per lane
+          b->coop_pick = false;
+        } else {
+          if (b->coop_tune == 1) b->coop_t_lane = tf;
+          if (b->coop_tune == 3) b->coop_pick = b->last_coop && tf < b->coop_t_lane;
+          ++b->coop_tune;
+        }
       }
     }
     b->last.n_extract_errors = ds[DS_EXTRACT_ERRORS];

@@ -601,3 +601,41 @@ def test_reads_in_any_order_under_their_ids(sa, name):
         for d in (d_ids, d_bad):
             if d is not None:
                 d.free()
+
+
+def test_finder_choice_measured_by_the_batch_object(sa):
+    """Between 2^30 and 2^31 symbols a batch object times its finder both ways and keeps the faster (sigax_api.cpp:
+    want_coop; run_info.coop says which one a run used): two runs per lane, two cooperative, then the choice -- the same
+    bytes every time.  The fixtures are far below that range: all runs per lane, unless SIGAX_COOP_TUNE_MIN=0 puts them in
+    it (tests/test_gpu_wide.py runs this test that way)."""
+    import ctypes as C
+    from siga_amd import _lib
+    from siga_amd.overlap import pack_reads, name_ranks
+    fx = fixture("rep")
+    pair = _pair(sa, fx)
+    reads = sa.overlap.read_sequences(fx.fa)
+    seqs = [r[2] for r in reads]
+    pair.set_reads(np.array([len(s) for s in seqs], dtype=np.uint32), name_ranks([r[0] for r in reads]))
+    L = _lib.lib()
+    flags = _lib.SIGAX_IRREDUCIBLE | _lib.SIGAX_RC | _lib.SIGAX_EDGES
+    want = _run_batch(sa, L, pair, seqs, 30, flags)
+    buf, offs = pack_reads(seqs)
+    bt = C.c_void_p()
+    assert L.sigax_batch_create(pair.handle, len(seqs), len(buf), max(map(len, seqs)), C.byref(bt)) == 0, _lib.last_error()
+    used = []
+    try:
+        assert L.sigax_batch_upload(bt, buf, offs.ctypes.data, len(seqs), None) == 0, _lib.last_error()
+        for rep in range(7):
+            assert L.sigax_batch_run(bt, 0, 30, flags, None) == 0, _lib.last_error()
+            stats, ri = _lib.Stats(), _lib.RunInfo()
+            assert L.sigax_batch_finish(bt, None, C.byref(stats)) == 0, _lib.last_error()
+            assert L.sigax_batch_run_info(bt, C.byref(ri)) == 0
+            used.append(int(ri.coop))
+            _same_run(_batch_download(sa, L, bt) + (stats.as_dict(), ri.as_dict()), want)
+    finally:
+        L.sigax_batch_destroy(bt)
+    static = any(os.environ.get(k) for k in ("SIGAX_FIND_COOP", "SIGAX_COOP_MIN_SYMBOLS")) or os.environ.get("SIGAX_FORCE_WIDE")
+    if os.environ.get("SIGAX_COOP_TUNE_MIN") == "0" and not static and os.environ.get("SIGAX_TWO_STEP") != "0":
+        assert used[:4] == [0, 0, 1, 1] and used[4] == used[5] == used[6], used
+    elif not static:
+        assert used == [0] * 7, used

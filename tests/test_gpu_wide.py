@@ -116,6 +116,15 @@ def test_filter_extract_grid_does_not_change_results():
     _run_parity({"SIGAX_FX_GRID": "3"}, "in_flight or deep_coverage or duplicate")
 
 
+def test_finder_measured_by_the_batch_object():
+    """SIGAX_COOP_TUNE_MIN=0 puts the small fixtures in the range where a batch object times both finders and keeps the
+    faster (sigax_api.cpp: want_coop): the runs of one batch object go per lane, per lane, cooperative, cooperative, then
+    the choice -- same bytes throughout; batch objects in flight tune side by side; a batch whose reads carry ids starts
+    over."""
+    _run_parity({"SIGAX_COOP_TUNE_MIN": "0"}, "finder_choice or in_flight or any_order or deep_coverage")
+    _run_parity({"SIGAX_COOP_TUNE_MIN": "0", "SIGAX_SUBBATCHES": "3"}, None, seeds=(1, 8, 21))
+
+
 def test_correct_without_the_kmer_prefix_table():
     """`siga correct`'s k-mer lookups start from the interval of their last twelve bases (a table of all 12-mers, built on
     first use); SIGAX_KMER_PREFIX=0 walks every step as the reference does.  Same files either way, 32- and 64-bit positions."""
