@@ -364,26 +364,43 @@ static bool slurp(const std::string& path, FileImage* img) {
 namespace {
 struct ChunkOut {
   std::vector<uint64_t> head_off, seq_len, qual_off;
+  std::vector<uint64_t> seq_off;  // by_ref: where the record's one sequence line starts in the file image
   std::vector<uint32_t> head_len;
   std::vector<char> seqs;
+  bool by_ref = false;    // every record of the chunk has its bases on ONE line: they stay in the file image until the join
+  size_t n_bases = 0;     // bases of the chunk's records (by_ref: nothing was copied; else seqs.size())
   bool stopped = false;   // the reader returned false inside this chunk: nothing after it is read
   bool nameless = false;  // a header with no text: its sequence lines leak into the next record (serial semantics only)
   bool open_empty = false;  // the chunk ends in a named record without sequence
 };
 }  // namespace
 
-// FASTAReader::read over [b, e) of the file image (src/kseq.cpp:187-228); the chunk starts at a header line
-static void parse_fasta_chunk(const char* base, size_t b, size_t e, bool last_chunk, ChunkOut* o) {
+// FASTAReader::read over [b, e) of the file image (src/kseq.cpp:187-228); the chunk starts at a header line.
+// by_ref: the bases are not copied here -- a record's sequence is remembered as a span of the file image, which works as
+// long as every record has its bases on one line (reads: always); returns false at the first record that has not, and the
+// caller parses the chunk again the copying way.  (BASELINE configs[2]'s 20 M reads: the chunk buffers were 3 GB written,
+// read once by the join and unmapped again.)
+static bool parse_fasta_chunk(const char* base, size_t b, size_t e, bool last_chunk, ChunkOut* o, bool by_ref) {
   bool have_name = false;
   uint64_t hoff = 0;
   uint32_t hlen = 0;
-  o->seqs.reserve(o->seqs.size() + (e - b));  // a chunk's bases are fewer than its bytes: no regrowth
+  o->by_ref = by_ref;
+  if (!by_ref) o->seqs.reserve(o->seqs.size() + (e - b));  // a chunk's bases are fewer than its bytes: no regrowth
   size_t seq_start = o->seqs.size();
+  uint64_t cur_off = 0, cur_len = 0;  // by_ref: the open record's sequence line
+  unsigned cur_lines = 0;
   size_t p = b;
+  auto cur_seq = [&]() -> size_t { return by_ref ? (size_t)cur_len : o->seqs.size() - seq_start; };
   auto emit = [&] {
     o->head_off.push_back(hoff);
     o->head_len.push_back(hlen);
-    o->seq_len.push_back(o->seqs.size() - seq_start);
+    o->seq_len.push_back(cur_seq());
+    if (by_ref) {
+      o->seq_off.push_back(cur_off);
+      o->n_bases += cur_len;
+      cur_len = 0;
+      cur_lines = 0;
+    }
     seq_start = o->seqs.size();
   };
   while (p < e) {
@@ -395,26 +412,34 @@ static void parse_fasta_chunk(const char* base, size_t b, size_t e, bool last_ch
     while (le > ls && is_space(base[le - 1])) --le;
     if (ls == le) continue;
     if (base[ls] == '>') {
-      const size_t cur_seq = o->seqs.size() - seq_start;
-      if (cur_seq > 0 && have_name && hlen > 0) {
+      const size_t have = cur_seq();
+      if (have > 0 && have_name && hlen > 0) {
         emit();
       } else if (have_name && hlen > 0) {  // a named record without sequence: the reader gives up here
         o->stopped = true;
-        return;
+        if (!by_ref) o->n_bases = o->seqs.size();
+        return true;
       }
       if (have_name && hlen == 0) o->nameless = true;
       have_name = true;
       hoff = ls + 1;
       hlen = (uint32_t)(le - ls - 1);
+    } else if (by_ref) {
+      if (cur_lines != 0) return false;  // a second sequence line: not a span of the file
+      cur_off = ls;
+      cur_len = le - ls;
+      cur_lines = 1;
     } else {
       o->seqs.insert(o->seqs.end(), base + ls, base + le);
     }
   }
-  const size_t cur_seq = o->seqs.size() - seq_start;
+  const size_t have = cur_seq();
   if (have_name && hlen == 0) o->nameless = true;
-  if (cur_seq > 0 && have_name && hlen > 0) emit();
+  if (have > 0 && have_name && hlen > 0) emit();
   else if (have_name && hlen > 0 && !last_chunk) o->open_empty = true;  // the next header makes the reader give up
-  else if (cur_seq > 0) o->seqs.resize(seq_start);
+  else if (have > 0 && !by_ref) o->seqs.resize(seq_start);
+  if (!by_ref) o->n_bases = o->seqs.size();
+  return true;
 }
 
 // FASTQReader::read (src/kseq.cpp:140-185), serial
@@ -475,6 +500,7 @@ static bool LoadReads(const std::string& path, ReadStore* rs, unsigned nt) {
   if (rs->fastq) {
     outs.resize(1);
     parse_fastq(base, size, &outs[0]);
+    outs[0].n_bases = outs[0].seqs.size();
   } else {
     // chunk starts: the first header line at or after i * size / K
     const size_t K = std::max<size_t>(1, std::min<size_t>((size_t)nt * 4, size >> 16));
@@ -498,15 +524,19 @@ static bool LoadReads(const std::string& path, ReadStore* rs, unsigned nt) {
       if (p < size && p > starts.back()) starts.push_back(p);
     }
     outs.resize(starts.size());
+    static const bool no_ref = getenv("SIGA_LOADER_COPY") != nullptr;  // A/B aid: every chunk the copying way
     parallel_for(starts.size(), nt, [&](size_t i) {
       const size_t e = i + 1 < starts.size() ? starts[i + 1] : size;
-      parse_fasta_chunk(base, starts[i], e, i + 1 == starts.size(), &outs[i]);
+      if (no_ref || !parse_fasta_chunk(base, starts[i], e, i + 1 == starts.size(), &outs[i], true)) {
+        outs[i] = ChunkOut();
+        parse_fasta_chunk(base, starts[i], e, i + 1 == starts.size(), &outs[i], false);
+      }
     });
     bool nameless = false;
     for (auto& o : outs) nameless = nameless || o.nameless;
     if (nameless) {  // state leaks across records: only the serial walk reproduces it
       outs.assign(1, ChunkOut());
-      parse_fasta_chunk(base, 0, size, true, &outs[0]);
+      parse_fasta_chunk(base, 0, size, true, &outs[0], false);
     }
   }
   lap("chunks parsed");
@@ -514,7 +544,7 @@ static bool LoadReads(const std::string& path, ReadStore* rs, unsigned nt) {
   size_t nchunks = 0, n = 0, nb = 0;
   for (; nchunks < outs.size(); ++nchunks) {
     n += outs[nchunks].head_off.size();
-    nb += outs[nchunks].seqs.size();
+    nb += outs[nchunks].n_bases;
     if (outs[nchunks].stopped || outs[nchunks].open_empty) {
       ++nchunks;
       break;
@@ -529,7 +559,7 @@ static bool LoadReads(const std::string& path, ReadStore* rs, unsigned nt) {
   std::vector<size_t> rbase(nchunks + 1, 0), bbase(nchunks + 1, 0);
   for (size_t c = 0; c < nchunks; ++c) {
     rbase[c + 1] = rbase[c] + outs[c].head_off.size();
-    bbase[c + 1] = bbase[c] + outs[c].seqs.size();
+    bbase[c + 1] = bbase[c] + outs[c].n_bases;
   }
   parallel_for(nchunks, nt, [&](size_t c) {
     ChunkOut& o = outs[c];
@@ -543,15 +573,17 @@ static bool LoadReads(const std::string& path, ReadStore* rs, unsigned nt) {
       while (nl < o.head_len[k] && h[nl] != ' ' && h[nl] != '\t') ++nl;  // make_seq_name (src/kseq.cpp:71-79)
       rs->name_len[r] = nl;
       rs->offs[r] = off;
+      if (o.by_ref) memcpy(rs->seqs.data() + off, base + o.seq_off[k], o.seq_len[k]);  // straight from the file image
       off += o.seq_len[k];
       if (rs->fastq) rs->qual_off[r] = o.qual_off[k];
     }
-    if (!o.seqs.empty()) memcpy(rs->seqs.data() + bbase[c], o.seqs.data(), o.seqs.size());
+    if (!o.by_ref && !o.seqs.empty()) memcpy(rs->seqs.data() + bbase[c], o.seqs.data(), o.seqs.size());
     // the chunk's own buffers go back here, on this thread: left to the vector of chunks' destructor they were unmapped
     // one after the other (0.4 s of the 0.97 s BASELINE configs[2]'s reads took to load)
     std::vector<char>().swap(o.seqs);
     std::vector<uint64_t>().swap(o.head_off);
     std::vector<uint64_t>().swap(o.seq_len);
+    std::vector<uint64_t>().swap(o.seq_off);
     std::vector<uint64_t>().swap(o.qual_off);
     std::vector<uint32_t>().swap(o.head_len);
   });

@@ -146,7 +146,9 @@ def test_parallel_loader_equals_record_reader(tmp_path):
     """The chunk-parallel FASTA loader and the serial FASTQ walk of the host library give the records of the
     record-at-a-time reader (src/kseq.cpp:140-228 semantics), quirks included: blank and padded lines, multi-line
     sequences, comments, a named record without sequence (the reader gives up there), a header without text (its
-    sequence leaks into the next record), gz input."""
+    sequence leaks into the next record), gz input.  Files whose records have their bases on one line take the loader's
+    by-reference chunks (bases copied once, from the file image), files with multi-line records the copying ones, a file
+    with both kinds either per chunk (SIGA_LOADER_COPY=1 forces the copying way everywhere)."""
     import gzip
     import random
     rnd = random.Random(4)
@@ -159,8 +161,17 @@ def test_parallel_loader_equals_record_reader(tmp_path):
         s = seq(rnd.choice([30, 70, 151]))
         body = s if i % 3 else s[:20] + "\n  " + s[20:] + "  \n\n"
         big.append(">r%d%s\n%s\n" % (i, " BX:Z:AC CR:i:%d" % i if i % 11 == 0 else ("\tx" if i % 13 == 0 else ""), body))
+    # records with their bases on one line (what reads files are): the chunks' bases stay in the file image until the join
+    one = [">s%d%s\n%s%s\n" % (i, " c=%d" % i if i % 7 == 0 else "", "  " if i % 5 == 0 else "", seq(rnd.choice([25, 100, 150]))) + ("\n" if i % 17 == 0 else "")
+           for i in range(30000)]
     cases = {
         "big.fa": "".join(big),
+        "one.fa": "".join(one),
+        "one_then_many.fa": "".join(one[:15000]) + "".join(big[:15000]),   # chunks of either kind in one file
+        "one_stop.fa": "".join(one[:12345]) + ">empty\n>after\nACGT\n" + "".join(one[12345:]),
+        "one_nameless.fa": "".join(one[:700]) + ">\nAAAA\n>next\nCCCC\n" + "".join(one[700:1500]),
+        "one_tail.fa": "".join(one[:20000]) + ">last",
+        "one_noeol.fa": "".join(one[:9999]) + ">z\nACGTACGT",
         "stop.fa": "".join(big[:20000]) + ">empty\n>after\nACGT\n" + "".join(big[20000:]),
         "nameless.fa": "".join(big[:500]) + ">\nAAAA\n>next\nCCCC\n" + "".join(big[500:900]),
         "spaces.fa": " >x y\n AC GT \n\n\r\n>z\nTT\n",
@@ -181,6 +192,9 @@ def test_parallel_loader_equals_record_reader(tmp_path):
             assert na == nb, (name, na, nb)
             assert open(tmp_path / "a.txt", "rb").read() == open(tmp_path / "b.txt", "rb").read(), name
     assert host.parse_file(str(tmp_path / "stop.fa"), str(tmp_path / "a.txt")) == 20000
+    assert host.parse_file(str(tmp_path / "one.fa"), str(tmp_path / "a.txt")) == 30000
+    assert host.parse_file(str(tmp_path / "one_stop.fa"), str(tmp_path / "a.txt")) == 12345
+    assert host.parse_file(str(tmp_path / "one_noeol.fa"), str(tmp_path / "a.txt")) == 10000
     assert host.parse_file(str(tmp_path / "bad.fq"), str(tmp_path / "a.txt")) == 1
 
 
