@@ -1118,6 +1118,11 @@ extern "C" int sigax_index_open(const char* bwt_path, const char* rbwt_path, con
     });
   };
   std::vector<std::thread> sides;
+  // the HIP runtime comes up (0.2-0.3 s in a fresh process) while the files are read, not after them
+  sides.push_back(std::thread([device] {
+    if (hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr);
+    (void)hipGetLastError();
+  }));
   sides.push_back(side(1, [&] { return read_file(rbwt_path, &rb); }));
   if (have_sai) {
     sides.push_back(side(2, [&] { return load_sai(sai_path, &sai); }));
