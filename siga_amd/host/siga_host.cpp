@@ -1104,6 +1104,28 @@ uint64_t FMIndex::length() const {
 // a sync flush, the blocks are concatenated in order and the CRC-32s are combined (the pigz scheme, without dictionary
 // priming).  Block boundaries depend on the text alone, so the file's bytes do not depend on how many threads, batches
 // or GPUs produced it.
+// Blocks of the stream deflated ahead of their turn (VtAhead below): block J = bytes [J, J + 1) MiB of the text.  state: 0 not
+// there, 1 ready (out/crc hold what deflate_block gives for the block's text), 2 the text has changed since.
+// (a block whose text changes may still be on its way in the thread that deflates ahead: that thread only ever turns a 0 into
+// a 1, so the 2 stays whichever of the two comes first)
+struct SpecBlocks {
+  std::vector<std::string> out;
+  std::vector<uLong> crc;
+  std::unique_ptr<std::atomic<uint8_t>[]> state;
+  size_t n = 0;
+  void resize(size_t k) {
+    out.resize(k);
+    crc.resize(k, 0);
+    state.reset(new std::atomic<uint8_t>[k]);
+    for (size_t i = 0; i < k; ++i) state[i].store(0);
+    n = k;
+  }
+  void made(size_t J) {
+    uint8_t none = 0;
+    state[J].compare_exchange_strong(none, 1);
+  }
+};
+
 class OutFile {
  public:
   explicit OutFile(const std::string& path, unsigned threads = 0) : _f(nullptr), _gz(false), _bad(false), _crc(0), _total(0), _nt(threads) {
@@ -1129,7 +1151,9 @@ class OutFile {
   }
   void write(const std::string& s) { write(s.data(), s.size()); }
   // the concatenation of `parts` goes out next; whole blocks are deflated now (in parallel), the rest waits in _buf
-  void write_parts(const std::vector<std::string>& parts) {
+  // (spec: blocks of this stream that were deflated ahead; the caller vouches that a block in state 1 holds the deflate of
+  // exactly the text that arrives here for it)
+  void write_parts(const std::vector<std::string>& parts, SpecBlocks* spec = nullptr) {
     if (!_f) return;
     if (!_gz) {
       if (!_buf.empty()) put(_buf.data(), _buf.size());
@@ -1164,7 +1188,14 @@ class OutFile {
     if (nfull) {
       std::vector<std::string> outs(nfull);
       std::vector<uLong> crcs(nfull, 0);
+      const size_t first_block = (size_t)(_total / kBlock);
       parallel_for(nfull, _nt, [&](size_t i) {
+        const size_t J = first_block + i;
+        if (spec && J < spec->n && spec->state[J].load() == 1) {
+          outs[i].swap(spec->out[J]);
+          crcs[i] = spec->crc[J];
+          return;
+        }
         const size_t off = i * kBlock, k = (size_t)(std::upper_bound(start.begin(), start.end(), off) - start.begin()) - 1;
         if (off - start[k] + kBlock <= segs[k]->size()) {  // the block lies in one segment: no copy
           deflate_block(segs[k]->data() + (off - start[k]), kBlock, false, &outs[i], &crcs[i]);
@@ -1184,6 +1215,10 @@ class OutFile {
     if (!rest.empty()) gather(nfull * kBlock, rest.size(), &rest[0]);
     _buf.swap(rest);
   }
+  static size_t block_bytes() { return kBlock; }
+  static void deflate_ahead(const char* in, std::string* out, uLong* crc) { deflate_block(in, kBlock, false, out, crc); }
+  bool gz() const { return _gz; }
+  static bool gz_name(const std::string& path) { return path.size() >= 3 && path.compare(path.size() - 3, 3, ".gz") == 0; }
   bool close() {
     if (!_f) return true;
     std::vector<std::string> none;
@@ -1522,6 +1557,182 @@ static void name_ranks(const ReadStore& rs, unsigned nt, std::vector<uint32_t>* 
 // gzip writer; the ED lines follow in hits order from the collected 16-byte edge records.  With --gpus N the index is
 // replicated device to device and batches go to whichever GPU is free: the output does not depend on N.
 // ------------------------------------------------------------------------------------------------------
+// VT lines ahead of the GPU.  A VT line is known from the reads file but for one character, the digit of SS:i: (is the read
+// a substring of another: the device's answer), and in a set that went through `siga rmdup` -- what the extractor asks for,
+// src/overlap_builder.cpp:755-756 -- that digit is 0.  So the text of every VT line is written with SS:i:0 as soon as the
+// reads are parsed, and the 1 MiB blocks of the output stream (fixed offsets of the TEXT, whose length the digit does not
+// change) are deflated, by threads of this object, while the index is still on its way to the GPU and while the batches
+// run.  build() takes the chunks in input order once the batches that cover them are back: a chunk with a substring read
+// is formatted again and the blocks it touches are deflated again by the writer; every other block goes to the file as
+// it is.  The bytes of the file are the ones the in-order path writes (SIGA_NO_VT_AHEAD=1: that path).
+class VtAhead {
+ public:
+  static constexpr size_t kChunk = 4096;  // reads per chunk of text
+  VtAhead(std::shared_ptr<const ReadStore> keep, const ReadStore* reads, unsigned nt, const std::string& header, bool gz)
+      : _keep(std::move(keep)), _reads(*reads), _nt(std::max(1u, nt)), _header(header), _gz(gz), _n(reads->size()) {
+    _nchunks = (_n + kChunk - 1) / kChunk;
+    _text.resize(_nchunks);
+    _off.assign(_nchunks + 1, 0);
+    _off[0] = header.size();
+    // room for the longest text there can be: "VT\t" name "\t" seq "\tSS:i:0" + the three tags (each shorter than the
+    // comment it is cut from, plus its six characters) + "\n"
+    uint64_t bound = header.size();
+    for (size_t i = 0; i < _n; ++i) bound += 3 + 1 + 7 + 1 + 18 + 2 * (uint64_t)_reads.head_len[i] + (_reads.offs[i + 1] - _reads.offs[i]);
+    if (gz) _spec.resize((size_t)(bound / OutFile::block_bytes()) + 1);
+    if (const char* env = getenv("SIGA_VT_AHEAD_BYTES")) _cap = std::max<uint64_t>(strtoull(env, nullptr, 10), 1);
+    _thread = std::thread([this] { run(); });
+  }
+  ~VtAhead() {
+    {
+      std::lock_guard<std::mutex> g(_mu);
+      _stop = true;
+    }
+    _cv.notify_all();
+    if (_thread.joinable()) _thread.join();
+  }
+  VtAhead(const VtAhead&) = delete;
+  VtAhead& operator=(const VtAhead&) = delete;
+  const std::string& header() const { return _header; }
+  bool gz() const { return _gz; }
+  size_t chunks() const { return _nchunks; }
+  // The chunks [from, to) -- formatted, their blocks deflated -- with the substring flags of their reads applied; `parts`
+  // takes their text.  Call with from = the previous call's to.
+  void take(size_t from, size_t to, const uint8_t* substring, std::vector<std::string>* parts) {
+    {
+      std::unique_lock<std::mutex> g(_mu);
+      _want = to;  // (whatever the cap says: these chunks are waited for)
+      _cv.notify_all();
+      _cv.wait(g, [&] { return _done >= to; });
+    }
+    parts->clear();
+    parts->resize(to - from);
+    std::vector<uint8_t> again(to - from, 0);
+    parallel_for(to - from, _nt, [&](size_t k) {
+      const size_t c = from + k, cb = c * kChunk, ce = std::min(_n, cb + kChunk);
+      bool any = false;
+      for (size_t i = cb; substring && i < ce && !any; ++i) any = substring[i] != 0;
+      if (any) {
+        std::string o;
+        o.reserve(_text[c].size());
+        for (size_t i = cb; i < ce; ++i) write_vertex(o, _reads.name(i), _reads.comment(i), _reads.seq(i), substring[i] != 0);
+        _text[c].swap(o);
+        again[k] = 1;
+      }
+      (*parts)[k].swap(_text[c]);
+      std::string().swap(_text[c]);
+    });
+    // the blocks a re-written chunk touches are the writer's to deflate
+    const size_t kb = OutFile::block_bytes();
+    for (size_t k = 0; _gz && k < to - from; ++k) {
+      const size_t c = from + k;
+      if (!again[k] || _off[c + 1] == _off[c]) continue;
+      for (size_t J = (size_t)(_off[c] / kb); J <= (size_t)((_off[c + 1] - 1) / kb) && J < _spec.n; ++J) _spec.state[J].store(2);
+    }
+  }
+  SpecBlocks* blocks() { return _gz ? &_spec : nullptr; }
+  // the text of chunks below `to` has left: the threads may run further ahead
+  void taken(size_t to) {
+    {
+      std::lock_guard<std::mutex> g(_mu);
+      _taken_off = _off[to];
+    }
+    _cv.notify_all();
+  }
+
+ private:
+  void run() {
+    const size_t kb = OutFile::block_bytes();
+    const size_t wave = (size_t)_nt * 8;
+    std::string carry = _header;   // text of the stream from `carry_off` on that is in no finished block yet
+    uint64_t carry_off = 0;        // a multiple of the block size
+    for (size_t c0 = 0; c0 < _nchunks; c0 += wave) {
+      {
+        std::unique_lock<std::mutex> g(_mu);
+        _cv.wait(g, [&] { return _stop || c0 < _want || _off[c0] - _taken_off <= _cap; });
+        if (_stop) return;
+      }
+      const size_t c1 = std::min(_nchunks, c0 + wave);
+      parallel_for(c1 - c0, _nt, [&](size_t k) {
+        const size_t c = c0 + k, cb = c * kChunk, ce = std::min(_n, cb + kChunk);
+        std::string& o = _text[c];
+        o.reserve((size_t)(_reads.offs[ce] - _reads.offs[cb]) + (ce - cb) * 32);
+        for (size_t i = cb; i < ce; ++i) write_vertex(o, _reads.name(i), _reads.comment(i), _reads.seq(i), false);
+      });
+      for (size_t c = c0; c < c1; ++c) _off[c + 1] = _off[c] + _text[c].size();
+      if (_gz) {
+        // pending text = carry + the wave's chunks, from carry_off on
+        std::vector<const std::string*> segs;
+        std::vector<uint64_t> start;
+        uint64_t total = 0;
+        auto add = [&](const std::string* x) {
+          if (x->empty()) return;
+          segs.push_back(x);
+          start.push_back(total);
+          total += x->size();
+        };
+        add(&carry);
+        for (size_t c = c0; c < c1; ++c) add(&_text[c]);
+        auto gather = [&](uint64_t off, size_t len, char* dst) {
+          size_t k = (size_t)(std::upper_bound(start.begin(), start.end(), off) - start.begin()) - 1;
+          while (len) {
+            const size_t in = (size_t)(off - start[k]), take = std::min(len, segs[k]->size() - in);
+            memcpy(dst, segs[k]->data() + in, take);
+            dst += take;
+            off += take;
+            len -= take;
+            ++k;
+          }
+        };
+        const size_t nfull = (size_t)(total / kb), J0 = (size_t)(carry_off / kb);
+        parallel_for(nfull, _nt, [&](size_t i) {
+          if (J0 + i >= _spec.n) return;
+          const uint64_t off = (uint64_t)i * kb;
+          const size_t k = (size_t)(std::upper_bound(start.begin(), start.end(), off) - start.begin()) - 1;
+          if (off - start[k] + kb <= segs[k]->size()) {
+            OutFile::deflate_ahead(segs[k]->data() + (off - start[k]), &_spec.out[J0 + i], &_spec.crc[J0 + i]);
+          } else {
+            std::string tmp(kb, '\0');
+            gather(off, kb, &tmp[0]);
+            OutFile::deflate_ahead(tmp.data(), &_spec.out[J0 + i], &_spec.crc[J0 + i]);
+          }
+          _spec.made(J0 + i);
+        });
+        std::string rest((size_t)(total - (uint64_t)nfull * kb), '\0');
+        if (!rest.empty()) gather((uint64_t)nfull * kb, rest.size(), &rest[0]);
+        carry.swap(rest);
+        carry_off += (uint64_t)nfull * kb;
+      }
+      {
+        std::lock_guard<std::mutex> g(_mu);
+        _done = c1;
+      }
+      _cv.notify_all();
+    }
+  }
+
+  std::shared_ptr<const ReadStore> _keep;
+  const ReadStore& _reads;
+  unsigned _nt;
+  std::string _header;
+  bool _gz;
+  size_t _n, _nchunks = 0;
+  std::vector<std::string> _text;
+  std::vector<uint64_t> _off;  // _off[c]: where chunk c starts in the stream (the header first)
+  SpecBlocks _spec;
+  uint64_t _cap = (uint64_t)8 << 30;  // text held ahead of the writer at most (SIGA_VT_AHEAD_BYTES)
+  std::mutex _mu;
+  std::condition_variable _cv;
+  size_t _done = 0, _want = 0;
+  uint64_t _taken_off = 0;
+  bool _stop = false;
+  std::thread _thread;
+};
+
+static std::string asqg_header(size_t minOverlap) {
+  // src/overlap_builder.cpp:428-437 (the IN tag is never written: :494-495)
+  return "HT\tVN:i:1\tOL:i:" + std::to_string((int)minOverlap) + "\tCN:i:1\n";
+}
+
 namespace {
 struct BatchOut {
   std::vector<uint8_t> substring;
@@ -1550,15 +1761,21 @@ struct sigah::OverlapBuilder::Preloaded {
   ReadStore reads;
   std::vector<uint32_t> lengths, ranks;
   bool ok = false;
+  std::unique_ptr<VtAhead> ahead;  // (after `reads`: gone before them)
 };
 namespace sigah {
-void OverlapBuilder::preload(const std::string& input, size_t threads) const {
+static bool vt_ahead_wanted() { return getenv("SIGA_NO_VT_AHEAD") == nullptr; }
+
+void OverlapBuilder::preload(const std::string& input, size_t threads, long minOverlap, const std::string& output) const {
   const unsigned nt = host_threads(threads);
   auto p = std::make_shared<Preloaded>();
   p->path = input;
   PhaseTimer pt;
   p->ok = LoadReads(input, &p->reads, nt);
   pt.lap("  reads parsed");
+  // the VT lines start now, beside the name ranks and the index on its way to the GPU
+  if (p->ok && minOverlap >= 0 && !output.empty() && vt_ahead_wanted())
+    p->ahead.reset(new VtAhead(nullptr, &p->reads, nt, asqg_header((size_t)minOverlap), OutFile::gz_name(output)));
   if (p->ok) name_ranks(p->reads, nt, &p->lengths, &p->ranks);
   pt.lap("  names ranked");
   _pre = p;
@@ -1608,9 +1825,14 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
     _error = "Failed to create ASQG " + output;
     return false;
   }
-  // header: src/overlap_builder.cpp:428-437 (the IN tag is never written: :494-495)
-  out.write("HT\tVN:i:1\tOL:i:" + std::to_string((int)minOverlap) + "\tCN:i:1\n");
+  const std::string header = asqg_header(minOverlap);
+  out.write(header);
   const size_t n = reads.size();
+  // the VT lines ahead of the batches (started by preload() when it knew the header; from here otherwise)
+  std::unique_ptr<VtAhead> ahead = std::move(pre->ahead);
+  if (ahead && (ahead->header() != header || ahead->gz() != out.gz())) ahead.reset();
+  if (!ahead && vt_ahead_wanted() && n > 0) ahead.reset(new VtAhead(nullptr, &reads, nt, header, out.gz()));
+  if (!vt_ahead_wanted()) ahead.reset();
   uint32_t maxLen = 0;
   for (uint32_t l : pre->lengths) maxLen = std::max(maxLen, l);
   if (n > 0 && sigax_index_set_reads(_fmi->handle(), pre->lengths.data(), pre->ranks.data(), n) != SIGAX_OK) {
@@ -1757,6 +1979,9 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
     format_edge_text(reads, read_len, e, cnt, nt, max_name, ed_chunk, parts);
   };
   const size_t vt_chunk = 4096;
+  std::vector<uint8_t> sub_all;  // (VT lines ahead) the substring flags of the reads whose chunk is not out yet
+  size_t ahead_from = 0;
+  if (ahead) sub_all.assign(n, 0);
   for (size_t b = 0; b < nbatch; ++b) {
     BatchOut r;
     {
@@ -1767,16 +1992,31 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
       pl.out[b].edges = nullptr;  // owned by `edges` from here on
     }
     const size_t lo = b * per, cnt = std::min(per, n - lo);
-    std::vector<std::string> parts((cnt + vt_chunk - 1) / vt_chunk);
     const auto tv0 = std::chrono::steady_clock::now();
-    parallel_for(parts.size(), nt, [&](size_t c) {
-      const size_t cb = c * vt_chunk, ce = std::min(cnt, cb + vt_chunk);
-      std::string& o = parts[c];
-      o.reserve((ce - cb) * (maxLen + 32));
-      for (size_t i = cb; i < ce; ++i) write_vertex(o, reads.name(lo + i), reads.comment(lo + i), reads.seq(lo + i), r.substring[i] != 0);
-    });
-    const auto tv1 = std::chrono::steady_clock::now();
-    out.write_parts(parts);
+    auto tv1 = tv0;
+    if (ahead) {
+      // every chunk of text whose reads are all back (the chunks do not know about batches)
+      memcpy(sub_all.data() + lo, r.substring.data(), cnt);
+      const size_t to = lo + cnt == n ? ahead->chunks() : (lo + cnt) / VtAhead::kChunk;
+      if (to > ahead_from) {
+        std::vector<std::string> parts;
+        ahead->take(ahead_from, to, sub_all.data(), &parts);
+        tv1 = std::chrono::steady_clock::now();
+        out.write_parts(parts, ahead->blocks());
+        ahead->taken(to);
+        ahead_from = to;
+      }
+    } else {
+      std::vector<std::string> parts((cnt + vt_chunk - 1) / vt_chunk);
+      parallel_for(parts.size(), nt, [&](size_t c) {
+        const size_t cb = c * vt_chunk, ce = std::min(cnt, cb + vt_chunk);
+        std::string& o = parts[c];
+        o.reserve((ce - cb) * (maxLen + 32));
+        for (size_t i = cb; i < ce; ++i) write_vertex(o, reads.name(lo + i), reads.comment(lo + i), reads.seq(lo + i), r.substring[i] != 0);
+      });
+      tv1 = std::chrono::steady_clock::now();
+      out.write_parts(parts);
+    }
     if (pt.on) fprintf(stderr, "[siga]   batch %zu: VT text %.3f s, deflate + write %.3f s\n", b, std::chrono::duration<double>(tv1 - tv0).count(),
                        std::chrono::duration<double>(std::chrono::steady_clock::now() - tv1).count());
     // the reference's progress line (OverlapPostProcess, src/overlap_builder.cpp:319-321: every threads x batch reads)
@@ -1820,6 +2060,7 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
     return false;
   }
   pt.lap("ED lines + close");
+  if (_keep_reads) _pre = pre;
   return true;
 }
 
@@ -2240,19 +2481,39 @@ int64_t sigah_format_asqg(const char* path, const uint8_t* substring, const siga
     if (edges[i].query >= rs.size() || edges[i].target >= rs.size()) return -1;
   sigah::OutFile out(out_path, nt);
   if (!out.ok()) return -1;
-  out.write("HT\tVN:i:1\tOL:i:" + std::to_string((int)min_overlap) + "\tCN:i:1\n");
+  const std::string header = sigah::asqg_header((size_t)min_overlap);
+  out.write(header);
   uint32_t maxLen = 0, max_name = 0;
   for (uint32_t l : lengths) maxLen = std::max(maxLen, l);
   for (uint32_t l : rs.name_len) max_name = std::max(max_name, l);
-  const size_t vt_chunk = 4096;
-  std::vector<std::string> parts((rs.size() + vt_chunk - 1) / vt_chunk);
-  sigah::parallel_for(parts.size(), nt, [&](size_t c) {
-    const size_t cb = c * vt_chunk, ce = std::min(rs.size(), cb + vt_chunk);
-    std::string& o = parts[c];
-    o.reserve((ce - cb) * (maxLen + 32));
-    for (size_t i = cb; i < ce; ++i) sigah::write_vertex(o, rs.name(i), rs.comment(i), rs.seq(i), substring && substring[i] != 0);
-  });
-  out.write_parts(parts);
+  if (sigah::vt_ahead_wanted() && rs.size() > 0) {
+    // the way build() takes them: in pieces, as if batches of SIGA_BATCH_READS reads came back one by one
+    sigah::VtAhead ahead(nullptr, &rs, nt, header, out.gz());
+    const char* env = getenv("SIGA_BATCH_READS");
+    const size_t per = env ? std::max<size_t>(strtoull(env, nullptr, 10), 1) : rs.size();
+    size_t from = 0;
+    for (size_t hi = std::min(per, rs.size());; hi = std::min(hi + per, rs.size())) {
+      const size_t to = hi == rs.size() ? ahead.chunks() : hi / sigah::VtAhead::kChunk;
+      if (to > from) {
+        std::vector<std::string> parts;
+        ahead.take(from, to, substring, &parts);
+        out.write_parts(parts, ahead.blocks());
+        ahead.taken(to);
+        from = to;
+      }
+      if (hi == rs.size()) break;
+    }
+  } else {
+    const size_t vt_chunk = 4096;
+    std::vector<std::string> parts((rs.size() + vt_chunk - 1) / vt_chunk);
+    sigah::parallel_for(parts.size(), nt, [&](size_t c) {
+      const size_t cb = c * vt_chunk, ce = std::min(rs.size(), cb + vt_chunk);
+      std::string& o = parts[c];
+      o.reserve((ce - cb) * (maxLen + 32));
+      for (size_t i = cb; i < ce; ++i) sigah::write_vertex(o, rs.name(i), rs.comment(i), rs.seq(i), substring && substring[i] != 0);
+    });
+    out.write_parts(parts);
+  }
   std::vector<std::string> ed;
   sigah::format_edge_text(rs, lengths.data(), edges, n_edges, nt, max_name, 1000, &ed);
   out.write_parts(ed);

@@ -90,9 +90,11 @@ class OverlapBuilder {
       : _fmi(fmi), _prefix(prefix), _irreducible(irreducible), _rc(rc), _gpus(1) {}
   // reads shard over `n` GPUs of the node, starting at the index's device; the index is replicated device to device
   void setGPUs(int n) { _gpus = n < 1 ? 1 : n; }
+  // build() leaves the parsed reads with the builder instead of unmapping them (a CLI about to exit: its pages go with the process)
+  void keepReads(bool on) { _keep_reads = on; }
   // parse `input` and rank its names now (host threads only), e.g. while FMIndex::load is busy on another thread;
   // the next build() of the same file uses the result
-  void preload(const std::string& input, size_t threads = 1) const;
+  void preload(const std::string& input, size_t threads = 1, long minOverlap = -1, const std::string& output = std::string()) const;
 
   // HT, VT (input order), ED (hits order) to `output` (gz when the name ends with .gz).  `threads` is accepted for
   // signature compatibility (the GPU replaces the OpenMP loop); `batch` = reads per device batch.
@@ -116,6 +118,7 @@ class OverlapBuilder {
   mutable std::string _error;
   struct Preloaded;
   mutable std::shared_ptr<Preloaded> _pre;
+  bool _keep_reads = false;
 };
 
 // src/correct_processor.h:25-42 (k-mer algorithm only; the reference's "overlap" algorithm is an empty stub)

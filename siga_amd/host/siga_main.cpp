@@ -218,9 +218,12 @@ static int run_overlap(int argc, char** argv) {
   if (help || argc - optind != 1) return overlap_help();
   std::string input = argv[optind];
   if (prefix.empty()) prefix = sigah::Utils::stem(input);
-  sigah::FMIndex fmi;
-  sigah::OverlapBuilder builder(&fmi, prefix, !exhaustive, !norc);
+  // (not destroyed: the process ends when this command returns, and handing tens of GB of tables back to the driver one
+  // hipFree at a time was 0.2 s of a 2 s run at BASELINE configs[2])
+  sigah::FMIndex& fmi = *new sigah::FMIndex;
+  sigah::OverlapBuilder& builder = *new sigah::OverlapBuilder(&fmi, prefix, !exhaustive, !norc);
   builder.setGPUs(gpus);
+  builder.keepReads(true);
   const auto t_load = std::chrono::steady_clock::now();
   // the index goes to the GPU while the host threads parse the reads
   bool loaded = false;
@@ -229,7 +232,7 @@ static int run_overlap(int argc, char** argv) {
     loaded = sigah::FMIndex::load(prefix, fmi, device);
     if (!loaded) load_error = sigax_last_error();
   });
-  builder.preload(input, threads);
+  builder.preload(input, threads, (long)minOverlap, prefix + ".asqg.gz");
   loader.join();
   if (!loaded) {
     fprintf(stderr, "Failed to load FMIndex from %s: %s\n", input.c_str(), load_error.c_str());

@@ -481,3 +481,44 @@ def test_asqg_text_formatters_without_a_gpu(tmp_path, gz):
     got = (gzip.open(out, "rb") if gz else open(out, "rb")).read().decode("latin-1")
     want = format_asqg(reads, {"substring": sub, "edges": ed}, 45)
     assert got == want
+
+
+@pytest.mark.parametrize("threads,cap", [(1, None), (3, "1")])
+def test_vt_lines_ahead_give_the_in_order_file(tmp_path, threads, cap, monkeypatch):
+    """VT lines ahead of the batches (siga_host.cpp, VtAhead: text with SS:i:0 and its 1 MiB deflate blocks made before the
+    substring flags are known) against the in-order path (SIGA_NO_VT_AHEAD=1) and the Python mirror: the .asqg.gz files are
+    the same BYTES -- with clean stretches (blocks used as they are), stretches with substring reads (chunks formatted
+    again, their blocks deflated by the writer), text taken in pieces that do not line up with the chunks, several waves with
+    a carried tail, and a cap that keeps the threads one wave ahead of the writer."""
+    import gzip
+    from siga_amd import host
+    from siga_amd.overlap import EDGE_DTYPE, format_asqg, read_sequences
+    rng = np.random.default_rng(11)
+    n = 90000
+    codes = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, 150))]
+    lens = rng.integers(100, 151, size=n)
+    fa = str(tmp_path / "r.fa")
+    with open(fa, "wb") as f:
+        f.write(b"".join(b">r%d%s\n%s\n" % (i, b" CR:i:7" if i % 1000 == 0 else b"", codes[i, :lens[i]].tobytes()) for i in range(n)))
+    sub = np.zeros(n, dtype=np.uint8)
+    sub[[5, 4095, 4096, 30000, 30001, 61439, 89999]] = 1  # chunks 0, 1, 7, 14 and the last; the others stay as made ahead
+    ed = np.zeros(3, dtype=EDGE_DTYPE)
+    ed[:] = [(0, 1, 50, 0), (2, 3, 60, 1), (n - 1, 0, 45, 2)]
+    monkeypatch.setenv("SIGA_BATCH_READS", "7001")
+    if cap:
+        monkeypatch.setenv("SIGA_VT_AHEAD_BYTES", cap)
+    ahead = str(tmp_path / "a.asqg.gz")
+    assert host.format_asqg(fa, sub, ed, 45, ahead, threads=threads) == n
+    monkeypatch.setenv("SIGA_NO_VT_AHEAD", "1")
+    plain = str(tmp_path / "p.asqg.gz")
+    assert host.format_asqg(fa, sub, ed, 45, plain, threads=threads) == n
+    a, p = open(ahead, "rb").read(), open(plain, "rb").read()
+    assert a == p and len(a) > 1 << 20
+    text = gzip.decompress(a).decode("latin-1")
+    assert text.count("SS:i:1") == 7 and len(text) > 12 << 20
+    assert text == format_asqg(read_sequences(fa), {"substring": sub, "edges": ed}, 45)
+    # a file without .gz: the text alone is made ahead
+    monkeypatch.delenv("SIGA_NO_VT_AHEAD")
+    raw = str(tmp_path / "a.asqg")
+    assert host.format_asqg(fa, sub, ed, 45, raw, threads=threads) == n
+    assert open(raw, "rb").read().decode("latin-1") == text
