@@ -15,6 +15,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -1206,7 +1207,7 @@ class OutFile {
         deflate_block(tmp.data(), kBlock, false, &outs[i], &crcs[i]);
       });
       for (size_t i = 0; i < nfull; ++i) {
-        put(outs[i].data(), outs[i].size());
+        put_owned(std::move(outs[i]));
         _crc = crc32_combine(_crc, crcs[i], (z_off_t)kBlock);
       }
       _total += nfull * kBlock;
@@ -1236,6 +1237,7 @@ class OutFile {
       for (int i = 0; i < 4; ++i) { tail[i] = (unsigned char)(c >> (8 * i)); tail[4 + i] = (unsigned char)(n >> (8 * i)); }
       put(tail, 8);
     }
+    finish_writes();
     // a short write (disk full, I/O error) leaves the stream's error flag set while fclose may still return 0
     bool ok = !_bad && ferror(_f) == 0;
     ok = fclose(_f) == 0 && ok;
@@ -1281,11 +1283,67 @@ class OutFile {
     out->resize(out->size() - z.avail_out);
     deflateEnd(&z);
   }
+  // The bytes go to the file from a thread of their own (1.2 GB of deflate blocks at BASELINE configs[2]: 0.26 s of
+  // fwrite that the thread formatting the next batch's lines used to spend between two batches); at most 1 GiB waits.
+  // SIGA_SYNC_WRITE=1: written by the caller.
   void put(const void* p, size_t n) {
-    if (n && fwrite(p, 1, n, _f) != n) _bad = true;
+    if (!n) return;
+    if (!_async) {
+      if (fwrite(p, 1, n, _f) != n) _bad = true;
+      return;
+    }
+    put_owned(std::string((const char*)p, n));
+  }
+  void put_owned(std::string&& s) {
+    if (s.empty()) return;
+    if (!_async) {
+      if (fwrite(s.data(), 1, s.size(), _f) != s.size()) _bad = true;
+      return;
+    }
+    std::unique_lock<std::mutex> g(_wmu);
+    if (!_wt.joinable()) _wt = std::thread([this] { drain(); });
+    _wcv.wait(g, [&] { return _wq_bytes <= ((size_t)1 << 30); });
+    _wq_bytes += s.size();
+    _wq.push_back(std::move(s));
+    _wcv.notify_all();
+  }
+  void drain() {
+    std::unique_lock<std::mutex> g(_wmu);
+    for (;;) {
+      _wcv.wait(g, [&] { return !_wq.empty() || _wdone; });
+      if (_wq.empty()) return;
+      std::deque<std::string> mine;
+      mine.swap(_wq);
+      g.unlock();
+      size_t bytes = 0;
+      for (const std::string& x : mine) {
+        if (!_bad && fwrite(x.data(), 1, x.size(), _f) != x.size()) _bad = true;
+        bytes += x.size();
+      }
+      mine.clear();
+      g.lock();
+      _wq_bytes -= bytes;
+      _wcv.notify_all();
+    }
+  }
+  void finish_writes() {
+    {
+      std::lock_guard<std::mutex> g(_wmu);
+      _wdone = true;
+    }
+    _wcv.notify_all();
+    if (_wt.joinable()) _wt.join();
   }
   FILE* _f;
-  bool _gz, _bad;
+  bool _gz;
+  std::atomic<bool> _bad;
+  bool _async = getenv("SIGA_SYNC_WRITE") == nullptr;
+  std::thread _wt;
+  std::mutex _wmu;
+  std::condition_variable _wcv;
+  std::deque<std::string> _wq;
+  size_t _wq_bytes = 0;
+  bool _wdone = false;
   uLong _crc;
   uint64_t _total;
   unsigned _nt;
@@ -1564,7 +1622,7 @@ static void name_ranks(const ReadStore& rs, unsigned nt, std::vector<uint32_t>* 
 // change) are deflated, by threads of this object, while the index is still on its way to the GPU and while the batches
 // run.  build() takes the chunks in input order once the batches that cover them are back: a chunk with a substring read
 // is formatted again and the blocks it touches are deflated again by the writer; every other block goes to the file as
-// it is.  The bytes of the file are the ones the in-order path writes (SIGA_NO_VT_AHEAD=1: that path).
+// it is.  The bytes of the file are the ones the in-order path writes.  An option (SIGA_VT_AHEAD=1), see vt_ahead_wanted().
 class VtAhead {
  public:
   static constexpr size_t kChunk = 4096;  // reads per chunk of text
@@ -1719,7 +1777,7 @@ class VtAhead {
   std::vector<std::string> _text;
   std::vector<uint64_t> _off;  // _off[c]: where chunk c starts in the stream (the header first)
   SpecBlocks _spec;
-  uint64_t _cap = (uint64_t)8 << 30;  // text held ahead of the writer at most (SIGA_VT_AHEAD_BYTES)
+  uint64_t _cap = (uint64_t)3 << 29;  // text held ahead of the writer at most (SIGA_VT_AHEAD_BYTES)
   std::mutex _mu;
   std::condition_variable _cv;
   size_t _done = 0, _want = 0;
@@ -1764,7 +1822,12 @@ struct sigah::OverlapBuilder::Preloaded {
   std::unique_ptr<VtAhead> ahead;  // (after `reads`: gone before them)
 };
 namespace sigah {
-static bool vt_ahead_wanted() { return getenv("SIGA_NO_VT_AHEAD") == nullptr; }
+// Off unless asked for (SIGA_VT_AHEAD=1): on the 16-core boxes the phases of `siga overlap` already keep every core busy, and
+// text made early is text the name ranks and the index load wait for (20 M reads 1.53 s without, 1.84-1.95 s with).
+static bool vt_ahead_wanted() {
+  const char* env = getenv("SIGA_VT_AHEAD");
+  return env && atoi(env) > 0 && getenv("SIGA_NO_VT_AHEAD") == nullptr;
+}
 
 void OverlapBuilder::preload(const std::string& input, size_t threads, long minOverlap, const std::string& output) const {
   const unsigned nt = host_threads(threads);
@@ -1773,11 +1836,11 @@ void OverlapBuilder::preload(const std::string& input, size_t threads, long minO
   PhaseTimer pt;
   p->ok = LoadReads(input, &p->reads, nt);
   pt.lap("  reads parsed");
-  // the VT lines start now, beside the name ranks and the index on its way to the GPU
-  if (p->ok && minOverlap >= 0 && !output.empty() && vt_ahead_wanted())
-    p->ahead.reset(new VtAhead(nullptr, &p->reads, nt, asqg_header((size_t)minOverlap), OutFile::gz_name(output)));
   if (p->ok) name_ranks(p->reads, nt, &p->lengths, &p->ranks);
   pt.lap("  names ranked");
+  // (an option) the VT lines start now, while the index is still on its way to the GPU
+  if (p->ok && minOverlap >= 0 && !output.empty() && vt_ahead_wanted())
+    p->ahead.reset(new VtAhead(nullptr, &p->reads, nt, asqg_header((size_t)minOverlap), OutFile::gz_name(output)));
   _pre = p;
 }
 

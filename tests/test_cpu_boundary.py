@@ -486,7 +486,7 @@ def test_asqg_text_formatters_without_a_gpu(tmp_path, gz):
 @pytest.mark.parametrize("threads,cap", [(1, None), (3, "1")])
 def test_vt_lines_ahead_give_the_in_order_file(tmp_path, threads, cap, monkeypatch):
     """VT lines ahead of the batches (siga_host.cpp, VtAhead: text with SS:i:0 and its 1 MiB deflate blocks made before the
-    substring flags are known) against the in-order path (SIGA_NO_VT_AHEAD=1) and the Python mirror: the .asqg.gz files are
+    substring flags are known; SIGA_VT_AHEAD=1) against the in-order path and the Python mirror: the .asqg.gz files are
     the same BYTES -- with clean stretches (blocks used as they are), stretches with substring reads (chunks formatted
     again, their blocks deflated by the writer), text taken in pieces that do not line up with the chunks, several waves with
     a carried tail, and a cap that keeps the threads one wave ahead of the writer."""
@@ -505,6 +505,7 @@ def test_vt_lines_ahead_give_the_in_order_file(tmp_path, threads, cap, monkeypat
     ed = np.zeros(3, dtype=EDGE_DTYPE)
     ed[:] = [(0, 1, 50, 0), (2, 3, 60, 1), (n - 1, 0, 45, 2)]
     monkeypatch.setenv("SIGA_BATCH_READS", "7001")
+    monkeypatch.setenv("SIGA_VT_AHEAD", "1")
     if cap:
         monkeypatch.setenv("SIGA_VT_AHEAD_BYTES", cap)
     ahead = str(tmp_path / "a.asqg.gz")
@@ -514,6 +515,11 @@ def test_vt_lines_ahead_give_the_in_order_file(tmp_path, threads, cap, monkeypat
     assert host.format_asqg(fa, sub, ed, 45, plain, threads=threads) == n
     a, p = open(ahead, "rb").read(), open(plain, "rb").read()
     assert a == p and len(a) > 1 << 20
+    monkeypatch.setenv("SIGA_SYNC_WRITE", "1")  # the caller writes the file itself instead of the writer's thread
+    sync = str(tmp_path / "s.asqg.gz")
+    assert host.format_asqg(fa, sub, ed, 45, sync, threads=threads) == n
+    assert open(sync, "rb").read() == p
+    monkeypatch.delenv("SIGA_SYNC_WRITE")
     text = gzip.decompress(a).decode("latin-1")
     assert text.count("SS:i:1") == 7 and len(text) > 12 << 20
     assert text == format_asqg(read_sequences(fa), {"substring": sub, "edges": ed}, 45)
