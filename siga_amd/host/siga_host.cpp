@@ -2042,6 +2042,13 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
     format_edge_text(reads, read_len, e, cnt, nt, max_name, ed_chunk, parts);
   };
   const size_t vt_chunk = 4096;
+  edges.reserve(nbatch);    // (the edge-text job of a batch keeps its slots while the next batch is taken)
+  ed_text.reserve(nbatch);
+  std::thread ed_job;
+  auto join_ed = [&] {
+    if (ed_job.joinable()) ed_job.join();
+  };
+  const bool ed_inline = getenv("SIGA_ED_INLINE") != nullptr;
   std::vector<uint8_t> sub_all;  // (VT lines ahead) the substring flags of the reads whose chunk is not out yet
   size_t ahead_from = 0;
   if (ahead) sub_all.assign(n, 0);
@@ -2090,14 +2097,22 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
     }
     edges.emplace_back(r.edges, r.n_edges);
     ed_text.emplace_back();
+    join_ed();  // (one batch's edge text at a time; ed_held is the job's to update, ours to read after the join)
     if (ed_held < ed_hold_max) {
-      format_edges(r.edges, r.n_edges, &ed_text.back());
-      for (const std::string& p : ed_text.back()) ed_held += p.size();
-      if (ed_text.back().empty()) ed_text.back().emplace_back();  // "formatted, and nothing to say"
-      sigax_free(r.edges);
-      edges.back().first = nullptr;
+      const size_t k = edges.size() - 1;
+      auto job = [&, k] {
+        format_edges(edges[k].first, edges[k].second, &ed_text[k]);
+        for (const std::string& p : ed_text[k]) ed_held += p.size();
+        if (ed_text[k].empty()) ed_text[k].emplace_back();  // "formatted, and nothing to say"
+        sigax_free(edges[k].first);
+        edges[k].first = nullptr;
+      };
+      // beside the next batch's VT lines (SIGA_ED_INLINE=1: before them, on this thread)
+      if (ed_inline) job();
+      else ed_job = std::thread(job);
     }
   }
+  join_ed();
   for (auto& t : workers) t.join();
   drop_replicas();
   auto free_edges = [&] {
