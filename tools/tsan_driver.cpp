@@ -72,6 +72,26 @@ int main(int argc, char** argv) {
       if (std::string(ext) == ".asqg") { const std::string got = slurp(out); if (t == 1) ref = got; else check(got == ref, "ASQG text independent of threads"); }
     }
   }
+  {  // VT lines ahead of their flags (its own threads + the writer's thread) and the caller-written file: the same bytes
+    const std::string base = slurp(dir + "/tsan_fmt_4.asqg.gz");
+    auto again = [&](int t, const char* what) {
+      const std::string out = dir + "/tsan_ahead.asqg.gz";
+      check(sigah_format_asqg(reads.c_str(), sub.data(), ed.data(), ed.size(), 45, out.c_str(), t) == n, what);
+      check(slurp(out) == base, what);
+    };
+    setenv("SIGA_VT_AHEAD", "1", 1);
+    setenv("SIGA_BATCH_READS", "3001", 1);
+    again(1, "VT lines ahead, 1 thread");
+    again(4, "VT lines ahead, 4 threads");
+    setenv("SIGA_VT_AHEAD_BYTES", "1", 1);
+    again(3, "VT lines ahead, one wave at a time");
+    unsetenv("SIGA_VT_AHEAD_BYTES");
+    unsetenv("SIGA_VT_AHEAD");
+    unsetenv("SIGA_BATCH_READS");
+    setenv("SIGA_SYNC_WRITE", "1", 1);
+    again(4, "file written by the caller");
+    unsetenv("SIGA_SYNC_WRITE");
+  }
   check(sigah_write_file((dir + "/tsan_w.gz").c_str(), fa.data(), fa.size(), 37) == 0, "gz writer in pieces");
   char err[512];
   std::string ib[4];
