@@ -2044,6 +2044,7 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
   const size_t vt_chunk = 4096;
   edges.reserve(nbatch);    // (the edge-text job of a batch keeps its slots while the next batch is taken)
   ed_text.reserve(nbatch);
+  std::vector<std::string> vt_parts;
   std::thread ed_job;
   auto join_ed = [&] {
     if (ed_job.joinable()) ed_job.join();
@@ -2054,6 +2055,7 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
   if (ahead) sub_all.assign(n, 0);
   for (size_t b = 0; b < nbatch; ++b) {
     BatchOut r;
+    const auto tw0 = std::chrono::steady_clock::now();
     {
       std::unique_lock<std::mutex> g(pl.mu);
       pl.cv.wait(g, [&] { return pl.out[b].ready || pl.failed; });
@@ -2063,6 +2065,7 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
     }
     const size_t lo = b * per, cnt = std::min(per, n - lo);
     const auto tv0 = std::chrono::steady_clock::now();
+    const double wait_s = std::chrono::duration<double>(tv0 - tw0).count();
     auto tv1 = tv0;
     if (ahead) {
       // every chunk of text whose reads are all back (the chunks do not know about batches)
@@ -2077,10 +2080,13 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
         ahead_from = to;
       }
     } else {
-      std::vector<std::string> parts((cnt + vt_chunk - 1) / vt_chunk);
+      // (the strings keep their room from batch to batch: 165 MB of fresh 4 KB pages per batch otherwise)
+      std::vector<std::string>& parts = vt_parts;
+      parts.resize((cnt + vt_chunk - 1) / vt_chunk);
       parallel_for(parts.size(), nt, [&](size_t c) {
         const size_t cb = c * vt_chunk, ce = std::min(cnt, cb + vt_chunk);
         std::string& o = parts[c];
+        o.clear();
         o.reserve((ce - cb) * (maxLen + 32));
         for (size_t i = cb; i < ce; ++i) write_vertex(o, reads.name(lo + i), reads.comment(lo + i), reads.seq(lo + i), r.substring[i] != 0);
       });
@@ -2097,11 +2103,16 @@ bool OverlapBuilder::build(const std::string& input, size_t minOverlap, const st
     }
     edges.emplace_back(r.edges, r.n_edges);
     ed_text.emplace_back();
+    const auto tj0 = std::chrono::steady_clock::now();
     join_ed();  // (one batch's edge text at a time; ed_held is the job's to update, ours to read after the join)
+    if (pt.on) fprintf(stderr, "[siga]   batch %zu: waited %.3f s for the batch, %.3f s for the ED text before it\n", b, wait_s,
+                       std::chrono::duration<double>(std::chrono::steady_clock::now() - tj0).count());
     if (ed_held < ed_hold_max) {
       const size_t k = edges.size() - 1;
       auto job = [&, k] {
+        const auto te0 = std::chrono::steady_clock::now();
         format_edges(edges[k].first, edges[k].second, &ed_text[k]);
+        if (pt.on) fprintf(stderr, "[siga]   batch %zu: ED text %.3f s\n", k, std::chrono::duration<double>(std::chrono::steady_clock::now() - te0).count());
         for (const std::string& p : ed_text[k]) ed_held += p.size();
         if (ed_text[k].empty()) ed_text[k].emplace_back();  // "formatted, and nothing to say"
         sigax_free(edges[k].first);
