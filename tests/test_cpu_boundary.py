@@ -528,3 +528,24 @@ def test_vt_lines_ahead_give_the_in_order_file(tmp_path, threads, cap, monkeypat
     raw = str(tmp_path / "a.asqg")
     assert host.format_asqg(fa, sub, ed, 45, raw, threads=threads) == n
     assert open(raw, "rb").read().decode("latin-1") == text
+
+
+@pytest.mark.parametrize("sync", [False, True])
+@pytest.mark.parametrize("name", ["/dev/full", "/dev/full.gz"])
+def test_a_short_write_is_an_error_whichever_thread_writes(name, sync, monkeypatch):
+    """Utils::ofstream as used for the ASQG (src/utils.cpp:92-126; a failed stream makes OverlapBuilder::build return false,
+    src/overlap_builder.cpp:425-427): a device that takes no bytes must surface as an error from close(), with the file written
+    by the writer's own thread (default) or by the caller (SIGA_SYNC_WRITE=1), plain or gzip."""
+    from siga_amd import host
+    if not os.path.exists("/dev/full"):
+        pytest.skip("no /dev/full here")
+    if sync:
+        monkeypatch.setenv("SIGA_SYNC_WRITE", "1")
+    if name.endswith(".gz"):  # (a name the writer treats as gzip: a link to the device)
+        import tempfile
+        d = tempfile.mkdtemp()
+        name = os.path.join(d, "full.gz")
+        os.symlink("/dev/full", name)
+    data = np.random.default_rng(3).integers(65, 90, size=5 << 20, dtype=np.uint8).tobytes()
+    with pytest.raises(IOError):
+        host.write_file(name, data, pieces=7)
